@@ -1,0 +1,64 @@
+"""Seeded synthetic checkpoints and inputs (no network, no weights on disk - BASELINE.md §4).
+
+Weights follow the diffusers key layout of ``arch.py`` so a real checkpoint is a drop-in.
+Each tensor is drawn from its own CPU generator seeded by crc32(key) ^ seed, so the values do
+not depend on enumeration order.  Conv/Linear weights ~ N(0, gain/fan_in); norm affine
+parameters are non-trivial (gamma = 1 + 0.1 n, beta = 0.1 n) so the affine paths are tested.
+Inputs follow SURVEY.md §8(d): smooth low-frequency RGB image, fixed text context, initial
+latents drawn from a CPU generator.
+"""
+import zlib
+
+import torch
+
+from .arch import UNetConfig, VAEConfig, unet_param_shapes, vae_param_shapes
+
+
+def _draw(key, shape, seed):
+    g = torch.Generator("cpu").manual_seed((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+    leaf = key.rsplit(".", 2)
+    is_norm = any(s in key for s in ("norm", "group_norm"))
+    if key.endswith(".weight") and len(shape) >= 2:
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        return torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5
+    if key.endswith(".weight") and is_norm:
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    if key.endswith(".bias") and is_norm:
+        return 0.1 * torch.randn(shape, generator=g)
+    del leaf
+    return 0.05 * torch.randn(shape, generator=g)  # conv / linear bias
+
+
+def synthetic_state_dict(shapes, seed):
+    return {k: _draw(k, tuple(s), seed) for k, s in shapes.items()}
+
+
+def synthetic_unet_state_dict(cfg: UNetConfig = UNetConfig(), seed: int = 1234):
+    return synthetic_state_dict(unet_param_shapes(cfg), seed)
+
+
+def synthetic_vae_state_dict(cfg: VAEConfig = VAEConfig(), seed: int = 1234):
+    return synthetic_state_dict(vae_param_shapes(cfg), seed + 1)
+
+
+def synthetic_text_embedding(cross_dim: int = 1024, seed: int = 7):
+    """Stands in for CLIP("") with padding="do_not_pad": 2 tokens
+    (/root/reference/marigold/marigold_depth_pipeline.py:381-394)."""
+    g = torch.Generator("cpu").manual_seed(seed)
+    return torch.randn(1, 2, cross_dim, generator=g)
+
+
+def synthetic_image(height: int = 768, width: int = 768, seed: int = 0):
+    """uint8 [1,3,H,W]: low-frequency content (random 24x24 grid, bilinear up-sampled)."""
+    g = torch.Generator("cpu").manual_seed(seed)
+    coarse = torch.rand(1, 3, 24, 24, generator=g)
+    img = torch.nn.functional.interpolate(coarse, size=(height, width), mode="bilinear",
+                                          align_corners=False)
+    return (img * 255.0).round().clamp(0, 255).to(torch.uint8)
+
+
+def synthetic_latents(n, h, w, seed: int = 2024, dtype=torch.float32):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return torch.randn(n, 4, h, w, generator=g, dtype=dtype)

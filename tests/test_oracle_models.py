@@ -1,0 +1,104 @@
+"""Structural + golden checks of the oracle's UNet / VAE / scheduler restatements."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from marigold_amd import synthetic as syn
+from marigold_amd.arch import (TINY_UNET, TINY_VAE, UNetConfig, unet_param_shapes,
+                               unet_up_resnet_channels, vae_param_shapes)
+from oracle import pipeline as opipe
+from oracle.schedulers import DDIMScheduler, LCMScheduler
+from oracle.sd2_unet import UNet2DConditionModel
+from oracle.sd2_vae import AutoencoderKL
+
+
+def _count(d, *prefixes):
+    return sum(math.prod(s) for k, s in d.items() if k.startswith(prefixes))
+
+
+def test_param_counts_match_published_sd2():
+    u, v = unet_param_shapes(), vae_param_shapes()
+    assert round(_count(u, "") / 1e6, 2) == 865.92
+    assert round(_count(v, "encoder", "quant_conv") / 1e6, 2) == 34.16
+    assert round(_count(v, "decoder", "post_quant_conv") / 1e6, 2) == 49.49
+
+
+def test_state_dict_keys_match_arch_tables():
+    with torch.device("meta"):
+        m, a = UNet2DConditionModel(), AutoencoderKL()
+    assert {k: tuple(p.shape) for k, p in m.state_dict().items()} == dict(unet_param_shapes())
+    assert {k: tuple(p.shape) for k, p in a.state_dict().items()} == dict(vae_param_shapes())
+
+
+def test_skip_stack_widths():
+    rows = unet_up_resnet_channels(UNetConfig())
+    assert [r[2] + r[3] for r in rows] == [2560, 2560, 2560, 2560, 2560, 1920,
+                                            1920, 1280, 960, 960, 640, 640]
+
+
+def test_scheduler_tables(golden_dir):
+    g = np.load(os.path.join(golden_dir, "scheduler_tables.npz"))
+    for n in (10, 4, 1):
+        s = DDIMScheduler()
+        s.set_timesteps(n)
+        assert s.timesteps.tolist() == g[f"ddim_trailing_{n}"].tolist()
+    for n in (10, 1):
+        s = DDIMScheduler(timestep_spacing="leading", rescale_betas_zero_snr=False)
+        s.set_timesteps(n)
+        assert s.timesteps.tolist() == g[f"ddim_leading_{n}"].tolist()
+    for n in (4, 1):
+        s = LCMScheduler()
+        s.set_timesteps(n)
+        assert s.timesteps.tolist() == g[f"lcm_{n}"].tolist()
+    z = DDIMScheduler()
+    assert float(z.alphas_cumprod[999]) == 0.0          # zero terminal SNR
+    assert abs(float(z.alphas_cumprod[0]) - 0.99915) < 1e-4
+
+
+def test_zero_snr_first_step_is_minus_v():
+    s = DDIMScheduler()
+    s.set_timesteps(1)
+    x, v = torch.randn(1, 4, 4, 4), torch.randn(1, 4, 4, 4)
+    out = s.step(v, 999, x)
+    torch.testing.assert_close(out.pred_original_sample, -v)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    unet = UNet2DConditionModel(block_out_channels=TINY_UNET.block_out_channels,
+                                attention_head_dim=TINY_UNET.heads,
+                                cross_attention_dim=TINY_UNET.cross_attention_dim).eval()
+    unet.load_state_dict(syn.synthetic_unet_state_dict(TINY_UNET))
+    vae = AutoencoderKL(block_out_channels=TINY_VAE.block_out_channels).eval()
+    vae.load_state_dict(syn.synthetic_vae_state_dict(TINY_VAE))
+    return unet, vae
+
+
+def test_tiny_pipeline_golden(tiny, golden_dir):
+    unet, vae = tiny
+    g = np.load(os.path.join(golden_dir, "tiny_pipeline.npz"))
+    ctx = syn.synthetic_text_embedding(TINY_UNET.cross_attention_dim)
+    img = syn.synthetic_image(64, 128, seed=0)
+    lat0 = syn.synthetic_latents(3, 8, 16, seed=2024)
+    rgb = img.float() / 255.0 * 2.0 - 1.0
+    with torch.no_grad():
+        rl = opipe.encode_rgb(vae, rgb)
+        np.testing.assert_allclose(rl.numpy(), g["rgb_latent"], atol=1e-4)
+        d = opipe.single_infer("depth", unet, vae, DDIMScheduler(), rgb.expand(3, -1, -1, -1),
+                               lat0, ctx, 4)
+        np.testing.assert_allclose(d.numpy(), g["depth_ddim4"], atol=1e-3)
+        gen = torch.Generator("cpu").manual_seed(99)
+        dl = opipe.single_infer("depth", unet, vae, LCMScheduler(), rgb, lat0[:1], ctx, 3,
+                                generator=gen)
+        np.testing.assert_allclose(dl.numpy(), g["depth_lcm3"], atol=1e-3)
+
+
+def test_unet_odd_latent_size_uses_upsample_size(tiny):
+    unet, _ = tiny
+    x = torch.randn(1, 8, 12, 20)
+    y = unet(x, torch.tensor(500), torch.randn(1, 2, TINY_UNET.cross_attention_dim)).sample
+    assert y.shape == (1, 4, 12, 20)
