@@ -1,0 +1,172 @@
+/*
+ * marigold_hip.h - C ABI of libmarigold_hip.so, the MI355X (gfx950) engine behind the
+ * Marigold inference hot path.
+ *
+ * The reference has no FFI: its hot path sits behind Python module attributes registered on
+ * the pipeline (marigold/marigold_depth_pipeline.py:133-139) whose arithmetic lives in
+ * diffusers/torch.  Each entry point below replaces one of those call sites (cited per op).
+ * Plain pointers and sizes only: device pointers are raw HIP device addresses, `stream` is a
+ * hipStream_t passed as void*.  All functions return 0 on success, non-zero on error
+ * (message via mg_last_error()).  Activations are bf16 NHWC ([B][H][W][C] == [B*H*W][C]
+ * token-major); latents and decoded maps at the pipeline boundary are fp32 NCHW like the
+ * reference's tensors.
+ *
+ * Every kernel launch is described by one fixed-size `mg_op`; a sequence of them is a
+ * *program* (mg_program_*) that the library replays with no host logic in between (and
+ * optionally as a captured hipGraph).  The Python host mirrors the reference's
+ * unet/vae/scheduler interface by building such programs (marigold_amd/unet_program.py ...).
+ */
+#ifndef MARIGOLD_HIP_H
+#define MARIGOLD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_ABI_VERSION 1
+
+enum mg_op_kind {
+  /* conv3x3 / conv1x1 / Linear / batched GEMM as ONE implicit-GEMM bf16 MFMA kernel.
+   * Replaces torch conv2d / linear / matmul inside diffusers UNet2DConditionModel and
+   * AutoencoderKL (reference call sites marigold_depth_pipeline.py:461-463, 491-492, 512-513).
+   *  p[0] A bf16 [B][H][W][lda>=Cin]   p[1] Wt bf16 [N][ldw>=taps*Cin] (k = (ky*3+kx)*Cin+c)
+   *  p[2] out                          p[3] bias f32[N] | NULL
+   *  p[4] rowvec f32 [B][N] | NULL (time-embedding add)   p[5] residual bf16 [M][ldr] | NULL
+   *  p[6] out2 (transposed section)    i[0] B  i[1] H  i[2] W  i[3] Cin  i[4] Ho  i[5] Wo
+   *  i[6] N  i[7] taps(1|9)  i[8] stride  i[9] pad  i[10] Hu  i[11] Wu (virtual nearest-
+   *  upsampled input size, 0 = none)  i[12] epilogue (MG_EPI_*)  i[13] ldo  i[14] trans_from
+   *  (columns >= this go to out2 as [img][n-trans_from][ldt] transposed; -1 = none)
+   *  i[15] batch_z  i[16] ldr  i[17] lda  i[18] ldt  i[19] tile variant (0 = auto)  i[20] ldw
+   *  l[0..3] z-strides (elements) of A, Wt, out, residual      f[0] scale on the accumulator */
+  MG_OP_IGEMM = 1,
+  /* GroupNorm, 3 launches (stats partials -> per-(b,c) scale/shift -> apply [+SiLU]).
+   * Replaces torch group_norm + silu in every ResNet block / Transformer2D input norm.
+   *  STATS:    p[0] x bf16 [B][HW][C]  p[1] partials f32 [B][chunks][C][2]; i: B,HW,C,chunks
+   *  FINALIZE: p[0] partials p[1] gamma f32 p[2] beta f32 p[3] scale_shift f32 [B][C][2];
+   *            i: B,C,groups,chunks,HW ; f[0] eps
+   *  APPLY:    p[0] x  p[1] scale_shift  p[2] out bf16 ; i: B,HW,C,silu */
+  MG_OP_GN_STATS = 2,
+  MG_OP_GN_FINALIZE = 3,
+  MG_OP_GN_APPLY = 4,
+  /* LayerNorm over the last dim. p[0] x bf16 [M][C] p[1] gamma f32 p[2] beta f32 p[3] out;
+   * i: M,C ; f[0] eps */
+  MG_OP_LAYERNORM = 5,
+  /* Self-attention core, head dim 64, bf16 MFMA flash attention with LDS-staged K / V^T
+   * tiles (replaces diffusers Attention / SDPA / xformers, run.py:217-220).
+   *  p[0] Q bf16 (row stride ldq)  p[1] K (row stride ldq)  p[2] Vt bf16 [B][heads*64][ldvt]
+   *  p[3] O bf16 (row stride ldo); i: B, heads, Ntok, ldq, ldo, ldvt ;
+   *  l[0] q batch stride l[1] k batch stride l[2] vt batch stride l[3] o batch stride;
+   *  f[0] softmax scale */
+  MG_OP_FLASH_ATTN64 = 6,
+  /* Row softmax fp32 -> bf16 (VAE single-head d=512 attention, materialised scores).
+   *  p[0] S f32 [R][lds] p[1] P bf16 [R][ldp] ; i: R, ncols, lds, ldp (pad cols zeroed) */
+  MG_OP_SOFTMAX_ROWS = 7,
+  /* Pairwise softmax for cross-attention against the 2-token empty-prompt context
+   * (marigold_depth_pipeline.py:381-394, 438-442).  With only 2 keys per head the attention
+   * collapses algebraically to  scores = LN(x) @ Wqk^T  (Wqk[(h,j)] = Wq_h^T k_{j,h}),
+   * p = softmax over the key pair, out = p @ VO + bias + x  (VO[(h,j)] = Wo[:,h] v_{j,h});
+   * the two thin GEMMs run on MG_OP_IGEMM, this op is the softmax between them.
+   *  p[0] S f32 [M][lds]  p[1] P bf16 [M][ldp] ; i: M, pairs(=heads), lds, ldp ;
+   *  f[0] softmax scale.  Columns >= 2*pairs of P are zero-filled up to ldp. */
+  MG_OP_SOFTMAX_PAIRS = 8,
+  /* Direct conv3x3 (pad 1) from <= 8 fp32 NCHW channels (two sources: rgb latent + target
+   * latent, folding the torch.cat of marigold_depth_pipeline.py:456-458) to bf16 NHWC.
+   *  p[0] src0 f32 [B|1][C0][H][W]  p[1] src1 f32 [B][C1][H][W] | NULL
+   *  p[2] W f32 [Cout][9][C0+C1]  p[3] bias f32  p[4] out bf16 [B][H][W][Cout];
+   *  i: B,H,W,C0,C1,Cout, src0_broadcast */
+  MG_OP_CONV_CIN_SMALL = 9,
+  /* Direct conv3x3 (pad 1) bf16 NHWC -> <= 8 fp32 NCHW channels with the pipeline's pointwise
+   * tail fused (MG_POST_*: depth = mean over channels, clip, (x+1)/2 - marigold_depth_
+   * pipeline.py:515,473-475; normals = clip, L2 normalise - marigold_normals_pipeline.py:
+   * 438-440).  p[0] x bf16  p[1] W f32 [Cout][9][Cin]  p[2] bias f32  p[3] out f32 NCHW;
+   *  i: B,H,W,Cin,Cout,post ; f[0] output scale */
+  MG_OP_CONV_COUT_SMALL = 10,
+  /* Channel concat of two NHWC tensors (UNet skip connections).  p[0] a [M][C1] p[1] b [M][C2]
+   * p[2] out [M][C1+C2]; i: M,C1,C2 */
+  MG_OP_CONCAT_C = 11,
+  /* Scheduler update (DDIM / LCM, diffusers *.step at marigold_depth_pipeline.py:466-468):
+   * out = f[0]*x + f[1]*model_out + f[2]*noise.  p[0] x f32 p[1] model_out f32
+   * p[2] noise f32 | NULL  p[3] out f32 ; l[0] n elements */
+  MG_OP_SCHED_STEP = 12,
+  /* Small-M dense layer in fp32 (time-embedding MLP and per-ResNet projections):
+   * out[m][n] = act_out(sum_k act_in(in[m][k]) * W[n][k] + b[n]).
+   *  p[0] in f32 [M][K] p[1] W f32 [N][K] p[2] b f32|NULL p[3] out f32 [M][ldo];
+   *  i: M,N,K,act_in,act_out(0 none,1 silu),ldo */
+  MG_OP_LINEAR_SMALL_M = 13,
+  /* 1x1 conv on fp32 NCHW latents with input scale (post_quant_conv after /0.18215,
+   * marigold_depth_pipeline.py:510-512).  p[0] in f32 [B][Ci][HW] p[1] W f32 [Co][Ci]
+   * p[2] b f32 p[3] out f32 [B][Co][HW] ; i: B,Ci,Co,HW ; f[0] input scale */
+  MG_OP_LATENT_1X1 = 14,
+  /* Test-time ensembling (marigold/util/ensemble.py).
+   * DEPTH_STATS : one pass over [E][HW]: per-member min,max,mean and the centred E x E
+   *               second-moment matrix (closed form of the pairwise-RMSE cost, :138-145).
+   *   p[0] d f32 [E][HW] p[1] blocks f64 scratch p[2] out f64 [3E + E*E] ; i: E ; l[0] HW
+   * DEPTH_MEDIAN: aligned = s*d+t; lower-middle median over E (+MAD); block min/max.
+   *   p[0] d f32 [E][HW] p[1] st f32 [2E] p[2] med f32 [HW]|NULL p[3] mad f32 [HW]|NULL
+   *   p[4] minmax f32 [2] (final, via last-block reduce) p[5] scratch ; i: E, reduction(0
+   *   median,1 mean) ; l[0] HW
+   * DEPTH_NORM  : out = (med - lo)/range ; unc /= range.  p[0] med p[1] mad|NULL p[2] minmax
+   *   ; i[0] shift_invariant ; l[0] HW
+   * NORMALS     : p[0] n f32 [E][3][HW] p[1] out f32 [3][HW] p[2] unc f32 [HW]|NULL ;
+   *   i: E, reduction(0 closest,1 mean) ; l[0] HW */
+  MG_OP_ENS_DEPTH_STATS = 20,
+  MG_OP_ENS_DEPTH_MEDIAN = 21,
+  MG_OP_ENS_DEPTH_NORM = 22,
+  MG_OP_ENS_NORMALS = 23,
+  MG_OP_MEMSET = 30, /* p[0] dst ; i[0] byte value ; l[0] bytes */
+  MG_OP_COPY = 31    /* p[0] src p[1] dst ; l[0] bytes (device to device) */
+};
+
+enum { MG_EPI_BF16 = 0, MG_EPI_GEGLU = 1, MG_EPI_F32 = 2 };
+enum { MG_POST_NONE = 0, MG_POST_DEPTH = 1, MG_POST_NORMALS = 2 };
+
+typedef struct mg_op {
+  int32_t kind;
+  int32_t i[24];
+  float f[8];
+  void* p[8];
+  int64_t l[4];
+} mg_op;
+
+typedef struct mg_program mg_program;
+
+/* Library / device */
+int mg_abi_version(void);
+const char* mg_last_error(void);
+int mg_init(int device);                 /* idempotent; allocates the zero page */
+int mg_device_info(int* cu_count, int* lds_bytes, int64_t* hbm_bytes, char* arch, int arch_len);
+
+/* One launch (also the body of mg_program_run) */
+int mg_launch(const mg_op* op, void* stream);
+
+/* Programs: replace the per-step Python loop of single_infer
+ * (marigold_depth_pipeline.py:455-468) and the module forwards it calls. */
+mg_program* mg_program_create(const mg_op* ops, int n_ops);
+int mg_program_num_ops(const mg_program* prog);
+int mg_program_run(mg_program* prog, void* stream);
+int mg_program_run_range(mg_program* prog, int first, int count, void* stream);
+/* Capture the program into a hipGraph on `stream` and replay that on later runs. */
+int mg_program_capture(mg_program* prog, void* stream);
+/* Time every op with HIP events on `stream` (ms per op written to `ms`, length n_ops). */
+int mg_program_profile(mg_program* prog, void* stream, float* ms);
+void mg_program_destroy(mg_program* prog);
+
+/* Named wrappers - what a binding for the reference's seams would call directly. */
+int mg_conv2d_igemm(const mg_op* conv_desc, void* stream);   /* kind must be MG_OP_IGEMM */
+int mg_sched_step(const float* x, const float* model_out, const float* noise, float* out,
+                  int64_t n, float cx, float cm, float cn, void* stream);
+int mg_ensemble_normals(const float* normals, float* out, float* unc, int E, int64_t hw,
+                        int reduction, void* stream);
+
+/* HIP-event timing helpers for bench.py (the kernels run on the caller's stream). */
+void* mg_event_create(void);
+int mg_event_record(void* ev, void* stream);
+int mg_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+void mg_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARIGOLD_HIP_H */

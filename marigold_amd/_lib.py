@@ -1,0 +1,101 @@
+"""ctypes binding of libmarigold_hip.so (C ABI in include/marigold_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or does not export the ABI
+this module raises, loudly.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+(or ``make -C marigold_amd/csrc``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmarigold_hip.so")
+ABI_VERSION = 1
+
+# enum mg_op_kind
+OP_IGEMM, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_LAYERNORM = 1, 2, 3, 4, 5
+OP_FLASH_ATTN64, OP_SOFTMAX_ROWS, OP_SOFTMAX_PAIRS = 6, 7, 8
+OP_CONV_CIN_SMALL, OP_CONV_COUT_SMALL, OP_CONCAT_C, OP_SCHED_STEP = 9, 10, 11, 12
+OP_LINEAR_SMALL_M, OP_LATENT_1X1 = 13, 14
+OP_ENS_DEPTH_STATS, OP_ENS_DEPTH_MEDIAN, OP_ENS_DEPTH_NORM, OP_ENS_NORMALS = 20, 21, 22, 23
+OP_MEMSET, OP_COPY = 30, 31
+EPI_BF16, EPI_GEGLU, EPI_F32 = 0, 1, 2
+POST_NONE, POST_DEPTH, POST_NORMALS = 0, 1, 2
+
+OP_NAMES = {v: k[3:].lower() for k, v in list(globals().items()) if k.startswith("OP_")}
+
+EXPORTS = [
+    "mg_abi_version", "mg_last_error", "mg_init", "mg_device_info", "mg_launch",
+    "mg_program_create", "mg_program_num_ops", "mg_program_run", "mg_program_run_range",
+    "mg_program_capture", "mg_program_profile", "mg_program_destroy", "mg_conv2d_igemm",
+    "mg_sched_step", "mg_ensemble_normals", "mg_event_create", "mg_event_record",
+    "mg_event_elapsed_ms", "mg_event_destroy",
+]
+
+
+class MgOp(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("i", ctypes.c_int32 * 24), ("f", ctypes.c_float * 8),
+                ("p", ctypes.c_void_p * 8), ("l", ctypes.c_int64 * 4)]
+
+
+class MarigoldHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no GPU needed) and check that every ABI symbol is exported."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MarigoldHipError(
+            f"{LIB_PATH} not found: the HIP engine is not built. Run __graft_entry__.build() "
+            f"(make -C marigold_amd/csrc). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in EXPORTS if not hasattr(lib, s)]
+    if missing:
+        raise MarigoldHipError(f"{LIB_PATH} lacks ABI symbols: {missing}")
+    lib.mg_last_error.restype = ctypes.c_char_p
+    lib.mg_launch.argtypes = [ctypes.POINTER(MgOp), ctypes.c_void_p]
+    lib.mg_conv2d_igemm.argtypes = [ctypes.POINTER(MgOp), ctypes.c_void_p]
+    lib.mg_program_create.restype = ctypes.c_void_p
+    lib.mg_program_create.argtypes = [ctypes.POINTER(MgOp), ctypes.c_int]
+    lib.mg_program_num_ops.argtypes = [ctypes.c_void_p]
+    lib.mg_program_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.mg_program_run_range.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.mg_program_capture.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.mg_program_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    lib.mg_program_destroy.argtypes = [ctypes.c_void_p]
+    lib.mg_program_destroy.restype = None
+    lib.mg_sched_step.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_float] * 3 + [ctypes.c_void_p]
+    lib.mg_ensemble_normals.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    lib.mg_device_info.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                   ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_int]
+    lib.mg_event_create.restype = ctypes.c_void_p
+    lib.mg_event_record.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.mg_event_elapsed_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    lib.mg_event_destroy.argtypes = [ctypes.c_void_p]
+    lib.mg_event_destroy.restype = None
+    if lib.mg_abi_version() != ABI_VERSION:
+        raise MarigoldHipError(f"ABI version mismatch: library {lib.mg_abi_version()}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what="libmarigold_hip"):
+    if rc != 0:
+        raise MarigoldHipError(f"{what}: {load().mg_last_error().decode(errors='replace')}")
+
+
+_inited = set()
+
+
+def init(device_index=0):
+    """Bind the library to a GPU (one process drives one GPU)."""
+    lib = load()
+    if device_index not in _inited:
+        check(lib.mg_init(int(device_index)), "mg_init")
+        _inited.add(device_index)
+    return lib

@@ -1,0 +1,313 @@
+// Attention kernels.
+//  * flash_attn64: bf16 MFMA flash attention for head dim 64 (SD-v2 UNet self-attention,
+//    seq 9216/2304/576/144 at 768x768).  Replaces diffusers Attention / SDPA / xformers
+//    (reference: script/depth/run.py:217-220; reached from marigold_depth_pipeline.py:461-463).
+//    gfx950 design: 4 waves x 32 queries per workgroup; K tiles [64 keys][64 d] and V^T tiles
+//    [64 d][64 keys] stream global->LDS with global_load_lds (16 B/lane), double buffered,
+//    XOR-swizzled (on the source address) so fragment reads are conflict-free.  QK^T is computed
+//    "swapped" (S^T = K Q^T) so every lane owns ONE query column: the online-softmax row
+//    max/sum are lane-local plus a single lane^32 exchange, and the exponentiated P registers
+//    feed the PV MFMA as its B operand with no cross-lane shuffle - V^T is read from LDS in the
+//    matching key order (two ds_read_b64 per fragment).  V^T itself is produced by the QKV
+//    projection's transposed epilogue (igemm.hip), never by a transpose pass.
+//  * softmax_rows: fp32 -> bf16 row softmax for the VAE's single-head d=512 attention, whose
+//    scores are materialised by the GEMM kernel (288 GB HBM: 340 MB/member is cheap).
+//  * softmax_pairs: 2-key softmax of the collapsed cross-attention (see marigold_hip.h).
+#include "common.h"
+
+namespace {
+
+struct FaArgs {
+  const bf16_t* Q;
+  const bf16_t* K;
+  const bf16_t* Vt;
+  bf16_t* O;
+  const void* zero;
+  int B, heads, Ntok, ldq, ldo, ldvt, nqb;
+  long long sQ, sK, sVt, sO;
+  float scale_log2;
+};
+
+constexpr int FA_QB = 128;   // queries per workgroup (4 waves x 32)
+constexpr int FA_KB = 64;    // keys per tile
+constexpr int FA_STAGE = 2 * FA_KB * 128;  // K tile + V^T tile, bytes
+
+__global__ __launch_bounds__(256) void flash_attn64_kernel(const FaArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = bid % a.nqb;
+  const int bh = bid / a.nqb;
+  const int h = bh % a.heads, b = bh / a.heads;
+
+  const bf16_t* Qb = a.Q + (long long)b * a.sQ + h * 64;
+  const bf16_t* Kb = a.K + (long long)b * a.sK + h * 64;
+  const bf16_t* Vb = a.Vt + (long long)b * a.sVt + (long long)h * 64 * a.ldvt;
+  const char* zero = (const char*)a.zero;
+
+  // Q fragments (MFMA B operand: column = query, k = d): 4 k-steps x 8 bf16
+  const int q_row = qb * FA_QB + wave * 32 + l31;
+  const int q_ld = q_row < a.Ntok ? q_row : a.Ntok - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(Qb + (long long)q_ld * a.ldq + ks * 16 + half * 8));
+
+  // staging: 2 chunks of K and 2 chunks of V^T per thread per tile
+  int st_row[2], st_q[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ci = it * 256 + tid;
+    st_row[it] = ci >> 3;
+    st_q[it] = (ci & 7) ^ ((st_row[it] >> 1) & 7);
+  }
+  auto stage = [&](int kt, int buf) {
+    const int k0 = kt * FA_KB;
+    char* sb = smem + buf * FA_STAGE;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int key = k0 + st_row[it];
+      const char* src = key < a.Ntok ? (const char*)(Kb + (long long)key * a.ldq + st_q[it] * 8) : zero;
+      glds16(src, sb + (it * 256 + wave * 64) * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const char* src = (const char*)(Vb + (long long)st_row[it] * a.ldvt + k0 + st_q[it] * 8);
+      glds16(src, sb + FA_KB * 128 + (it * 256 + wave * 64) * 16);
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int nkt = (a.Ntok + FA_KB - 1) / FA_KB;
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
+    const char* sK = smem + buf * FA_STAGE;
+    const char* sV = sK + FA_KB * 128;
+
+    // ---- S^T = K Q^T : two 32-key sub-tiles ----
+    f32x16 s[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t2][r] = 0.f;
+      const int row = t2 * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int q = ks * 2 + half;
+        const bf16x8 kf = __builtin_bit_cast(
+            bf16x8, *(const uint4*)(sK + row * 128 + ((q ^ ((row >> 1) & 7)) << 4)));
+        s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t2], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (log2 domain); lane owns query l31, keys (r&3)+8(r>>2)+4*half ----
+    const int kbase = kt * FA_KB;
+    float mx = -1e30f;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = s[t2][r] * a.scale_log2;
+        if (kbase + FA_KB > a.Ntok) {
+          const int key = kbase + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= a.Ntok) v = -1e30f;
+        }
+        s[t2][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(s[t2][r] - m_new);
+        s[t2][r] = p;
+        ps += p;
+      }
+    l_run = l_run * alpha + ps;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+    // ---- O^T += V^T P^T : k-step (t2, sh) covers keys 32*t2 + 16*sh + [0,16) ----
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) {
+        uint4 pw;
+        pw.x = pack2bf(s[t2][8 * sh + 0], s[t2][8 * sh + 1]);
+        pw.y = pack2bf(s[t2][8 * sh + 2], s[t2][8 * sh + 3]);
+        pw.z = pack2bf(s[t2][8 * sh + 4], s[t2][8 * sh + 5]);
+        pw.w = pack2bf(s[t2][8 * sh + 6], s[t2][8 * sh + 7]);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+        const int c0 = 4 * t2 + 2 * sh;  // 16-B chunk holding keys 32*t2+16*sh+[0,8)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int row = dt * 32 + l31;
+          const int sw = (row >> 1) & 7;
+          const uint2 v0 = *(const uint2*)(sV + row * 128 + ((c0 ^ sw) << 4) + 8 * half);
+          const uint2 v1 = *(const uint2*)(sV + row * 128 + (((c0 + 1) ^ sw) << 4) + 8 * half);
+          uint4 vw;
+          vw.x = v0.x; vw.y = v0.y; vw.z = v1.x; vw.w = v1.y;
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- finalize: O[q][d] = o^T / l ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (q_row < a.Ntok) {
+    bf16_t* orow = a.O + (long long)b * a.sO + (long long)q_row * a.ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * half;
+        uint2 pk;
+        pk.x = pack2bf(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        pk.y = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *(uint2*)(orow + d) = pk;
+      }
+  }
+}
+
+// one workgroup per row; fp32 scores -> bf16 probabilities, pad columns zeroed
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S,
+                                                           bf16_t* __restrict__ P, int ncols,
+                                                           long long lds_, long long ldp) {
+  __shared__ float red[8];
+  const long long row = blockIdx.x;
+  const float* s = S + row * lds_;
+  bf16_t* p = P + row * ldp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -1e30f;
+  for (int c = tid * 4; c < ncols; c += 1024) {
+    if (c + 3 < ncols) {
+      const float4 v = *(const float4*)(s + c);
+      mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    } else {
+      for (int j = c; j < ncols; ++j) mx = fmaxf(mx, s[j]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int c = tid * 4; c < ncols; c += 1024) {
+    if (c + 3 < ncols) {
+      const float4 v = *(const float4*)(s + c);
+      sum += __expf(v.x - mx) + __expf(v.y - mx) + __expf(v.z - mx) + __expf(v.w - mx);
+    } else {
+      for (int j = c; j < ncols; ++j) sum += __expf(s[j] - mx);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int c = tid * 4; c < ldp; c += 1024) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (c + j < ncols) ? __expf(s[c + j] - mx) * inv : 0.f;
+    if (c + 3 < ldp) {
+      uint2 pk;
+      pk.x = pack2bf(v[0], v[1]);
+      pk.y = pack2bf(v[2], v[3]);
+      *(uint2*)(p + c) = pk;
+    } else {
+      for (int j = 0; c + j < ldp; ++j) p[c + j] = f2bf(v[j]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_pairs_kernel(const float* __restrict__ S,
+                                                            bf16_t* __restrict__ P, long long M,
+                                                            int pairs, int lds_, int ldp,
+                                                            float scale) {
+  const int ppr = ldp >> 1;  // output pairs per row (incl. zero padding)
+  const long long total = M * ppr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    const long long m = i / ppr;
+    const int pr = (int)(i % ppr);
+    uint32_t w = 0;
+    if (pr < pairs) {
+      const float2 s = *(const float2*)(S + m * lds_ + 2 * pr);
+      const float a = s.x * scale, b = s.y * scale;
+      const float mx = fmaxf(a, b);
+      const float ea = __expf(a - mx), eb = __expf(b - mx);
+      const float inv = 1.0f / (ea + eb);
+      w = pack2bf(ea * inv, eb * inv);
+    }
+    *(uint32_t*)(P + m * ldp + 2 * pr) = w;
+  }
+}
+
+}  // namespace
+
+int mg_launch_attention(const mg_op* op, hipStream_t s) {
+  switch (op->kind) {
+    case MG_OP_FLASH_ATTN64: {
+      FaArgs a;
+      a.Q = (const bf16_t*)op->p[0];
+      a.K = (const bf16_t*)op->p[1];
+      a.Vt = (const bf16_t*)op->p[2];
+      a.O = (bf16_t*)op->p[3];
+      a.zero = g_zero_page;
+      a.B = op->i[0]; a.heads = op->i[1]; a.Ntok = op->i[2];
+      a.ldq = op->i[3]; a.ldo = op->i[4]; a.ldvt = op->i[5];
+      a.sQ = op->l[0]; a.sK = op->l[1]; a.sVt = op->l[2]; a.sO = op->l[3];
+      a.scale_log2 = op->f[0] * 1.4426950408889634f;
+      a.nqb = (a.Ntok + FA_QB - 1) / FA_QB;
+      MG_REQUIRE(g_zero_page, "flash_attn64: mg_init() not called");
+      MG_REQUIRE(a.Q && a.K && a.Vt && a.O, "flash_attn64: null pointer");
+      MG_REQUIRE(a.B > 0 && a.heads > 0 && a.Ntok > 0, "flash_attn64: empty problem");
+      MG_REQUIRE(a.ldvt % 64 == 0 && a.ldvt >= a.Ntok, "flash_attn64: ldvt must be a multiple of 64 >= Ntok");
+      MG_REQUIRE(a.ldq % 8 == 0 && a.ldo % 4 == 0, "flash_attn64: bad leading dims");
+      const long long grid = (long long)a.nqb * a.heads * a.B;
+      hipLaunchKernelGGL(flash_attn64_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
+      break;
+    }
+    case MG_OP_SOFTMAX_ROWS: {
+      const int R = op->i[0], ncols = op->i[1], lds_ = op->i[2], ldp = op->i[3];
+      MG_REQUIRE(R > 0 && ncols > 0 && lds_ % 4 == 0 && ldp % 4 == 0 && ldp >= ncols, "softmax_rows: bad dims");
+      hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(256), 0, s, (const float*)op->p[0],
+                         (bf16_t*)op->p[1], ncols, (long long)lds_, (long long)ldp);
+      break;
+    }
+    case MG_OP_SOFTMAX_PAIRS: {
+      const long long M = op->i[0];
+      const int pairs = op->i[1], lds_ = op->i[2], ldp = op->i[3];
+      MG_REQUIRE(M > 0 && pairs > 0 && ldp % 2 == 0 && 2 * pairs <= ldp && lds_ % 2 == 0, "softmax_pairs: bad dims");
+      const long long total = M * (ldp / 2);
+      const int grid = (int)min((total + 255) / 256, (long long)4096);
+      hipLaunchKernelGGL(softmax_pairs_kernel, dim3(grid), dim3(256), 0, s, (const float*)op->p[0],
+                         (bf16_t*)op->p[1], M, pairs, lds_, ldp, op->f[0]);
+      break;
+    }
+    default: MG_REQUIRE(false, "attention: bad op kind %d", op->kind);
+  }
+  MG_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,313 @@
+// On-device test-time ensembling (reference: marigold/util/ensemble.py).
+//
+// Depth (ensemble_depth :39-196).  The reference evaluates, per BFGS cost call, E(E-1)/2
+// pairwise RMSE reductions with one .item() sync each (:142-144) plus a median (:147-150).
+// Here:
+//   * DEPTH_STATS makes ONE pass set over the members and produces per-member min/max/mean
+//     and the centred second-moment matrix C (E x E, fp64).  With a_i = s_i d_i + t_i,
+//       mean((a_i - a_j)^2) = s_i^2 C_ii + s_j^2 C_jj - 2 s_i s_j C_ij + (s_i m_i + t_i - s_j m_j - t_j)^2
+//     so the pairwise term of the cost - and its exact gradient - is O(E^2) host arithmetic.
+//   * DEPTH_MEDIAN is the only per-evaluation pixel work: align -> lower-middle median over E
+//     (torch.median semantics, :129) -> global min/max (regulariser, :146-150); the same kernel
+//     writes the final median / MAD maps (:178-182).
+//   * DEPTH_NORM applies the final min/max normalisation (:184-194) from device-resident
+//     scalars (no host sync).
+// Normals (ensemble_normals :199-249): one fused per-pixel kernel (mean -> normalise -> cosine
+// -> arccos mean / pi -> argmax -> gather).
+// All HBM-bound streaming kernels: E*HW*4 B read per pass, coalesced over pixels.
+#include "common.h"
+
+namespace {
+
+constexpr int EMAX = 32;
+constexpr int ENS_BLOCKS = 512;
+
+// grid (nblk, E): block (x, i) accumulates row i of the raw second-moment matrix
+__global__ __launch_bounds__(256) void depth_stats_kernel(const float* __restrict__ d, double* __restrict__ part,
+                                                          int E, long long HW) {
+  __shared__ double red[4][EMAX + 3];
+  const int i = blockIdx.y;
+  float acc[EMAX];
+#pragma unroll
+  for (int j = 0; j < EMAX; ++j) acc[j] = 0.f;
+  float mn = 3.0e38f, mx = -3.0e38f;
+  double sum = 0.0;
+  // fp32 partials over short strides, promoted to fp64 every 64 pixels per thread
+  double accd[EMAX];
+#pragma unroll
+  for (int j = 0; j < EMAX; ++j) accd[j] = 0.0;
+  int cnt = 0;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+    const float di = d[(long long)i * HW + p];
+    mn = fminf(mn, di);
+    mx = fmaxf(mx, di);
+    sum += (double)di;
+#pragma unroll
+    for (int j = 0; j < EMAX; ++j)
+      if (j < E) acc[j] += di * d[(long long)j * HW + p];
+    if (++cnt == 64) {
+#pragma unroll
+      for (int j = 0; j < EMAX; ++j) { accd[j] += (double)acc[j]; acc[j] = 0.f; }
+      cnt = 0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EMAX; ++j) accd[j] += (double)acc[j];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+    sum += __shfl_xor(sum, o);
+#pragma unroll
+    for (int j = 0; j < EMAX; ++j)
+      if (j < E) accd[j] += __shfl_xor(accd[j], o);
+  }
+  if (lane == 0) {
+    red[wave][0] = (double)mn; red[wave][1] = (double)mx; red[wave][2] = sum;
+#pragma unroll
+    for (int j = 0; j < EMAX; ++j)
+      if (j < E) red[wave][3 + j] = accd[j];
+  }
+  __syncthreads();
+  double* o = part + ((long long)blockIdx.x * E + i) * (EMAX + 3);
+  for (int k = threadIdx.x; k < E + 3; k += 256) {
+    double v;
+    if (k == 0) v = fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0]));
+    else if (k == 1) v = fmax(fmax(red[0][1], red[1][1]), fmax(red[2][1], red[3][1]));
+    else v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    o[k] = v;
+  }
+}
+
+// one block; out = [min[E], max[E], mean[E], C[E][E]] (C centred)
+__global__ __launch_bounds__(256) void depth_stats_final_kernel(const double* __restrict__ part, double* __restrict__ out,
+                                                                int E, int nblk, long long HW) {
+  __shared__ double mean_s[EMAX];
+  __shared__ double raw[EMAX * EMAX];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < E * (E + 3); idx += 256) {
+    const int i = idx / (E + 3), k = idx % (E + 3);
+    double v = (k == 0) ? 3.0e38 : (k == 1 ? -3.0e38 : 0.0);
+    for (int b = 0; b < nblk; ++b) {
+      const double x = part[((long long)b * E + i) * (EMAX + 3) + k];
+      if (k == 0) v = fmin(v, x);
+      else if (k == 1) v = fmax(v, x);
+      else v += x;
+    }
+    if (k == 0) out[i] = v;
+    else if (k == 1) out[E + i] = v;
+    else if (k == 2) { mean_s[i] = v / (double)HW; out[2 * E + i] = mean_s[i]; }
+    else raw[i * E + (k - 3)] = v / (double)HW;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < E * E; idx += 256) {
+    const int i = idx / E, j = idx % E;
+    out[3 * E + idx] = raw[idx] - mean_s[i] * mean_s[j];
+  }
+}
+
+template <int E_>
+__device__ __forceinline__ float select_rank(const float (&a)[E_], int E, int k) {
+  float res = a[0];
+#pragma unroll
+  for (int e = 0; e < E_; ++e) {
+    if (e < E) {
+      int rank = 0;
+#pragma unroll
+      for (int j = 0; j < E_; ++j)
+        if (j < E) rank += (a[j] < a[e]) || (a[j] == a[e] && j < e);
+      if (rank == k) res = a[e];
+    }
+  }
+  return res;
+}
+
+// E_ = compile-time upper bound of E (registers); st = [s[E], t[E]] fp32; reduction 0 median 1 mean
+template <int E_>
+__global__ __launch_bounds__(256) void depth_median_kernel(const float* __restrict__ d, const float* __restrict__ st,
+                                                           float* __restrict__ med, float* __restrict__ mad,
+                                                           float* __restrict__ blockmm, int E, long long HW,
+                                                           int reduction, int has_shift, int aligned) {
+  __shared__ float red[8];
+  float sc[E_], sh[E_];
+#pragma unroll
+  for (int e = 0; e < E_; ++e) {
+    sc[e] = (aligned && e < E) ? st[e] : 1.f;
+    sh[e] = (aligned && has_shift && e < E) ? st[E + e] : 0.f;
+  }
+  float mn = 3.0e38f, mx = -3.0e38f;
+  const int k = (E - 1) >> 1;  // torch.median: lower middle
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+    float a[E_];
+#pragma unroll
+    for (int e = 0; e < E_; ++e) {
+      if (e < E) {
+        const float v = d[(long long)e * HW + p];
+        // reference: depth * s + t as two separately rounded fp32 ops (ensemble.py:112)
+        a[e] = aligned ? __fadd_rn(__fmul_rn(v, sc[e]), sh[e]) : v;
+      } else a[e] = 0.f;
+    }
+    float pred, unc = 0.f;
+    if (reduction == 0) {
+      pred = select_rank<E_>(a, E, k);
+      if (mad) {
+        float dv[E_];
+#pragma unroll
+        for (int e = 0; e < E_; ++e) dv[e] = fabsf(__fsub_rn(a[e], pred));
+        unc = select_rank<E_>(dv, E, k);
+      }
+    } else {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < E_; ++e)
+        if (e < E) s += a[e];
+      pred = s / (float)E;
+      if (mad) {
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < E_; ++e)
+          if (e < E) { const float dd = a[e] - pred; q += dd * dd; }
+        unc = sqrtf(q / (float)(E > 1 ? E - 1 : 1));  // torch.std: unbiased
+      }
+    }
+    if (med) med[p] = pred;
+    if (mad) mad[p] = unc;
+    mn = fminf(mn, pred);
+    mx = fmaxf(mx, pred);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    blockmm[2 * blockIdx.x] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    blockmm[2 * blockIdx.x + 1] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+  }
+}
+
+__global__ __launch_bounds__(256) void minmax_final_kernel(const float* __restrict__ blockmm, float* __restrict__ out, int nblk) {
+  __shared__ float red[8];
+  float mn = 3.0e38f, mx = -3.0e38f;
+  for (int i = threadIdx.x; i < nblk; i += 256) {
+    mn = fminf(mn, blockmm[2 * i]);
+    mx = fmaxf(mx, blockmm[2 * i + 1]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    out[1] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+  }
+}
+
+__global__ __launch_bounds__(256) void depth_norm_kernel(float* __restrict__ med, float* __restrict__ unc,
+                                                         const float* __restrict__ mm, long long HW, int shift_inv) {
+  const float hi = mm[1];
+  const float lo = shift_inv ? mm[0] : 0.f;
+  const float rng = fmaxf(hi - lo, 1e-6f);
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+    med[p] = (med[p] - lo) / rng;
+    if (unc) unc[p] = unc[p] / rng;
+  }
+}
+
+__global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ n, float* __restrict__ out,
+                                                      float* __restrict__ unc, int E, long long HW, int reduction) {
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int e = 0; e < E; ++e) {
+      const float* q = n + (long long)e * 3 * HW + p;
+      sx += q[0]; sy += q[HW]; sz += q[2 * HW];
+    }
+    float mx_ = sx / (float)E, my = sy / (float)E, mz = sz / (float)E;
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(mx_, mx_), __fmul_rn(my, my)), __fmul_rn(mz, mz)));
+    const float den = fmaxf(nrm, 1e-6f);
+    mx_ = mx_ / den; my = my / den; mz = mz / den;
+    float best = -2.f, ua = 0.f;
+    int bi = 0;
+    for (int e = 0; e < E; ++e) {
+      const float* q = n + (long long)e * 3 * HW + p;
+      float c = __fadd_rn(__fadd_rn(__fmul_rn(mx_, q[0]), __fmul_rn(my, q[HW])), __fmul_rn(mz, q[2 * HW]));
+      c = fminf(fmaxf(c, -1.f), 1.f);
+      if (c > best) { best = c; bi = e; }
+      ua += acosf(c);
+    }
+    if (unc) unc[p] = ua / (float)E / 3.14159265358979323846f;
+    if (reduction == 1) {
+      out[p] = mx_; out[HW + p] = my; out[2 * HW + p] = mz;
+    } else {
+      const float* q = n + (long long)bi * 3 * HW + p;
+      out[p] = q[0]; out[HW + p] = q[HW]; out[2 * HW + p] = q[2 * HW];
+    }
+  }
+}
+
+template <int E_>
+void launch_median(const mg_op* op, int nblk, hipStream_t s) {
+  hipLaunchKernelGGL(depth_median_kernel<E_>, dim3(nblk), dim3(256), 0, s, (const float*)op->p[0],
+                     (const float*)op->p[1], (float*)op->p[2], (float*)op->p[3], (float*)op->p[5],
+                     op->i[0], op->l[0], op->i[1], op->i[2], op->p[1] != nullptr);
+}
+
+}  // namespace
+
+int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
+  switch (op->kind) {
+    case MG_OP_ENS_DEPTH_STATS: {
+      const int E = op->i[0];
+      const long long HW = op->l[0];
+      MG_REQUIRE(E >= 1 && E <= EMAX, "ens_depth_stats: E %d out of range [1,%d]", E, EMAX);
+      const int nblk = (int)min((HW + 255) / 256, (long long)128);
+      hipLaunchKernelGGL(depth_stats_kernel, dim3(nblk, E), dim3(256), 0, s, (const float*)op->p[0],
+                         (double*)op->p[1], E, HW);
+      hipLaunchKernelGGL(depth_stats_final_kernel, dim3(1), dim3(256), 0, s, (const double*)op->p[1],
+                         (double*)op->p[2], E, nblk, HW);
+      break;
+    }
+    case MG_OP_ENS_DEPTH_MEDIAN: {
+      const int E = op->i[0];
+      const long long HW = op->l[0];
+      MG_REQUIRE(E >= 1 && E <= EMAX, "ens_depth_median: E %d out of range [1,%d]", E, EMAX);
+      MG_REQUIRE(op->p[4] && op->p[5], "ens_depth_median: minmax / scratch missing");
+      const int nblk = (int)min((HW + 255) / 256, (long long)ENS_BLOCKS);
+      if (E <= 4) launch_median<4>(op, nblk, s);
+      else if (E <= 8) launch_median<8>(op, nblk, s);
+      else if (E <= 10) launch_median<10>(op, nblk, s);
+      else if (E <= 16) launch_median<16>(op, nblk, s);
+      else launch_median<EMAX>(op, nblk, s);
+      hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, s, (const float*)op->p[5],
+                         (float*)op->p[4], nblk);
+      break;
+    }
+    case MG_OP_ENS_DEPTH_NORM: {
+      const long long HW = op->l[0];
+      const int nblk = (int)min((HW + 255) / 256, (long long)2048);
+      hipLaunchKernelGGL(depth_norm_kernel, dim3(nblk), dim3(256), 0, s, (float*)op->p[0], (float*)op->p[1],
+                         (const float*)op->p[2], HW, op->i[0]);
+      break;
+    }
+    case MG_OP_ENS_NORMALS: {
+      const int E = op->i[0];
+      const long long HW = op->l[0];
+      MG_REQUIRE(E >= 1, "ens_normals: E must be >= 1");
+      const int nblk = (int)min((HW + 255) / 256, (long long)2048);
+      hipLaunchKernelGGL(normals_kernel, dim3(nblk), dim3(256), 0, s, (const float*)op->p[0],
+                         (float*)op->p[1], (float*)op->p[2], E, HW, op->i[1]);
+      break;
+    }
+    default: MG_REQUIRE(false, "ensemble: bad op kind %d", op->kind);
+  }
+  MG_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,239 @@
+// GroupNorm (stats partials -> per-(image,channel) scale/shift -> apply [+SiLU]) and LayerNorm
+// on bf16 NHWC activations.  All HBM-bound streaming kernels: 16-byte (8 x bf16) accesses,
+// fp32 statistics, deterministic (no atomics to global memory).
+// Replaces torch group_norm / silu / layer_norm inside diffusers ResnetBlock2D,
+// Transformer2DModel and BasicTransformerBlock (reached from
+// marigold/marigold_depth_pipeline.py:461-463, 491-492, 512-513).
+#include "common.h"
+
+namespace {
+
+constexpr int GN_NV = 4;  // channel vectors per thread: supports C <= 256*8*GN_NV
+
+// grid (chunks, B); block 256.  partials[b][chunk][c][2] = (sum, sumsq) over the chunk's rows.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x,
+                                                       float* __restrict__ partials, int HW, int C,
+                                                       int chunks) {
+  extern __shared__ float lds[];  // [C][2]
+  const int cv = C >> 3;
+  const int txn = cv < 256 ? cv : 256;
+  const int tyn = 256 / txn;
+  const int tx = threadIdx.x % txn, ty = threadIdx.x / txn;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int rpc = (HW + chunks - 1) / chunks;
+  const int r0 = chunk * rpc;
+  const int r1 = min(HW, r0 + rpc);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  float s[GN_NV][8], q[GN_NV][8];
+#pragma unroll
+  for (int v = 0; v < GN_NV; ++v)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[v][j] = q[v][j] = 0.f;
+  if (ty < tyn) {
+    const bf16_t* xb = x + (long long)b * HW * C;
+    for (int r = r0 + ty; r < r1; r += tyn) {
+#pragma unroll
+      for (int v = 0; v < GN_NV; ++v) {
+        const int vc = tx + v * txn;
+        if (vc < cv) {
+          const uint4 u = *(const uint4*)(xb + (long long)r * C + vc * 8);
+          const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = bflo(w[j]), c = bfhi(w[j]);
+            s[v][2 * j] += a; q[v][2 * j] += a * a;
+            s[v][2 * j + 1] += c; q[v][2 * j + 1] += c * c;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < GN_NV; ++v) {
+      const int vc = tx + v * txn;
+      if (vc < cv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          atomicAdd(&lds[(vc * 8 + j) * 2], s[v][j]);
+          atomicAdd(&lds[(vc * 8 + j) * 2 + 1], q[v][j]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* out = partials + ((long long)b * chunks + chunk) * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = lds[i];
+}
+
+// one wave per (b, group); writes ss[b][0][c] = scale, ss[b][1][c] = shift
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ ss, int B, int C,
+                                                          int groups, int chunks, int HW, float eps) {
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (wid >= B * groups) return;
+  const int b = wid / groups, g = wid % groups;
+  const int cpg = C / groups;
+  double s = 0.0, q = 0.0;
+  const int n = chunks * cpg;
+  for (int i = lane; i < n; i += 64) {
+    const int ch = i / cpg, c = g * cpg + (i % cpg);
+    const float* p = partials + (((long long)b * chunks + ch) * C + c) * 2;
+    s += (double)p[0];
+    q += (double)p[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  const double cnt = (double)HW * cpg;
+  const double mean = s / cnt;
+  double var = q / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int i = lane; i < cpg; i += 64) {
+    const int c = g * cpg + i;
+    const float sc = rstd * gamma[c];
+    ss[((long long)b * 2 + 0) * C + c] = sc;
+    ss[((long long)b * 2 + 1) * C + c] = beta[c] - (float)mean * sc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x,
+                                                       const float* __restrict__ ss,
+                                                       bf16_t* __restrict__ out, long long nvec,
+                                                       int HW, int C, int silu) {
+  const int cv = C >> 3;
+  const long long per_img = (long long)HW * cv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / per_img);
+    const int vc = (int)(i % cv);
+    const uint4 u = *(const uint4*)(x + i * 8);
+    const float* sc = ss + ((long long)b * 2) * C + vc * 8;
+    const float* sh = sc + C;
+    const float4 s0 = *(const float4*)sc, s1 = *(const float4*)(sc + 4);
+    const float4 h0 = *(const float4*)sh, h1 = *(const float4*)(sh + 4);
+    float v[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
+    const float scs[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float shs[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = v[j] * scs[j] + shs[j];
+      if (silu) v[j] = silu_f(v[j]);
+    }
+    uint4 o;
+    o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+    o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+    *(uint4*)(out + i * 8) = o;
+  }
+}
+
+// one wave per row, C <= 64*8*LN_NV
+constexpr int LN_NV = 4;
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        bf16_t* __restrict__ out, int M, int C,
+                                                        float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int cv = C >> 3;
+  float v[LN_NV][8];
+  float s = 0.f;
+  const bf16_t* xr = x + (long long)row * C;
+#pragma unroll
+  for (int k = 0; k < LN_NV; ++k) {
+    const int vc = lane + k * 64;
+    if (vc < cv) {
+      const uint4 u = *(const uint4*)(xr + vc * 8);
+      v[k][0] = bflo(u.x); v[k][1] = bfhi(u.x); v[k][2] = bflo(u.y); v[k][3] = bfhi(u.y);
+      v[k][4] = bflo(u.z); v[k][5] = bfhi(u.z); v[k][6] = bflo(u.w); v[k][7] = bfhi(u.w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[k][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[k][j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_NV; ++k) {
+    const int vc = lane + k * 64;
+    if (vc < cv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; q += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  bf16_t* orow = out + (long long)row * C;
+#pragma unroll
+  for (int k = 0; k < LN_NV; ++k) {
+    const int vc = lane + k * 64;
+    if (vc < cv) {
+      const float4 g0 = *(const float4*)(gamma + vc * 8), g1 = *(const float4*)(gamma + vc * 8 + 4);
+      const float4 b0 = *(const float4*)(beta + vc * 8), b1 = *(const float4*)(beta + vc * 8 + 4);
+      const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = (v[k][j] - mean) * rstd * gs[j] + bs[j];
+      uint4 o;
+      o.x = pack2bf(r[0], r[1]); o.y = pack2bf(r[2], r[3]);
+      o.z = pack2bf(r[4], r[5]); o.w = pack2bf(r[6], r[7]);
+      *(uint4*)(orow + vc * 8) = o;
+    }
+  }
+}
+
+}  // namespace
+
+int mg_launch_norm(const mg_op* op, hipStream_t s) {
+  switch (op->kind) {
+    case MG_OP_GN_STATS: {
+      const int B = op->i[0], HW = op->i[1], C = op->i[2], chunks = op->i[3];
+      MG_REQUIRE(C % 8 == 0 && C <= 256 * 8 * GN_NV, "gn_stats: unsupported C %d", C);
+      MG_REQUIRE(B > 0 && HW > 0 && chunks > 0 && chunks <= HW, "gn_stats: bad dims");
+      hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B), dim3(256), 2 * C * sizeof(float), s,
+                         (const bf16_t*)op->p[0], (float*)op->p[1], HW, C, chunks);
+      break;
+    }
+    case MG_OP_GN_FINALIZE: {
+      const int B = op->i[0], C = op->i[1], groups = op->i[2], chunks = op->i[3], HW = op->i[4];
+      MG_REQUIRE(C % groups == 0, "gn_finalize: C %d not divisible by groups %d", C, groups);
+      hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, s,
+                         (const float*)op->p[0], (const float*)op->p[1], (const float*)op->p[2],
+                         (float*)op->p[3], B, C, groups, chunks, HW, op->f[0]);
+      break;
+    }
+    case MG_OP_GN_APPLY: {
+      const int B = op->i[0], HW = op->i[1], C = op->i[2];
+      MG_REQUIRE(C % 8 == 0, "gn_apply: C %d must be a multiple of 8", C);
+      const long long nvec = (long long)B * HW * (C / 8);
+      const int grid = (int)min((nvec + 255) / 256, (long long)256 * 16);
+      hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)op->p[0],
+                         (const float*)op->p[1], (bf16_t*)op->p[2], nvec, HW, C, op->i[3]);
+      break;
+    }
+    case MG_OP_LAYERNORM: {
+      const int M = op->i[0], C = op->i[1];
+      MG_REQUIRE(C % 8 == 0 && C <= 64 * 8 * LN_NV, "layernorm: unsupported C %d", C);
+      hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s,
+                         (const bf16_t*)op->p[0], (const float*)op->p[1], (const float*)op->p[2],
+                         (bf16_t*)op->p[3], M, C, op->f[0]);
+      break;
+    }
+    default: MG_REQUIRE(false, "norm: bad op kind %d", op->kind);
+  }
+  MG_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,230 @@
+// Host runtime of libmarigold_hip: error state, device init, op dispatch, op programs
+// (replayed back-to-back on one HIP stream, optionally as a captured hipGraph), per-op
+// HIP-event profiling.  This is the native executor behind the Python pipeline: the T-step
+// denoising loop of marigold_depth_pipeline.py:455-468 becomes ONE mg_program_run call.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+void* g_zero_page = nullptr;
+static thread_local char g_err[512] = "";
+static std::mutex g_init_mutex;
+static int g_device = -1;
+
+void mg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct mg_program {
+  std::vector<mg_op> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+static int dispatch(const mg_op* op, hipStream_t s) {
+  switch (op->kind) {
+    case MG_OP_IGEMM: return mg_launch_igemm(op, s);
+    case MG_OP_GN_STATS:
+    case MG_OP_GN_FINALIZE:
+    case MG_OP_GN_APPLY:
+    case MG_OP_LAYERNORM: return mg_launch_norm(op, s);
+    case MG_OP_FLASH_ATTN64:
+    case MG_OP_SOFTMAX_ROWS:
+    case MG_OP_SOFTMAX_PAIRS: return mg_launch_attention(op, s);
+    case MG_OP_CONV_CIN_SMALL:
+    case MG_OP_CONV_COUT_SMALL:
+    case MG_OP_CONCAT_C:
+    case MG_OP_SCHED_STEP:
+    case MG_OP_LINEAR_SMALL_M:
+    case MG_OP_LATENT_1X1:
+    case MG_OP_MEMSET:
+    case MG_OP_COPY: return mg_launch_misc(op, s);
+    case MG_OP_ENS_DEPTH_STATS:
+    case MG_OP_ENS_DEPTH_MEDIAN:
+    case MG_OP_ENS_DEPTH_NORM:
+    case MG_OP_ENS_NORMALS: return mg_launch_ensemble(op, s);
+    default: mg_set_error("mg_launch: unknown op kind %d", op->kind); return 2;
+  }
+}
+
+extern "C" {
+
+int mg_abi_version(void) { return MG_ABI_VERSION; }
+const char* mg_last_error(void) { return g_err; }
+
+int mg_init(int device) {
+  std::lock_guard<std::mutex> lk(g_init_mutex);
+  int n = 0;
+  MG_CHECK_HIP(hipGetDeviceCount(&n));
+  MG_REQUIRE(n > 0, "mg_init: no HIP device visible");
+  MG_REQUIRE(device >= 0 && device < n, "mg_init: device %d out of range (%d devices)", device, n);
+  hipDeviceProp_t prop;
+  MG_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  MG_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+             "mg_init: this library is built for gfx950 (MI355X) only, found %s", prop.gcnArchName);
+  MG_CHECK_HIP(hipSetDevice(device));
+  if (g_zero_page && g_device == device) return 0;
+  MG_REQUIRE(g_device < 0 || g_device == device,
+             "mg_init: one process drives one GPU (already bound to device %d)", g_device);
+  MG_CHECK_HIP(hipMalloc(&g_zero_page, 4096));
+  MG_CHECK_HIP(hipMemset(g_zero_page, 0, 4096));
+  g_device = device;
+  return 0;
+}
+
+int mg_device_info(int* cu_count, int* lds_bytes, int64_t* hbm_bytes, char* arch, int arch_len) {
+  int dev = 0;
+  MG_CHECK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  MG_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (lds_bytes) *lds_bytes = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  if (arch && arch_len > 0) {
+    strncpy(arch, prop.gcnArchName, arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  return 0;
+}
+
+int mg_launch(const mg_op* op, void* stream) {
+  MG_REQUIRE(op != nullptr, "mg_launch: null op");
+  return dispatch(op, (hipStream_t)stream);
+}
+
+mg_program* mg_program_create(const mg_op* ops, int n_ops) {
+  if (!ops || n_ops <= 0) {
+    mg_set_error("mg_program_create: empty program");
+    return nullptr;
+  }
+  mg_program* p = new mg_program();
+  p->ops.assign(ops, ops + n_ops);
+  return p;
+}
+
+int mg_program_num_ops(const mg_program* prog) { return prog ? (int)prog->ops.size() : 0; }
+
+int mg_program_run_range(mg_program* prog, int first, int count, void* stream) {
+  MG_REQUIRE(prog, "mg_program_run: null program");
+  MG_REQUIRE(first >= 0 && count >= 0 && first + count <= (int)prog->ops.size(),
+             "mg_program_run_range: [%d,+%d) outside %d ops", first, count, (int)prog->ops.size());
+  for (int i = first; i < first + count; ++i) {
+    const int rc = dispatch(&prog->ops[i], (hipStream_t)stream);
+    if (rc) {
+      char msg[400];
+      snprintf(msg, sizeof(msg), "%s", g_err);
+      mg_set_error("op %d (kind %d): %s", i, prog->ops[i].kind, msg);
+      return rc;
+    }
+  }
+  return 0;
+}
+
+int mg_program_run(mg_program* prog, void* stream) {
+  MG_REQUIRE(prog, "mg_program_run: null program");
+  if (prog->exec) {
+    MG_CHECK_HIP(hipGraphLaunch(prog->exec, (hipStream_t)stream));
+    return 0;
+  }
+  return mg_program_run_range(prog, 0, (int)prog->ops.size(), stream);
+}
+
+int mg_program_capture(mg_program* prog, void* stream) {
+  MG_REQUIRE(prog, "mg_program_capture: null program");
+  hipStream_t s = (hipStream_t)stream;
+  if (prog->exec) { hipGraphExecDestroy(prog->exec); prog->exec = nullptr; }
+  if (prog->graph) { hipGraphDestroy(prog->graph); prog->graph = nullptr; }
+  // one eager run first so lazy per-kernel attribute setup happens outside the capture
+  int rc = mg_program_run_range(prog, 0, (int)prog->ops.size(), stream);
+  if (rc) return rc;
+  MG_CHECK_HIP(hipStreamSynchronize(s));
+  MG_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  rc = mg_program_run_range(prog, 0, (int)prog->ops.size(), stream);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(s, &g);
+  if (rc) { if (g) hipGraphDestroy(g); return rc; }
+  MG_REQUIRE(e == hipSuccess && g, "mg_program_capture: hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  prog->graph = g;
+  MG_CHECK_HIP(hipGraphInstantiate(&prog->exec, g, nullptr, nullptr, 0));
+  return 0;
+}
+
+int mg_program_profile(mg_program* prog, void* stream, float* ms) {
+  MG_REQUIRE(prog && ms, "mg_program_profile: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)prog->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) MG_CHECK_HIP(hipEventCreate(&e));
+  MG_CHECK_HIP(hipEventRecord(ev[0], s));
+  for (int i = 0; i < n; ++i) {
+    const int rc = dispatch(&prog->ops[i], s);
+    if (rc) return rc;
+    MG_CHECK_HIP(hipEventRecord(ev[i + 1], s));
+  }
+  MG_CHECK_HIP(hipEventSynchronize(ev[n]));
+  for (int i = 0; i < n; ++i) MG_CHECK_HIP(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+  for (auto& e : ev) hipEventDestroy(e);
+  return 0;
+}
+
+void mg_program_destroy(mg_program* prog) {
+  if (!prog) return;
+  if (prog->exec) hipGraphExecDestroy(prog->exec);
+  if (prog->graph) hipGraphDestroy(prog->graph);
+  delete prog;
+}
+
+int mg_conv2d_igemm(const mg_op* conv_desc, void* stream) {
+  MG_REQUIRE(conv_desc && conv_desc->kind == MG_OP_IGEMM, "mg_conv2d_igemm: op kind must be MG_OP_IGEMM");
+  return mg_launch_igemm(conv_desc, (hipStream_t)stream);
+}
+
+int mg_sched_step(const float* x, const float* model_out, const float* noise, float* out, int64_t n,
+                  float cx, float cm, float cn, void* stream) {
+  mg_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = MG_OP_SCHED_STEP;
+  op.p[0] = (void*)x; op.p[1] = (void*)model_out; op.p[2] = (void*)noise; op.p[3] = out;
+  op.l[0] = n;
+  op.f[0] = cx; op.f[1] = cm; op.f[2] = cn;
+  return mg_launch_misc(&op, (hipStream_t)stream);
+}
+
+int mg_ensemble_normals(const float* normals, float* out, float* unc, int E, int64_t hw, int reduction,
+                        void* stream) {
+  mg_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = MG_OP_ENS_NORMALS;
+  op.p[0] = (void*)normals; op.p[1] = out; op.p[2] = unc;
+  op.i[0] = E; op.i[1] = reduction;
+  op.l[0] = hw;
+  return mg_launch_ensemble(&op, (hipStream_t)stream);
+}
+
+void* mg_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return (void*)e;
+}
+int mg_event_record(void* ev, void* stream) {
+  MG_CHECK_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+  return 0;
+}
+int mg_event_elapsed_ms(void* start, void* stop, float* ms) {
+  MG_CHECK_HIP(hipEventSynchronize((hipEvent_t)stop));
+  MG_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return 0;
+}
+void mg_event_destroy(void* ev) {
+  if (ev) hipEventDestroy((hipEvent_t)ev);
+}
+
+}  // extern "C"

@@ -1,0 +1,223 @@
+"""Op descriptors for libmarigold_hip (one ``mg_op`` per kernel launch) and ``OpSeq``, the
+host-side container that turns a list of them into a native program (``mg_program_*``).
+
+torch is used only as the owner of device memory and the source of the HIP stream handle.
+Field layout of every op is documented in include/marigold_hip.h.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from ._lib import MgOp
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.data_ptr()
+    return int(x)
+
+
+def make_op(kind, i=(), f=(), p=(), l=()):
+    op = MgOp()
+    op.kind = kind
+    for k, v in enumerate(i):
+        op.i[k] = int(v)
+    for k, v in enumerate(f):
+        op.f[k] = float(v)
+    for k, v in enumerate(p):
+        op.p[k] = _ptr(v)
+    for k, v in enumerate(l):
+        op.l[k] = int(v)
+    return op
+
+
+def current_stream_handle():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# --------------------------------------------------------------------------- builders
+
+def igemm(a, w, out, *, B, H, W, Cin, Ho, Wo, N, taps=1, stride=1, pad=0, up=None, bias=None,
+          rowvec=None, residual=None, epi=L.EPI_BF16, ldo=None, out2=None, trans_from=-1, ldt=0,
+          batch_z=1, ldr=0, lda=0, ldw=0, zstrides=(0, 0, 0, 0), scale=1.0, variant=0):
+    hu, wu = up if up else (0, 0)
+    if ldo is None:
+        ldo = N // 2 if epi == L.EPI_GEGLU else N
+    return make_op(L.OP_IGEMM,
+                   i=[B, H, W, Cin, Ho, Wo, N, taps, stride, pad, hu, wu, epi, ldo, trans_from,
+                      batch_z, ldr, lda, ldt, variant, ldw],
+                   f=[scale], p=[a, w, out, bias, rowvec, residual, out2], l=list(zstrides))
+
+
+def linear(x, w, out, *, M, K, N, **kw):
+    """out[M][N] = x[M][K] @ w[N][K]^T (+ fused epilogue)."""
+    return igemm(x, w, out, B=1, H=M, W=1, Cin=K, Ho=M, Wo=1, N=N, taps=1, **kw)
+
+
+def gn_stats(x, partials, *, B, HW, C, chunks):
+    return make_op(L.OP_GN_STATS, i=[B, HW, C, chunks], p=[x, partials])
+
+
+def gn_finalize(partials, gamma, beta, ss, *, B, C, groups, chunks, HW, eps):
+    return make_op(L.OP_GN_FINALIZE, i=[B, C, groups, chunks, HW], f=[eps], p=[partials, gamma, beta, ss])
+
+
+def gn_apply(x, ss, out, *, B, HW, C, silu):
+    return make_op(L.OP_GN_APPLY, i=[B, HW, C, int(silu)], p=[x, ss, out])
+
+
+def layernorm(x, gamma, beta, out, *, M, C, eps=1e-5):
+    return make_op(L.OP_LAYERNORM, i=[M, C], f=[eps], p=[x, gamma, beta, out])
+
+
+def flash_attn64(q, k, vt, o, *, B, heads, Ntok, ldq, ldo, ldvt, sq, sk, svt, so, scale):
+    return make_op(L.OP_FLASH_ATTN64, i=[B, heads, Ntok, ldq, ldo, ldvt], f=[scale],
+                   p=[q, k, vt, o], l=[sq, sk, svt, so])
+
+
+def softmax_rows(s, p, *, R, ncols, lds, ldp):
+    return make_op(L.OP_SOFTMAX_ROWS, i=[R, ncols, lds, ldp], p=[s, p])
+
+
+def softmax_pairs(s, p, *, M, pairs, lds, ldp, scale):
+    return make_op(L.OP_SOFTMAX_PAIRS, i=[M, pairs, lds, ldp], f=[scale], p=[s, p])
+
+
+def conv_cin_small(src0, src1, w, bias, out, *, B, H, W, C0, C1, Cout, bcast0=False):
+    return make_op(L.OP_CONV_CIN_SMALL, i=[B, H, W, C0, C1, Cout, int(bcast0)],
+                   p=[src0, src1, w, bias, out])
+
+
+def conv_cout_small(x, w, bias, out, *, B, H, W, Cin, Cout, post=L.POST_NONE, scale=1.0):
+    return make_op(L.OP_CONV_COUT_SMALL, i=[B, H, W, Cin, Cout, post], f=[scale], p=[x, w, bias, out])
+
+
+def concat_c(a, b, out, *, M, C1, C2):
+    return make_op(L.OP_CONCAT_C, i=[M, C1, C2], p=[a, b, out])
+
+
+def sched_step(x, model_out, noise, out, *, n, cx, cm, cn=0.0):
+    return make_op(L.OP_SCHED_STEP, f=[cx, cm, cn], p=[x, model_out, noise, out], l=[n])
+
+
+def linear_small_m(x, w, b, out, *, M, N, K, act_in=0, act_out=0, ldo=0):
+    return make_op(L.OP_LINEAR_SMALL_M, i=[M, N, K, act_in, act_out, ldo], p=[x, w, b, out])
+
+
+def latent_1x1(x, w, b, out, *, B, Ci, Co, HW, scale=1.0):
+    return make_op(L.OP_LATENT_1X1, i=[B, Ci, Co, HW], f=[scale], p=[x, w, b, out])
+
+
+def ens_depth_stats(d, scratch, out, *, E, HW):
+    return make_op(L.OP_ENS_DEPTH_STATS, i=[E], p=[d, scratch, out], l=[HW])
+
+
+def ens_depth_median(d, st, med, mad, minmax, scratch, *, E, HW, reduction=0, has_shift=True):
+    return make_op(L.OP_ENS_DEPTH_MEDIAN, i=[E, reduction, int(has_shift)],
+                   p=[d, st, med, mad, minmax, scratch], l=[HW])
+
+
+def ens_depth_norm(med, unc, minmax, *, HW, shift_invariant=True):
+    return make_op(L.OP_ENS_DEPTH_NORM, i=[int(shift_invariant)], p=[med, unc, minmax], l=[HW])
+
+
+def ens_normals(n, out, unc, *, E, HW, reduction=0):
+    return make_op(L.OP_ENS_NORMALS, i=[E, reduction], p=[n, out, unc], l=[HW])
+
+
+def memset(dst, nbytes, value=0):
+    return make_op(L.OP_MEMSET, i=[value], p=[dst], l=[nbytes])
+
+
+def copy(src, dst, nbytes):
+    return make_op(L.OP_COPY, p=[src, dst], l=[nbytes])
+
+
+# --------------------------------------------------------------------------- containers
+
+def launch(op, stream=None):
+    """Launch one op on torch's current stream (or the given raw handle)."""
+    lib = L.load()
+    L.check(lib.mg_launch(ctypes.byref(op), stream if stream is not None else current_stream_handle()),
+            f"mg_launch({L.OP_NAMES.get(op.kind, op.kind)})")
+
+
+class OpSeq:
+    """An ordered list of ops + the tensors they reference (kept alive), compiled on demand to
+    a native ``mg_program`` so that a whole UNet forward / denoising loop / VAE pass is ONE
+    C call (and optionally one hipGraph launch)."""
+
+    def __init__(self, name=""):
+        self.name = name
+        self.ops = []
+        self.labels = []
+        self.keep = []
+        self._prog = None
+        self._captured = False
+
+    def add(self, op, label=""):
+        self.ops.append(op)
+        self.labels.append(label)
+        self._prog = None
+        return op
+
+    def hold(self, *tensors):
+        self.keep.extend(tensors)
+        return tensors[0] if len(tensors) == 1 else tensors
+
+    def extend(self, other):
+        self.ops.extend(other.ops)
+        self.labels.extend(other.labels)
+        self.keep.extend(other.keep)
+        self._prog = None
+
+    def __len__(self):
+        return len(self.ops)
+
+    def compile(self):
+        if self._prog is None:
+            lib = L.load()
+            arr = (MgOp * len(self.ops))(*self.ops)
+            prog = lib.mg_program_create(arr, len(self.ops))
+            if not prog:
+                L.check(1, "mg_program_create")
+            self._prog = prog
+            self._captured = False
+        return self._prog
+
+    def run(self, stream=None):
+        lib = L.load()
+        prog = self.compile()
+        L.check(lib.mg_program_run(prog, stream if stream is not None else current_stream_handle()),
+                f"mg_program_run({self.name})")
+
+    def run_eager(self, stream=None):
+        for op in self.ops:
+            launch(op, stream)
+
+    def capture(self, stream=None):
+        """Capture into a hipGraph (the stream must not be the legacy default stream)."""
+        lib = L.load()
+        prog = self.compile()
+        L.check(lib.mg_program_capture(prog, stream if stream is not None else current_stream_handle()),
+                f"mg_program_capture({self.name})")
+        self._captured = True
+
+    def profile(self, stream=None):
+        """Per-op milliseconds (HIP events on the launch stream)."""
+        lib = L.load()
+        prog = self.compile()
+        ms = (ctypes.c_float * len(self.ops))()
+        L.check(lib.mg_program_profile(prog, stream if stream is not None else current_stream_handle(), ms),
+                f"mg_program_profile({self.name})")
+        return list(ms)
+
+    def __del__(self):
+        try:
+            if self._prog is not None:
+                L.load().mg_program_destroy(self._prog)
+        except Exception:
+            pass

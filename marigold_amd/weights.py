@@ -1,0 +1,75 @@
+"""Checkpoint -> engine weight layouts (done once at load time, on the host in fp32).
+
+diffusers state-dict tensors (``arch.py`` key scheme) are re-laid for the HIP kernels:
+  * conv3x3 [Cout,Cin,3,3] -> bf16 [Cout][(ky*3+kx)*Cin + c]   (K-contiguous rows for igemm)
+  * Linear / conv1x1        -> bf16 [N][K]
+  * GEGLU proj [8C, C]      -> rows interleaved in 16-row groups (8 "u" rows then their 8 gate
+                               rows) so the igemm epilogue can form u*gelu(g) inside one lane
+  * cross-attention against the constant 2-token empty-prompt embedding
+    (marigold_depth_pipeline.py:381-394) -> Wqk [64-padded 2*heads][C], VO^T [C][64]
+  * fused Q|K|V projection  -> [3C][C]
+"""
+import torch
+
+
+def bf16(t, device):
+    return t.detach().to(device=device, dtype=torch.bfloat16).contiguous()
+
+
+def f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def pack_conv3x3(w):
+    """[Cout,Cin,3,3] -> [Cout, 9*Cin] with k = (ky*3+kx)*Cin + c."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    return w.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+
+
+def pack_conv1x1(w):
+    return w.reshape(w.shape[0], w.shape[1]).contiguous()
+
+
+def pack_small_conv(w):
+    """[Cout,Cin,3,3] -> fp32 [Cout][9][Cin] for the direct small-channel conv kernels."""
+    co, ci = w.shape[:2]
+    return w.permute(0, 2, 3, 1).reshape(co, 9, ci).contiguous().float()
+
+
+def pack_geglu(w, b):
+    """proj [8C, C] (rows 0..4C-1 = u, 4C..8C-1 = gate) -> 16-row interleave (8 u, 8 gate)."""
+    n2 = w.shape[0]
+    h = n2 // 2
+    assert h % 8 == 0
+    idx = torch.arange(n2)
+    blk, within = idx // 16, idx % 16
+    src = torch.where(within < 8, blk * 8 + within, h + blk * 8 + (within - 8))
+    return w[src].contiguous(), b[src].contiguous()
+
+
+def pack_qkv(wq, wk, wv):
+    return torch.cat([wq, wk, wv], dim=0).contiguous()
+
+
+def cross_attention_tables(wq, wk, wv, wo, ctx, heads):
+    """Collapse attn2 (2 context tokens) into two thin matrices (fp32 math on the host).
+
+    wq [C,C], wk/wv [C,cross], wo [C,C], ctx [2,cross].
+    Returns Wqk [npad, C] (row 2h+j = Wq_h^T k_{j,h}; zero rows beyond 2*heads) and
+            VOt [C, npad] (column 2h+j = Wo[:, h-slice] @ v_{j,h}).
+    """
+    C = wq.shape[0]
+    dh = C // heads
+    wq, wk, wv, wo, ctx = (t.double() for t in (wq, wk, wv, wo, ctx))
+    k = ctx @ wk.t()           # [2, C]
+    v = ctx @ wv.t()           # [2, C]
+    npad = ((2 * heads + 63) // 64) * 64
+    wqk = torch.zeros(npad, C, dtype=torch.float64)
+    vot = torch.zeros(C, npad, dtype=torch.float64)
+    for h in range(heads):
+        sl = slice(h * dh, (h + 1) * dh)
+        for j in range(2):
+            wqk[2 * h + j] = k[j, sl] @ wq[sl, :]          # (Wq_h^T k_jh)[c] = sum_d Wq[hd,c] k[j,hd]
+            vot[:, 2 * h + j] = wo[:, sl] @ v[j, sl]
+    return wqk.float(), vot.float(), npad

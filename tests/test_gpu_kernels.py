@@ -1,0 +1,415 @@
+"""Per-kernel parity on a real MI355X: every HIP op (through the C ABI, mg_launch) vs a plain
+PyTorch fp32 CPU reference of the same op on the same (bf16-rounded) inputs.
+
+Tolerances: bf16 storage (8 mantissa bits) with fp32 accumulation -> |err| <= 1.5e-2 * scale
+of the output, where scale = max|ref|; fp32 kernels (scheduler, ensembling, latents) 1e-5.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from marigold_amd import _lib
+    _lib.init(0)
+    return torch.device("cuda:0")
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _close(name, got, ref, tol=1.5e-2):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    print(f"[parity] {name}: max|err|={err:.3e} scale={scale:.3e} rel={err / scale:.3e}")
+    assert err <= tol * scale, f"{name}: max|err| {err:.4e} > {tol} * {scale:.4e}"
+
+
+def _run(op):
+    from marigold_amd import ops
+    ops.launch(op)
+    torch.cuda.synchronize()
+
+
+# --------------------------------------------------------------------------- igemm: conv
+CONV_CASES = [
+    # name, B, H, W, Cin, Cout, stride, pad, up, variant
+    ("v1_basic", 2, 12, 20, 64, 128, 1, 1, None, 1),
+    ("v2_basic", 2, 16, 24, 128, 128, 1, 1, None, 2),
+    ("v3_basic", 1, 9, 7, 64, 64, 1, 1, None, 3),
+    ("v4_basic", 2, 12, 20, 64, 192, 1, 1, None, 4),
+    ("v11_regstaged", 2, 12, 20, 64, 128, 1, 1, None, 11),
+    ("v13_regstaged", 1, 9, 7, 64, 64, 1, 1, None, 13),
+    ("n_edge_320", 1, 12, 12, 320, 320, 1, 1, None, 1),
+    ("stride2_pad1", 2, 16, 16, 64, 64, 2, 1, None, 0),
+    ("stride2_pad0_asym", 1, 16, 24, 128, 128, 2, 0, None, 0),
+    ("stride2_odd", 1, 15, 11, 64, 64, 2, 1, None, 3),
+    ("up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 0),
+    ("up_to_size", 1, 4, 6, 64, 64, 1, 1, (7, 11), 0),
+    ("auto_big", 4, 32, 32, 192, 256, 1, 1, None, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_igemm_conv3x3(dev, case):
+    from marigold_amd import ops, weights as Wm
+    name, B, H, W, Cin, Cout, stride, pad, up, variant = case
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    x = _bf(torch.randn(B, Cin, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    xin = x
+    if up:
+        xin = F.interpolate(x, size=up, mode="nearest")
+    if stride == 2 and pad == 0:
+        ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w, bias, stride=2)
+    else:
+        ref = F.conv2d(xin, w, bias, stride=stride, padding=pad)
+    Ho, Wo = ref.shape[-2:]
+    temb = torch.randn(B, Cout, generator=g) * 0.2
+    res = _bf(torch.randn(B, Cout, Ho, Wo, generator=g))
+    ref = ref + temb[:, :, None, None] + res
+    xd = _nhwc(x).to(dev, torch.bfloat16)
+    wd = Wm.pack_conv3x3(w).to(dev, torch.bfloat16)
+    out = torch.full((B, Ho, Wo, Cout), float("nan"), device=dev, dtype=torch.bfloat16)
+    op = ops.igemm(xd, wd, out, B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, N=Cout, taps=9, stride=stride,
+                   pad=pad, up=up, bias=bias.to(dev), rowvec=temb.to(dev).contiguous(),
+                   residual=_nhwc(res).to(dev, torch.bfloat16), variant=variant)
+    _run(op)
+    _close(f"conv3x3/{name}", out.float().permute(0, 3, 1, 2), ref)
+
+
+def test_igemm_linear_geglu_f32_trans_batched(dev):
+    from marigold_amd import _lib as L, ops, weights as Wm
+    g = torch.Generator().manual_seed(5)
+    # --- plain linear with M / N edges, and every tile variant ---
+    M, K, N = 300, 192, 320
+    x = _bf(torch.randn(M, K, generator=g))
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    ref = x @ w.t() + b
+    for variant in (0, 1, 2, 3, 4, 11):
+        out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N,
+                        bias=b.to(dev), variant=variant))
+        _close(f"linear/v{variant}", out, ref)
+    # --- GEGLU epilogue ---
+    C = 64
+    wg = _bf(torch.randn(8 * C, C, generator=g) / math.sqrt(C))
+    bg = torch.randn(8 * C, generator=g) * 0.1
+    xg = _bf(torch.randn(200, C, generator=g))
+    u, gt = (xg @ wg.t() + bg).chunk(2, dim=-1)
+    ref = u * F.gelu(gt)
+    wp, bp = Wm.pack_geglu(wg, bg)
+    for variant in (1, 3):
+        out = torch.full((200, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.linear(xg.to(dev, torch.bfloat16), wp.to(dev, torch.bfloat16), out, M=200, K=C,
+                        N=8 * C, bias=bp.to(dev), epi=L.EPI_GEGLU, variant=variant))
+        _close(f"geglu/v{variant}", out, ref)
+    # --- fused QKV with transposed V section (+ bias), per-image token blocks ---
+    B, T, C = 2, 144, 128
+    xq = _bf(torch.randn(B * T, C, generator=g))
+    wqkv = _bf(torch.randn(3 * C, C, generator=g) / math.sqrt(C))
+    bq = torch.randn(3 * C, generator=g) * 0.1
+    refq = xq @ wqkv.t() + bq
+    ldt = 192
+    qk = torch.full((B * T, 3 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+    vt = torch.zeros((B, C, ldt), device=dev, dtype=torch.bfloat16)
+    _run(ops.igemm(xq.to(dev, torch.bfloat16), wqkv.to(dev, torch.bfloat16), qk, B=B, H=T, W=1, Cin=C,
+                   Ho=T, Wo=1, N=3 * C, bias=bq.to(dev), out2=vt, trans_from=2 * C, ldt=ldt, variant=1))
+    _close("qkv/qk", qk[:, :2 * C], refq[:, :2 * C])
+    refv = refq[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1)
+    _close("qkv/vt", vt[:, :, :T], refv)
+    assert (vt[:, :, T:] == 0).all()
+    # --- batched fp32 scores: S_z = scale * Q_z K_z^T with strided operands ---
+    Z, T, D = 3, 160, 128
+    qkv = _bf(torch.randn(Z, T, 3 * D, generator=g))
+    refS = torch.einsum("ztd,zsd->zts", qkv[..., :D], qkv[..., D:2 * D]) * 0.25
+    qd = qkv.to(dev, torch.bfloat16)
+    S = torch.full((Z, T, T), float("nan"), device=dev, dtype=torch.float32)
+    _run(ops.igemm(qd, qd[:, :, D:], S, B=1, H=T, W=1, Cin=D, Ho=T, Wo=1, N=T, epi=L.EPI_F32, ldo=T,
+                   lda=3 * D, ldw=3 * D, batch_z=Z, zstrides=(T * 3 * D, T * 3 * D, T * T, 0),
+                   scale=0.25))
+    _close("scores_f32", S, refS, tol=2e-3)
+
+
+# --------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,H,W,C,silu,eps", [(2, 12, 20, 64, True, 1e-5), (1, 9, 7, 320, True, 1e-6),
+                                              (3, 8, 8, 960, False, 1e-6), (1, 16, 16, 2560, True, 1e-5),
+                                              (2, 24, 24, 128, True, 1e-6)])
+def test_groupnorm(dev, B, H, W, C, silu, eps):
+    from marigold_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = _bf(torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3)
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    ref = F.group_norm(x, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    HW = H * W
+    chunks = min(HW, 8)
+    xd = _nhwc(x).to(dev, torch.bfloat16)
+    part = torch.empty(B, chunks, C, 2, device=dev)
+    ss = torch.empty(B, 2, C, device=dev)
+    out = torch.full_like(xd, float("nan"))
+    for op in (ops.gn_stats(xd, part, B=B, HW=HW, C=C, chunks=chunks),
+               ops.gn_finalize(part, gamma.to(dev), beta.to(dev), ss, B=B, C=C, groups=32,
+                               chunks=chunks, HW=HW, eps=eps),
+               ops.gn_apply(xd, ss, out, B=B, HW=HW, C=C, silu=silu)):
+        _run(op)
+    _close(f"groupnorm/C{C}", out.float().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("M,C", [(37, 64), (200, 320), (50, 1280)])
+def test_layernorm(dev, M, C):
+    from marigold_amd import ops
+    g = torch.Generator().manual_seed(M)
+    x = _bf(torch.randn(M, C, generator=g) * 2 + 0.5)
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    out = torch.full((M, C), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.layernorm(x.to(dev, torch.bfloat16), gamma.to(dev), beta.to(dev), out, M=M, C=C))
+    _close(f"layernorm/{M}x{C}", out, ref)
+
+
+# --------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,heads,T", [(1, 1, 64), (2, 2, 144), (1, 5, 200), (1, 2, 576), (2, 1, 1000)])
+def test_flash_attn64(dev, B, heads, T):
+    from marigold_amd import ops
+    C = heads * 64
+    g = torch.Generator().manual_seed(T)
+    qkv = _bf(torch.randn(B, T, 3 * C, generator=g))
+    q, k, v = qkv.split(C, dim=-1)
+    qh, kh, vh = (t.reshape(B, T, heads, 64).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, T, C)
+    ldvt = ((T + 63) // 64) * 64
+    qkd = qkv.to(dev, torch.bfloat16)
+    vt = torch.zeros(B, C, ldvt, device=dev, dtype=torch.bfloat16)
+    vt[:, :, :T] = v.permute(0, 2, 1).to(dev, torch.bfloat16)
+    out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.flash_attn64(qkd, qkd[:, :, C:], vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C,
+                          ldvt=ldvt, sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125))
+    _close(f"flash_attn64/B{B}h{heads}T{T}", out, ref)
+
+
+def test_flash_attn64_spiky_scores(dev):
+    """Online-softmax rescale path: one key dominates late in the sequence."""
+    from marigold_amd import ops
+    T, C = 320, 64
+    g = torch.Generator().manual_seed(3)
+    q = _bf(torch.randn(1, T, C, generator=g))
+    k = _bf(torch.randn(1, T, C, generator=g))
+    v = _bf(torch.randn(1, T, C, generator=g))
+    k[0, 250] = q[0, 17] * 4.0   # huge score for query 17 at key 250 (4th tile)
+    k[0, 5] = q[0, 100] * 3.0
+    ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+    qkv = torch.cat([q, k], dim=-1).to(dev, torch.bfloat16)
+    vt = v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16)
+    out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.flash_attn64(qkv, qkv[:, :, C:], vt, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T,
+                          sq=0, sk=0, svt=0, so=0, scale=0.125))
+    _close("flash_attn64/spiky", out, ref)
+
+
+def test_softmax_rows_and_pairs(dev):
+    from marigold_amd import ops
+    g = torch.Generator().manual_seed(1)
+    R, n, lds, ldp = 33, 1000, 1000, 1024
+    s = torch.randn(R, lds, generator=g) * 3
+    ref = torch.softmax(s[:, :n], dim=-1)
+    p = torch.full((R, ldp), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.softmax_rows(s.to(dev), p, R=R, ncols=n, lds=lds, ldp=ldp))
+    _close("softmax_rows", p[:, :n], ref)
+    assert (p[:, n:] == 0).all()
+    M, pairs = 77, 5
+    s2 = torch.randn(M, 64, generator=g) * 4
+    ref2 = torch.softmax((s2[:, :2 * pairs] * 0.125).reshape(M, pairs, 2), dim=-1).reshape(M, 2 * pairs)
+    p2 = torch.full((M, 64), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.softmax_pairs(s2.to(dev), p2, M=M, pairs=pairs, lds=64, ldp=64, scale=0.125))
+    _close("softmax_pairs", p2[:, :2 * pairs], ref2)
+    assert (p2[:, 2 * pairs:] == 0).all()
+
+
+# --------------------------------------------------------------------------- boundary convs etc.
+def test_conv_cin_small(dev):
+    from marigold_amd import ops, weights as Wm
+    g = torch.Generator().manual_seed(2)
+    B, H, W, Cout = 3, 10, 14, 64
+    rgb_lat = torch.randn(1, 4, H, W, generator=g)
+    tgt = torch.randn(B, 4, H, W, generator=g)
+    w = torch.randn(Cout, 8, 3, 3, generator=g) / math.sqrt(72)
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(torch.cat([rgb_lat.expand(B, -1, -1, -1), tgt], 1), w, b, padding=1)
+    out = torch.full((B, H, W, Cout), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.conv_cin_small(rgb_lat.to(dev), tgt.to(dev), Wm.pack_small_conv(w).to(dev), b.to(dev), out,
+                            B=B, H=H, W=W, C0=4, C1=4, Cout=Cout, bcast0=True))
+    _close("conv_cin_small/8ch", out.float().permute(0, 3, 1, 2), ref, tol=6e-3)
+    img = torch.rand(2, 3, 12, 9, generator=g) * 2 - 1
+    w3 = torch.randn(128, 3, 3, 3, generator=g) / math.sqrt(27)
+    b3 = torch.randn(128, generator=g) * 0.1
+    out3 = torch.full((2, 12, 9, 128), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.conv_cin_small(img.to(dev), None, Wm.pack_small_conv(w3).to(dev), b3.to(dev), out3,
+                            B=2, H=12, W=9, C0=3, C1=0, Cout=128))
+    _close("conv_cin_small/3ch", out3.float().permute(0, 3, 1, 2), F.conv2d(img, w3, b3, padding=1), tol=6e-3)
+
+
+def test_conv_cout_small(dev):
+    from marigold_amd import _lib as L, ops, weights as Wm
+    g = torch.Generator().manual_seed(4)
+    B, H, W, Cin = 2, 11, 13, 128
+    x = _bf(torch.randn(B, Cin, H, W, generator=g))
+    xd = _nhwc(x).to(dev, torch.bfloat16)
+    for cout, post in ((3, L.POST_NONE), (3, L.POST_DEPTH), (3, L.POST_NORMALS), (4, L.POST_NONE)):
+        w = torch.randn(cout, Cin, 3, 3, generator=g) * (3.0 / math.sqrt(9 * Cin))
+        b = torch.randn(cout, generator=g) * 0.1
+        y = F.conv2d(x, w, b, padding=1)
+        if post == L.POST_DEPTH:
+            ref = (torch.clip(y.mean(1, keepdim=True), -1, 1) + 1) / 2
+        elif post == L.POST_NORMALS:
+            y = torch.clip(y, -1, 1)
+            ref = y / torch.norm(y, dim=1, keepdim=True).clamp(min=1e-6)
+        else:
+            ref = y
+        out = torch.full(tuple(ref.shape), float("nan"), device=dev)
+        _run(ops.conv_cout_small(xd, Wm.pack_small_conv(w).to(dev), b.to(dev), out, B=B, H=H, W=W,
+                                 Cin=Cin, Cout=cout, post=post))
+        _close(f"conv_cout_small/c{cout}p{post}", out, ref, tol=1e-4)
+
+
+def test_small_ops(dev):
+    from marigold_amd import ops
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(50, 64, generator=g).to(torch.bfloat16)
+    b = torch.randn(50, 128, generator=g).to(torch.bfloat16)
+    out = torch.empty(50, 192, device=dev, dtype=torch.bfloat16)
+    _run(ops.concat_c(a.to(dev), b.to(dev), out, M=50, C1=64, C2=128))
+    assert torch.equal(out.cpu(), torch.cat([a, b], 1))
+    x, m, nz = (torch.randn(3, 4, 8, 8, generator=g) for _ in range(3))
+    o = torch.empty(3, 4, 8, 8, device=dev)
+    _run(ops.sched_step(x.to(dev), m.to(dev), nz.to(dev), o, n=x.numel(), cx=0.7, cm=-0.3, cn=0.2))
+    _close("sched_step", o, 0.7 * x - 0.3 * m + 0.2 * nz, tol=1e-6)
+    _run(ops.sched_step(x.to(dev), m.to(dev), None, o, n=x.numel(), cx=0.5, cm=0.25))
+    _close("sched_step/no-noise", o, 0.5 * x + 0.25 * m, tol=1e-6)
+    xi = torch.randn(5, 320, generator=g)
+    w = torch.randn(100, 320, generator=g) / 18
+    bb = torch.randn(100, generator=g)
+    o2 = torch.empty(5, 100, device=dev)
+    _run(ops.linear_small_m(xi.to(dev), w.to(dev), bb.to(dev), o2, M=5, N=100, K=320, act_in=1, act_out=1))
+    _close("linear_small_m", o2, F.silu(F.silu(xi) @ w.t() + bb), tol=1e-5)
+    lat = torch.randn(2, 4, 6, 5, generator=g)
+    w1 = torch.randn(4, 4, generator=g)
+    b1 = torch.randn(4, generator=g)
+    o3 = torch.empty(2, 4, 6, 5, device=dev)
+    _run(ops.latent_1x1(lat.to(dev), w1.to(dev), b1.to(dev), o3, B=2, Ci=4, Co=4, HW=30, scale=1 / 0.18215))
+    _close("latent_1x1", o3, F.conv2d(lat / 0.18215, w1[:, :, None, None], b1), tol=1e-5)
+
+
+# --------------------------------------------------------------------------- ensembling kernels
+def test_ensemble_kernels_vs_oracle(dev, golden_dir):
+    import os
+    from marigold_amd import ops
+    from oracle import ensemble as oens
+    gold = np.load(os.path.join(golden_dir, "ensemble_ref.npz"))
+    d = torch.from_numpy(gold["d_e10_in"])          # [10,1,32,40]
+    E, HW = d.shape[0], d.shape[2] * d.shape[3]
+    dd = d.reshape(E, HW).to(dev)
+    scratch = torch.empty(128 * E * 35, device=dev, dtype=torch.float64)
+    stats = torch.empty(3 * E + E * E, device=dev, dtype=torch.float64)
+    _run(ops.ens_depth_stats(dd, scratch, stats, E=E, HW=HW))
+    st = stats.cpu()
+    flat = d.reshape(E, HW).double()
+    np.testing.assert_allclose(st[:E], flat.min(1).values, rtol=0, atol=0)
+    np.testing.assert_allclose(st[E:2 * E], flat.max(1).values, rtol=0, atol=0)
+    np.testing.assert_allclose(st[2 * E:3 * E], flat.mean(1), atol=1e-7)
+    cen = flat - flat.mean(1, keepdim=True)
+    np.testing.assert_allclose(st[3 * E:].reshape(E, E), cen @ cen.t() / HW, atol=1e-8)
+    # align + median + MAD + min/max vs the oracle helpers, for arbitrary (s, t)
+    g = torch.Generator().manual_seed(0)
+    param = np.concatenate([1 + 0.3 * torch.rand(E, generator=g).numpy(), 0.1 * torch.randn(E, generator=g).numpy()])
+    al = oens.depth_align(d, param, True, True)
+    pred, mad = oens.depth_reduce(al, "median", True)
+    stv = torch.from_numpy(param).float().to(dev)
+    med = torch.empty(HW, device=dev)
+    madd = torch.empty(HW, device=dev)
+    mm = torch.empty(2, device=dev)
+    scr = torch.empty(2 * 512, device=dev)
+    _run(ops.ens_depth_median(dd, stv, med, madd, mm, scr, E=E, HW=HW))
+    nbad = (med.cpu() != pred.reshape(-1)).sum().item()
+    print(f"[parity] ens_depth_median: {nbad} / {HW} pixels differ from the oracle, "
+          f"max|diff| {(med.cpu() - pred.reshape(-1)).abs().max().item():.3e}")
+    assert torch.equal(med.cpu(), pred.reshape(-1)), "median must be bit-exact (fp32, same op order)"
+    assert torch.equal(madd.cpu(), mad.reshape(-1))
+    assert mm[0].item() == pred.min().item() and mm[1].item() == pred.max().item()
+    _run(ops.ens_depth_norm(med, madd, mm, HW=HW))
+    rng = (pred.max() - pred.min()).clamp(min=1e-6)
+    _close("ens_depth_norm", med, ((pred - pred.min()) / rng).reshape(-1), tol=1e-6)
+    # mean / std reduction, odd E, no-alignment path
+    d3 = torch.from_numpy(gold["d_e3_in"])
+    E3, HW3 = 3, d3.shape[2] * d3.shape[3]
+    pm, ps = oens.depth_reduce(d3, "mean", True)
+    med3 = torch.empty(HW3, device=dev)
+    std3 = torch.empty(HW3, device=dev)
+    _run(ops.ens_depth_median(d3.reshape(E3, HW3).to(dev), None, med3, std3, mm, scr, E=E3, HW=HW3, reduction=1))
+    _close("ens_depth_mean", med3, pm.reshape(-1), tol=1e-6)
+    _close("ens_depth_std", std3, ps.reshape(-1), tol=1e-5)
+    # normals vs the reference's own outputs
+    for name in ("n_e4", "n_e10"):
+        n = torch.from_numpy(gold[f"{name}_in"])
+        E, H, W = n.shape[0], n.shape[2], n.shape[3]
+        nd = n.reshape(E, 3, H * W).to(dev)
+        out = torch.empty(3, H * W, device=dev)
+        unc = torch.empty(H * W, device=dev)
+        _run(ops.ens_normals(nd, out, unc, E=E, HW=H * W))
+        same = (out.cpu().reshape(3, H, W) == torch.from_numpy(gold[f"{name}_closest"])[0]).all(0).float().mean()
+        print(f"[parity] ens_normals/{name}: identical closest member on {same.item() * 100:.2f}% of pixels")
+        assert same.item() >= 0.999
+        _close(f"ens_normals_unc/{name}", unc, torch.from_numpy(gold[f"{name}_unc"]).reshape(-1), tol=1e-5)
+        _run(ops.ens_normals(nd, out, None, E=E, HW=H * W, reduction=1))
+        _close(f"ens_normals_mean/{name}", out, torch.from_numpy(gold[f"{name}_mean"]).reshape(3, -1), tol=1e-5)
+
+
+def test_program_and_graph_replay(dev):
+    """A 3-op program replayed natively and as a captured hipGraph gives identical output."""
+    from marigold_amd import ops
+    g = torch.Generator().manual_seed(8)
+    B, HW, C = 2, 64, 64
+    x = torch.randn(B, HW, C, generator=g).to(dev, torch.bfloat16)
+    part = torch.empty(B, 4, C, 2, device=dev)
+    ss = torch.empty(B, 2, C, device=dev)
+    out = torch.zeros_like(x)
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    seq = ops.OpSeq("gn")
+    seq.add(ops.gn_stats(x, part, B=B, HW=HW, C=C, chunks=4))
+    seq.add(ops.gn_finalize(part, gamma, beta, ss, B=B, C=C, groups=32, chunks=4, HW=HW, eps=1e-5))
+    seq.add(ops.gn_apply(x, ss, out, B=B, HW=HW, C=C, silu=True))
+    seq.run()
+    torch.cuda.synchronize()
+    ref = out.clone()
+    out.zero_()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        seq.capture()
+        out.zero_()
+        seq.run()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    ms = seq.profile()
+    assert len(ms) == 3 and all(m >= 0 for m in ms)
