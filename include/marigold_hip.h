@@ -39,6 +39,7 @@ enum mg_op_kind {
    *  upsampled input size, 0 = none)  i[12] epilogue (MG_EPI_*)  i[13] ldo  i[14] trans_from
    *  (columns >= this go to out2 as [img][n-trans_from][ldt] transposed; -1 = none)
    *  i[15] batch_z  i[16] ldr  i[17] lda  i[18] ldt  i[19] tile variant (0 = auto)  i[20] ldw
+   *  i[21] rowvec broadcast (1 = a single [N] row shared by every image)
    *  l[0..3] z-strides (elements) of A, Wt, out, residual      f[0] scale on the accumulator */
   MG_OP_IGEMM = 1,
   /* GroupNorm, 3 launches (stats partials -> per-(b,c) scale/shift -> apply [+SiLU]).
@@ -104,9 +105,11 @@ enum mg_op_kind {
    *               second-moment matrix (closed form of the pairwise-RMSE cost, :138-145).
    *   p[0] d f32 [E][HW] p[1] blocks f64 scratch p[2] out f64 [3E + E*E] ; i: E ; l[0] HW
    * DEPTH_MEDIAN: aligned = s*d+t; lower-middle median over E (+MAD); block min/max.
-   *   p[0] d f32 [E][HW] p[1] st f32 [2E] p[2] med f32 [HW]|NULL p[3] mad f32 [HW]|NULL
-   *   p[4] minmax f32 [2] (final, via last-block reduce) p[5] scratch ; i: E, reduction(0
-   *   median,1 mean) ; l[0] HW
+   *   p[0] d f32 [E][HW] p[1] st f32 [s[E], t[E]] | NULL (no alignment) p[2] med f32 [HW]|NULL
+   *   p[3] mad f32 [HW]|NULL  p[4] out f32 [2+2E] = min, max of the prediction and the raw member
+   *   values d[.][argmin px], d[.][argmax px] (exact sub-gradient of the regulariser on the
+   *   host)  p[5] scratch (>= 12288 B) ; i: E, reduction(0 median,1 mean), has_shift ; l[0] HW
+   * (DEPTH_STATS scratch: >= 128*E*35 doubles)
    * DEPTH_NORM  : out = (med - lo)/range ; unc /= range.  p[0] med p[1] mad|NULL p[2] minmax
    *   ; i[0] shift_invariant ; l[0] HW
    * NORMALS     : p[0] n f32 [E][3][HW] p[1] out f32 [3][HW] p[2] unc f32 [HW]|NULL ;

@@ -1,0 +1,25 @@
+"""marigold_amd - MI355X-native engine for the Marigold inference hot path, behind the
+reference's pipeline API (exports mirror /root/reference/marigold/__init__.py:31-41)."""
+from .pipeline import (MarigoldDepthOutput, MarigoldDepthPipeline,  # noqa: F401
+                       MarigoldNormalsOutput, MarigoldNormalsPipeline)
+
+MarigoldPipeline = MarigoldDepthPipeline  # for backward compatibility
+
+
+def build_synthetic_pipeline(kind="depth", unet_cfg=None, vae_cfg=None, scheduler=None, seed=1234, **kw):
+    """A pipeline on seeded synthetic weights in the real architecture (no checkpoints exist in
+    this environment - BASELINE.md §4)."""
+    from . import synthetic as syn
+    from .arch import UNetConfig, VAEConfig
+    from .modules import AutoencoderKLHIP, UNet2DConditionModelHIP
+    from .schedulers import DDIMScheduler
+    unet_cfg = unet_cfg or UNetConfig()
+    vae_cfg = vae_cfg or VAEConfig()
+    unet = UNet2DConditionModelHIP(syn.synthetic_unet_state_dict(unet_cfg, seed), unet_cfg)
+    vae = AutoencoderKLHIP(syn.synthetic_vae_state_dict(vae_cfg, seed), vae_cfg)
+    emb = syn.synthetic_text_embedding(unet_cfg.cross_attention_dim)
+    scheduler = scheduler or DDIMScheduler()
+    cls = MarigoldDepthPipeline if kind == "depth" else MarigoldNormalsPipeline
+    kw.setdefault("default_denoising_steps", 4)
+    kw.setdefault("default_processing_resolution", 768)
+    return cls(unet=unet, vae=vae, scheduler=scheduler, empty_text_embed=emb, **kw)

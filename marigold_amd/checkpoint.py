@@ -1,0 +1,109 @@
+"""Checkpoint IO in the diffusers folder layout the reference loads with ``from_pretrained``
+(script/depth/run.py:203-215): ``model_index.json``, ``unet/config.json`` +
+``diffusion_pytorch_model[.fp16].safetensors``, ``vae/...``, ``scheduler/scheduler_config.json``,
+optional ``text_encoder/`` + ``tokenizer/`` (or a precomputed ``empty_text_embed.safetensors``).
+"""
+import json
+import os
+
+import torch
+from safetensors.torch import load_file, save_file
+
+from .arch import UNetConfig, VAEConfig
+from .modules import AutoencoderKLHIP, UNet2DConditionModelHIP
+from .schedulers import DDIMScheduler, LCMScheduler
+
+_SCHEDULERS = {"DDIMScheduler": DDIMScheduler, "LCMScheduler": LCMScheduler}
+
+
+def _weights(folder, variant):
+    names = ([f"diffusion_pytorch_model.{variant}.safetensors"] if variant else []) + \
+        ["diffusion_pytorch_model.safetensors"]
+    for n in names:
+        p = os.path.join(folder, n)
+        if os.path.exists(p):
+            return load_file(p)
+    raise FileNotFoundError(f"no safetensors weights in {folder} (tried {names})")
+
+
+def _json(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def _rename_legacy_vae_keys(sd):
+    """Older AutoencoderKL files use query/key/value/proj_attn."""
+    ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+    out = {}
+    for k, v in sd.items():
+        parts = k.split(".")
+        if "attentions" in parts:
+            parts = [ren.get(p, p) for p in parts]
+            if v.dim() == 4 and parts[-1] == "weight" and parts[-2] in ("to_q", "to_k", "to_v", "0"):
+                v = v.reshape(v.shape[0], v.shape[1])
+        out[".".join(parts)] = v
+    return out
+
+
+def load_pipeline(cls, path, variant=None, torch_dtype=None, **kw):
+    index = _json(os.path.join(path, "model_index.json"))
+    ucfg = _json(os.path.join(path, "unet", "config.json"))
+    unet_cfg = UNetConfig(in_channels=ucfg.get("in_channels", 8), out_channels=ucfg.get("out_channels", 4),
+                          block_out_channels=tuple(ucfg.get("block_out_channels", (320, 640, 1280, 1280))),
+                          layers_per_block=ucfg.get("layers_per_block", 2),
+                          heads=tuple(ucfg.get("attention_head_dim", (5, 10, 20, 20))),
+                          cross_attention_dim=ucfg.get("cross_attention_dim", 1024),
+                          norm_groups=ucfg.get("norm_num_groups", 32))
+    vcfg = _json(os.path.join(path, "vae", "config.json"))
+    vae_cfg = VAEConfig(block_out_channels=tuple(vcfg.get("block_out_channels", (128, 256, 512, 512))),
+                        layers_per_block=vcfg.get("layers_per_block", 2),
+                        latent_channels=vcfg.get("latent_channels", 4),
+                        norm_groups=vcfg.get("norm_num_groups", 32))
+    unet = UNet2DConditionModelHIP(_weights(os.path.join(path, "unet"), variant), unet_cfg)
+    vae = AutoencoderKLHIP(_rename_legacy_vae_keys(_weights(os.path.join(path, "vae"), variant)), vae_cfg)
+    scfg = _json(os.path.join(path, "scheduler", "scheduler_config.json"))
+    sname = scfg.get("_class_name", "DDIMScheduler")
+    if sname not in _SCHEDULERS:
+        raise RuntimeError(f"Unsupported scheduler type: {sname}")
+    allowed = set(_SCHEDULERS[sname]._defaults)
+    scheduler = _SCHEDULERS[sname](**{k: v for k, v in scfg.items() if k in allowed})
+    text_encoder = tokenizer = empty = None
+    emb = os.path.join(path, "empty_text_embed.safetensors")
+    if os.path.exists(emb):
+        empty = load_file(emb)["empty_text_embed"]
+    elif os.path.isdir(os.path.join(path, "text_encoder")):
+        from transformers import CLIPTextModel, CLIPTokenizer
+        text_encoder = CLIPTextModel.from_pretrained(os.path.join(path, "text_encoder"))
+        tokenizer = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
+    extra = {k: index[k] for k in ("scale_invariant", "shift_invariant", "default_denoising_steps",
+                                   "default_processing_resolution") if k in index}
+    if cls.__name__ == "MarigoldNormalsPipeline":
+        extra.pop("scale_invariant", None)
+        extra.pop("shift_invariant", None)
+    return cls(unet=unet, vae=vae, scheduler=scheduler, text_encoder=text_encoder, tokenizer=tokenizer,
+               empty_text_embed=empty, **extra)
+
+
+def save_synthetic_checkpoint(path, cls_name, unet_sd, vae_sd, unet_cfg, vae_cfg, scheduler, empty_text_embed,
+                              **model_index):
+    """Write a checkpoint folder in the layout above (used by tests; weights as safetensors)."""
+    for sub in ("unet", "vae", "scheduler"):
+        os.makedirs(os.path.join(path, sub), exist_ok=True)
+    save_file({k: v.contiguous() for k, v in unet_sd.items()},
+              os.path.join(path, "unet", "diffusion_pytorch_model.safetensors"))
+    save_file({k: v.contiguous() for k, v in vae_sd.items()},
+              os.path.join(path, "vae", "diffusion_pytorch_model.safetensors"))
+    with open(os.path.join(path, "unet", "config.json"), "w") as f:
+        json.dump(dict(_class_name="UNet2DConditionModel", in_channels=unet_cfg.in_channels,
+                       out_channels=unet_cfg.out_channels, block_out_channels=list(unet_cfg.block_out_channels),
+                       layers_per_block=unet_cfg.layers_per_block, attention_head_dim=list(unet_cfg.heads),
+                       cross_attention_dim=unet_cfg.cross_attention_dim, norm_num_groups=unet_cfg.norm_groups), f)
+    with open(os.path.join(path, "vae", "config.json"), "w") as f:
+        json.dump(dict(_class_name="AutoencoderKL", block_out_channels=list(vae_cfg.block_out_channels),
+                       layers_per_block=vae_cfg.layers_per_block, latent_channels=vae_cfg.latent_channels,
+                       norm_num_groups=vae_cfg.norm_groups), f)
+    with open(os.path.join(path, "scheduler", "scheduler_config.json"), "w") as f:
+        json.dump(dict(_class_name=type(scheduler).__name__, **vars(scheduler.config)), f)
+    save_file({"empty_text_embed": empty_text_embed.contiguous()}, os.path.join(path, "empty_text_embed.safetensors"))
+    with open(os.path.join(path, "model_index.json"), "w") as f:
+        json.dump(dict(_class_name=cls_name, **model_index), f)

@@ -127,9 +127,12 @@ __device__ __forceinline__ float select_rank(const float (&a)[E_], int E, int k)
 template <int E_>
 __global__ __launch_bounds__(256) void depth_median_kernel(const float* __restrict__ d, const float* __restrict__ st,
                                                            float* __restrict__ med, float* __restrict__ mad,
-                                                           float* __restrict__ blockmm, int E, long long HW,
+                                                           float* __restrict__ blockmm, long long* __restrict__ blockpx,
+                                                           int E, long long HW,
                                                            int reduction, int has_shift, int aligned) {
   __shared__ float red[8];
+  __shared__ long long redp[8];
+  long long pmn = 0, pmx = 0;
   float sc[E_], sh[E_];
 #pragma unroll
   for (int e = 0; e < E_; ++e) {
@@ -173,41 +176,54 @@ __global__ __launch_bounds__(256) void depth_median_kernel(const float* __restri
     }
     if (med) med[p] = pred;
     if (mad) mad[p] = unc;
-    mn = fminf(mn, pred);
-    mx = fmaxf(mx, pred);
+    if (pred < mn) { mn = pred; pmn = p; }
+    if (pred > mx) { mx = pred; pmx = p; }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, o));
-    mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float omn = __shfl_xor(mn, o), omx = __shfl_xor(mx, o);
+    const long long opmn = __shfl_xor(pmn, o), opmx = __shfl_xor(pmx, o);
+    if (omn < mn || (omn == mn && opmn < pmn)) { mn = omn; pmn = opmn; }
+    if (omx > mx || (omx == mx && opmx < pmx)) { mx = omx; pmx = opmx; }
   }
-  if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+  if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; redp[wave] = pmn; redp[4 + wave] = pmx; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    blockmm[2 * blockIdx.x] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-    blockmm[2 * blockIdx.x + 1] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    for (int w = 1; w < 4; ++w) {
+      if (red[w] < red[0] || (red[w] == red[0] && redp[w] < redp[0])) { red[0] = red[w]; redp[0] = redp[w]; }
+      if (red[4 + w] > red[4] || (red[4 + w] == red[4] && redp[4 + w] < redp[4])) { red[4] = red[4 + w]; redp[4] = redp[4 + w]; }
+    }
+    blockmm[2 * blockIdx.x] = red[0];
+    blockmm[2 * blockIdx.x + 1] = red[4];
+    blockpx[2 * blockIdx.x] = redp[0];
+    blockpx[2 * blockIdx.x + 1] = redp[4];
   }
 }
 
-__global__ __launch_bounds__(256) void minmax_final_kernel(const float* __restrict__ blockmm, float* __restrict__ out, int nblk) {
-  __shared__ float red[8];
-  float mn = 3.0e38f, mx = -3.0e38f;
-  for (int i = threadIdx.x; i < nblk; i += 256) {
-    mn = fminf(mn, blockmm[2 * i]);
-    mx = fmaxf(mx, blockmm[2 * i + 1]);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, o));
-    mx = fmaxf(mx, __shfl_xor(mx, o));
-  }
-  if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
-  __syncthreads();
+// out = [min, max, d[0..E)[argmin px], d[0..E)[argmax px]]  (raw member values at the extremal
+// pixels of the prediction: the host derives the exact sub-gradient of the regulariser from them)
+__global__ __launch_bounds__(64) void minmax_final_kernel(const float* __restrict__ blockmm,
+                                                          const long long* __restrict__ blockpx,
+                                                          const float* __restrict__ d, float* __restrict__ out,
+                                                          int nblk, int E, long long HW) {
+  __shared__ long long px[2];
   if (threadIdx.x == 0) {
-    out[0] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-    out[1] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    float mn = blockmm[0], mx = blockmm[1];
+    long long pmn = blockpx[0], pmx = blockpx[1];
+    for (int i = 1; i < nblk; ++i) {
+      const float a = blockmm[2 * i], b = blockmm[2 * i + 1];
+      const long long pa = blockpx[2 * i], pb = blockpx[2 * i + 1];
+      if (a < mn || (a == mn && pa < pmn)) { mn = a; pmn = pa; }
+      if (b > mx || (b == mx && pb < pmx)) { mx = b; pmx = pb; }
+    }
+    out[0] = mn; out[1] = mx;
+    px[0] = pmn; px[1] = pmx;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += 64) {
+    out[2 + e] = d[(long long)e * HW + px[0]];
+    out[2 + E + e] = d[(long long)e * HW + px[1]];
   }
 }
 
@@ -257,7 +273,8 @@ template <int E_>
 void launch_median(const mg_op* op, int nblk, hipStream_t s) {
   hipLaunchKernelGGL(depth_median_kernel<E_>, dim3(nblk), dim3(256), 0, s, (const float*)op->p[0],
                      (const float*)op->p[1], (float*)op->p[2], (float*)op->p[3], (float*)op->p[5],
-                     op->i[0], op->l[0], op->i[1], op->i[2], op->p[1] != nullptr);
+                     (long long*)((char*)op->p[5] + 8 * ENS_BLOCKS), op->i[0], op->l[0], op->i[1], op->i[2],
+                     op->p[1] != nullptr);
 }
 
 }  // namespace
@@ -286,8 +303,9 @@ int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
       else if (E <= 10) launch_median<10>(op, nblk, s);
       else if (E <= 16) launch_median<16>(op, nblk, s);
       else launch_median<EMAX>(op, nblk, s);
-      hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, s, (const float*)op->p[5],
-                         (float*)op->p[4], nblk);
+      hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, s, (const float*)op->p[5],
+                         (const long long*)((char*)op->p[5] + 8 * ENS_BLOCKS), (const float*)op->p[0],
+                         (float*)op->p[4], nblk, E, HW);
       break;
     }
     case MG_OP_ENS_DEPTH_NORM: {

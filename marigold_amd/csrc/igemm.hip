@@ -33,7 +33,7 @@ struct IgemmArgs {
   void* out2;
   const void* zero;
   int H, W, Cin, Ho, Wo, N, taps, stride, pad, Hu, Wu, epi, ldo, trans_from, ldr, lda, ldt, ldw;
-  int M, rows_per_img, tiles_m, tiles_n, cpt, KT;
+  int M, rows_per_img, tiles_m, tiles_n, cpt, KT, rv_stride;
   long long sA, sW, sO, sR;
   float scale;
 };
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(const IgemmArgs a)
       const int m = m0 + wm * TM + mi * 32 + l31;
       if (m >= a.M) continue;
       const int img = m / a.rows_per_img;
-      const float* rv = a.rowvec ? a.rowvec + (long long)img * a.N : nullptr;
+      const float* rv = a.rowvec ? a.rowvec + (long long)img * a.rv_stride : nullptr;
       if (a.epi == MG_EPI_GEGLU) {
         // Weight rows are pre-interleaved in 16-row groups: rows [16i,16i+8) = u(8i..8i+7),
         // rows [16i+8,16i+16) = gate(8i..8i+7); a lane's register groups g and g+1 pair up.
@@ -279,15 +279,26 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int m = m0 + wm * TM + mi * 32 + 8 * g + 4 * half;
-          if (m >= a.M) continue;  // M % 4 == 0 is required by the launcher
-          const int img = m / a.rows_per_img;
-          const int tok = m - img * a.rows_per_img;
-          uint2 pk;
-          pk.x = pack2bf(acc[ni][mi][4 * g + 0] * scale + bv, acc[ni][mi][4 * g + 1] * scale + bv);
-          pk.y = pack2bf(acc[ni][mi][4 * g + 2] * scale + bv, acc[ni][mi][4 * g + 3] * scale + bv);
-          bf16_t* o = (bf16_t*)a.out2 + (long long)z * a.sO +
-                      ((long long)img * ctr + nn) * a.ldt + tok;
-          *(uint2*)o = pk;
+          if (m >= a.M) continue;
+          if ((a.rows_per_img & 3) == 0) {  // 4 consecutive tokens of one image: one 8-byte store
+            const int img = m / a.rows_per_img;
+            const int tok = m - img * a.rows_per_img;
+            uint2 pk;
+            pk.x = pack2bf(acc[ni][mi][4 * g + 0] * scale + bv, acc[ni][mi][4 * g + 1] * scale + bv);
+            pk.y = pack2bf(acc[ni][mi][4 * g + 2] * scale + bv, acc[ni][mi][4 * g + 3] * scale + bv);
+            bf16_t* o = (bf16_t*)a.out2 + (long long)z * a.sO + ((long long)img * ctr + nn) * a.ldt + tok;
+            *(uint2*)o = pk;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int mj = m + j;
+              if (mj >= a.M) break;
+              const int img = mj / a.rows_per_img;
+              const int tok = mj - img * a.rows_per_img;
+              ((bf16_t*)a.out2)[(long long)z * a.sO + ((long long)img * ctr + nn) * a.ldt + tok] =
+                  f2bf(acc[ni][mi][4 * g + j] * scale + bv);
+            }
+          }
         }
       }
     }
@@ -339,6 +350,7 @@ int mg_launch_igemm(const mg_op* op, hipStream_t s) {
   a.ldt = op->i[18];
   int variant = op->i[19];
   a.ldw = op->i[20] > 0 ? op->i[20] : a.taps * a.Cin;
+  a.rv_stride = op->i[21] ? 0 : a.N;  // i[21] != 0: one rowvec row shared by all images
   a.sA = op->l[0]; a.sW = op->l[1]; a.sO = op->l[2]; a.sR = op->l[3];
   a.scale = op->f[0] == 0.f ? 1.f : op->f[0];
   a.rows_per_img = a.Ho * a.Wo;
@@ -355,7 +367,7 @@ int mg_launch_igemm(const mg_op* op, hipStream_t s) {
   MG_REQUIRE(a.M > 0 && a.stride >= 1, "igemm: empty problem");
   MG_REQUIRE(a.epi != MG_EPI_GEGLU || (a.N % 32 == 0), "igemm: GEGLU needs N %% 32 == 0");
   if (a.trans_from >= 0)
-    MG_REQUIRE(a.out2 && a.ldt > 0 && a.rows_per_img % 4 == 0, "igemm: bad transposed section");
+    MG_REQUIRE(a.out2 && a.ldt > 0 && a.ldt % 4 == 0, "igemm: bad transposed section");
   MG_REQUIRE(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.Wt % 16 == 0), "igemm: A/Wt need 16-B alignment");
   if (variant == 0) {
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch_z;

@@ -1,0 +1,486 @@
+"""Program builders: walk the SD-v2 UNet / AutoencoderKL structure (``arch.py``) and emit the
+flat op programs that libmarigold_hip replays.  This is the host-side mirror of the module
+seams the reference calls (marigold_depth_pipeline.py:461-463 ``unet(...)``, :491-492
+``vae.encoder``/``quant_conv``, :512-513 ``post_quant_conv``/``vae.decoder``); all arithmetic
+happens in the HIP kernels, torch only owns the device buffers.
+
+Data layout: activations bf16 NHWC; latents / decoded maps fp32 NCHW (the reference's layout at
+the pipeline boundary).  Buffers come from a size-keyed pool that is recycled along the static
+program order, so the working set of a forward stays small and cache-friendly.
+"""
+import math
+from collections import defaultdict
+
+import torch
+
+from . import _lib as L
+from . import ops as O
+from . import weights as Wm
+from .arch import UNetConfig, VAEConfig, unet_up_resnet_channels
+
+LATENT_SCALE = 0.18215  # marigold_depth_pipeline.py:118
+
+
+class Act:
+    """A bf16 NHWC activation [B][H][W][C] living in a pooled buffer."""
+    __slots__ = ("t", "B", "H", "W", "C")
+
+    def __init__(self, t, B, H, W, C):
+        self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
+
+    @property
+    def M(self):
+        return self.B * self.H * self.W
+
+    @property
+    def HW(self):
+        return self.H * self.W
+
+
+class Pool:
+    def __init__(self, device):
+        self.device = device
+        self.free_lists = defaultdict(list)
+        self.all = []
+        self.bytes = 0
+
+    def get(self, nbytes):
+        nbytes = (int(nbytes) + 255) // 256 * 256
+        fl = self.free_lists[nbytes]
+        if fl:
+            return fl.pop()
+        t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.all.append(t)
+        self.bytes += nbytes
+        return t
+
+    def put(self, t):
+        self.free_lists[t.numel()].append(t)
+
+
+class WeightStore:
+    """Device-resident, kernel-ready weights derived from a diffusers-layout state dict."""
+
+    def __init__(self, sd, device):
+        self.sd = sd
+        self.device = device
+        self.cache = {}
+
+    def _memo(self, key, fn):
+        if key not in self.cache:
+            self.cache[key] = fn()
+        return self.cache[key]
+
+    def has(self, name):
+        return f"{name}.weight" in self.sd
+
+    def conv3x3(self, name):
+        return self._memo(("c3", name), lambda: Wm.bf16(Wm.pack_conv3x3(self.sd[f"{name}.weight"].float()), self.device))
+
+    def mat(self, name):  # Linear or 1x1 conv -> [N][K]
+        def f():
+            w = self.sd[f"{name}.weight"].float()
+            return Wm.bf16(w.reshape(w.shape[0], -1), self.device)
+        return self._memo(("m", name), f)
+
+    def vec(self, key):
+        return self._memo(("v", key), lambda: Wm.f32(self.sd[key], self.device))
+
+    def bias(self, name):
+        return self.vec(f"{name}.bias") if f"{name}.bias" in self.sd else None
+
+    def f32mat(self, name):
+        return self._memo(("fm", name), lambda: Wm.f32(self.sd[f"{name}.weight"].reshape(self.sd[f"{name}.weight"].shape[0], -1), self.device))
+
+    def small_conv(self, name):
+        return self._memo(("sc", name), lambda: Wm.f32(Wm.pack_small_conv(self.sd[f"{name}.weight"]), self.device))
+
+    def geglu(self, name):
+        def f():
+            w, b = Wm.pack_geglu(self.sd[f"{name}.weight"].float(), self.sd[f"{name}.bias"].float())
+            return Wm.bf16(w, self.device), Wm.f32(b, self.device)
+        return self._memo(("gg", name), f)
+
+    def qkv(self, prefix, with_bias):
+        def f():
+            w = Wm.pack_qkv(*(self.sd[f"{prefix}.{q}.weight"].float() for q in ("to_q", "to_k", "to_v")))
+            b = None
+            if with_bias:
+                b = Wm.f32(torch.cat([self.sd[f"{prefix}.{q}.bias"].float() for q in ("to_q", "to_k", "to_v")]), self.device)
+            return Wm.bf16(w, self.device), b
+        return self._memo(("qkv", prefix), f)
+
+    def cross(self, prefix, ctx, heads):
+        def f():
+            wqk, vot, npad = Wm.cross_attention_tables(
+                self.sd[f"{prefix}.to_q.weight"], self.sd[f"{prefix}.to_k.weight"],
+                self.sd[f"{prefix}.to_v.weight"], self.sd[f"{prefix}.to_out.0.weight"], ctx, heads)
+            return Wm.bf16(wqk, self.device), Wm.bf16(vot, self.device), npad
+        return self._memo(("x", prefix), f)
+
+
+class Builder:
+    """Emits ops into an OpSeq, allocating/recycling activation buffers from a Pool."""
+
+    def __init__(self, seq, pool, ws, groups=32):
+        self.seq, self.pool, self.ws, self.groups = seq, pool, ws, groups
+        self.dev = pool.device
+        self.persist = {}
+
+    # ---- buffers -------------------------------------------------------------------------
+    def new(self, B, H, W, C):
+        return Act(self.pool.get(B * H * W * C * 2), B, H, W, C)
+
+    def raw(self, nbytes):
+        return self.pool.get(nbytes)
+
+    def free(self, *xs):
+        for x in xs:
+            if x is None:
+                continue
+            self.pool.put(x.t if isinstance(x, Act) else x)
+
+    def zeros_persistent(self, key, nbytes):
+        """A dedicated zero-initialised buffer (never recycled): V^T pad columns must stay 0."""
+        if key not in self.persist:
+            self.persist[key] = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)
+        return self.persist[key]
+
+    def add(self, op, label):
+        self.seq.add(op, label)
+
+    # ---- primitive layers ----------------------------------------------------------------
+    def group_norm(self, x, name, eps, silu):
+        C, B, HW = x.C, x.B, x.HW
+        chunks = max(1, min(64, HW // 16))
+        part = self.raw(B * chunks * C * 2 * 4)
+        ss = self.raw(B * 2 * C * 4)
+        out = self.new(x.B, x.H, x.W, C)
+        self.add(O.gn_stats(x.t, part, B=B, HW=HW, C=C, chunks=chunks), f"{name}.stats")
+        self.add(O.gn_finalize(part, self.ws.vec(f"{name}.weight"), self.ws.vec(f"{name}.bias"), ss, B=B,
+                               C=C, groups=self.groups, chunks=chunks, HW=HW, eps=eps), f"{name}.finalize")
+        self.add(O.gn_apply(x.t, ss, out.t, B=B, HW=HW, C=C, silu=silu), f"{name}.apply")
+        self.free(part, ss)
+        return out
+
+    def conv3x3(self, x, name, cout, *, stride=1, pad=1, up=None, rowvec=None, residual=None, out=None):
+        H, W = (up if up else (x.H, x.W))
+        if stride == 1:
+            Ho, Wo = H, W
+        elif pad == 1:
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        else:  # VAE encoder: pad (0,1,0,1) then stride 2
+            Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+        if out is None:
+            out = self.new(x.B, Ho, Wo, cout)
+        self.add(O.igemm(x.t, self.ws.conv3x3(name), out.t, B=x.B, H=x.H, W=x.W, Cin=x.C, Ho=Ho, Wo=Wo,
+                         N=cout, taps=9, stride=stride, pad=pad, up=up, bias=self.ws.bias(name),
+                         rowvec=rowvec, rowvec_bcast=rowvec is not None,
+                         residual=None if residual is None else residual.t), name)
+        return out
+
+    def dense(self, x, wt, bias, N, *, residual=None, out=None, epi=L.EPI_BF16, label="", K=None, out_dtype_bytes=2):
+        """x: Act viewed as [M][C]; wt: [N][K] bf16."""
+        M, K = x.M, (K or x.C)
+        n_out = N // 2 if epi == L.EPI_GEGLU else N
+        if out is None:
+            out = Act(self.pool.get(M * n_out * out_dtype_bytes), x.B, x.H, x.W, n_out)
+        self.add(O.linear(x.t, wt, out.t, M=M, K=K, N=N, bias=bias, epi=epi,
+                          residual=None if residual is None else residual.t), label)
+        return out
+
+    def layer_norm(self, x, name):
+        out = self.new(x.B, x.H, x.W, x.C)
+        self.add(O.layernorm(x.t, self.ws.vec(f"{name}.weight"), self.ws.vec(f"{name}.bias"), out.t,
+                             M=x.M, C=x.C, eps=1e-5), name)
+        return out
+
+    # ---- composite blocks ----------------------------------------------------------------
+    def resnet(self, x, name, cout, eps, temb_row=None):
+        h = self.group_norm(x, f"{name}.norm1", eps, True)
+        h1 = self.conv3x3(h, f"{name}.conv1", cout, rowvec=temb_row)
+        self.free(h)
+        h2 = self.group_norm(h1, f"{name}.norm2", eps, True)
+        self.free(h1)
+        if self.ws.has(f"{name}.conv_shortcut"):
+            res = self.dense(x, self.ws.mat(f"{name}.conv_shortcut"), self.ws.bias(f"{name}.conv_shortcut"),
+                             cout, label=f"{name}.conv_shortcut")
+            out = self.conv3x3(h2, f"{name}.conv2", cout, residual=res, out=res)  # in-place residual add
+        else:
+            out = self.conv3x3(h2, f"{name}.conv2", cout, residual=x)
+        self.free(h2)
+        return out
+
+    def self_attention(self, h, y, prefix, heads):
+        """h += to_out(attn(y)); y = LN(h) already computed.  Head dim 64."""
+        C, B, T, M = h.C, h.B, h.HW, h.M
+        wqkv, _ = self.ws.qkv(prefix, False)
+        ldvt = (T + 63) // 64 * 64
+        qk = self.raw(M * 2 * C * 2)
+        vt = self.zeros_persistent(("vt", B, C, ldvt), B * C * ldvt * 2)
+        self.add(O.igemm(y.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, out2=vt,
+                         trans_from=2 * C, ldt=ldvt), f"{prefix}.qkv")
+        o = self.new(h.B, h.H, h.W, C)
+        self.add(O.flash_attn64(qk, qk.data_ptr() + C * 2, vt, o.t, B=B, heads=heads, Ntok=T, ldq=2 * C,
+                                ldo=C, ldvt=ldvt, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C,
+                                scale=1.0 / math.sqrt(C // heads)), f"{prefix}.flash")
+        self.free(qk)
+        self.dense(o, self.ws.mat(f"{prefix}.to_out.0"), self.ws.bias(f"{prefix}.to_out.0"), C,
+                   residual=h, out=h, label=f"{prefix}.to_out")
+        self.free(o)
+
+    def cross_attention2(self, h, y, prefix, heads, ctx):
+        """h += attn2(y, ctx) with the 2-token context collapsed into two thin GEMMs."""
+        C, M = h.C, h.M
+        wqk, vot, npad = self.ws.cross(prefix, ctx, heads)
+        s = self.raw(M * npad * 4)
+        self.add(O.linear(y.t, wqk, s, M=M, K=C, N=npad, epi=L.EPI_F32), f"{prefix}.scores")
+        p = self.raw(M * npad * 2)
+        self.add(O.softmax_pairs(s, p, M=M, pairs=heads, lds=npad, ldp=npad,
+                                 scale=1.0 / math.sqrt(C // heads)), f"{prefix}.softmax2")
+        self.add(O.linear(p, vot, h.t, M=M, K=npad, N=C, bias=self.ws.bias(f"{prefix}.to_out.0"),
+                          residual=h.t), f"{prefix}.blend")
+        self.free(s, p)
+
+    def transformer(self, x, name, heads, ctx):
+        C = x.C
+        g = self.group_norm(x, f"{name}.norm", 1e-6, False)
+        h = self.dense(g, self.ws.mat(f"{name}.proj_in"), self.ws.bias(f"{name}.proj_in"), C,
+                       label=f"{name}.proj_in")
+        self.free(g)
+        b = f"{name}.transformer_blocks.0"
+        y = self.layer_norm(h, f"{b}.norm1")
+        self.self_attention(h, y, f"{b}.attn1", heads)
+        self.free(y)
+        y = self.layer_norm(h, f"{b}.norm2")
+        self.cross_attention2(h, y, f"{b}.attn2", heads, ctx)
+        self.free(y)
+        y = self.layer_norm(h, f"{b}.norm3")
+        wg, bg = self.ws.geglu(f"{b}.ff.net.0.proj")
+        ff = self.dense(y, wg, bg, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu")
+        self.free(y)
+        self.dense(ff, self.ws.mat(f"{b}.ff.net.2"), self.ws.bias(f"{b}.ff.net.2"), C, residual=h, out=h,
+                   label=f"{b}.ff.out")
+        self.free(ff)
+        # NB: the GEMM input must never alias its output (other column tiles still read it)
+        out = self.dense(h, self.ws.mat(f"{name}.proj_out"), self.ws.bias(f"{name}.proj_out"), C,
+                         residual=x, out=x, label=f"{name}.proj_out")
+        self.free(h)
+        return out
+
+    def vae_attention(self, x, name):
+        """Single-head d=C attention of the VAE mid block with materialised fp32 scores."""
+        C, B, T, M = x.C, x.B, x.HW, x.M
+        g = self.group_norm(x, f"{name}.group_norm", 1e-6, False)
+        wqkv, bqkv = self.ws.qkv(name, True)
+        ldp = (T + 63) // 64 * 64
+        qk = self.raw(M * 2 * C * 2)
+        vt = self.zeros_persistent(("vvt", B, C, ldp), B * C * ldp * 2)
+        self.add(O.igemm(g.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, bias=bqkv,
+                         out2=vt, trans_from=2 * C, ldt=ldp), f"{name}.qkv")
+        self.free(g)
+        s = self.raw(B * T * T * 4)
+        self.add(O.igemm(qk, qk.data_ptr() + C * 2, s, B=1, H=T, W=1, Cin=C, Ho=T, Wo=1, N=T,
+                         epi=L.EPI_F32, ldo=T, lda=2 * C, ldw=2 * C, batch_z=B,
+                         zstrides=(T * 2 * C, T * 2 * C, T * T, 0), scale=1.0 / math.sqrt(C)), f"{name}.scores")
+        self.free(qk)
+        p = self.raw(B * T * ldp * 2)
+        self.add(O.softmax_rows(s, p, R=B * T, ncols=T, lds=T, ldp=ldp), f"{name}.softmax")
+        self.free(s)
+        o = self.new(x.B, x.H, x.W, C)
+        self.add(O.igemm(p, vt, o.t, B=1, H=T, W=1, Cin=ldp, Ho=T, Wo=1, N=C, lda=ldp, ldw=ldp, batch_z=B,
+                         zstrides=(T * ldp, C * ldp, T * C, 0)), f"{name}.pv")
+        self.free(p)
+        out = self.dense(o, self.ws.mat(f"{name}.to_out.0"), self.ws.bias(f"{name}.to_out.0"), C,
+                         residual=x, label=f"{name}.to_out")
+        self.free(o)
+        return out
+
+
+# ------------------------------------------------------------------------------------------ UNet
+
+def sinusoid_table(timesteps, dim):
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0): [cos | sin], fp32."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    arg = torch.as_tensor(timesteps, dtype=torch.float32)[:, None] * freqs[None]
+    return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
+
+
+def unet_resnet_names(cfg: UNetConfig):
+    """[(state-dict prefix, cout)] of every ResNet block, in execution order."""
+    boc = list(cfg.block_out_channels)
+    n = len(boc)
+    names = []
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            names.append((f"down_blocks.{i}.resnets.{j}", boc[i]))
+    names += [("mid_block.resnets.0", boc[-1]), ("mid_block.resnets.1", boc[-1])]
+    for (i, j, _rin, _skip, out) in unet_up_resnet_channels(cfg):
+        names.append((f"up_blocks.{i}.resnets.{j}", out))
+    return names
+
+
+def emit_time_embeddings(bld, cfg, timesteps):
+    """Ops computing, for all T steps at once, the per-ResNet time-embedding projections
+    (sinusoid -> Linear -> SiLU -> Linear -> [SiLU -> Linear] per block).  Returns
+    {resnet prefix: fp32 tensor [T][cout]}."""
+    ws, dev = bld.ws, bld.dev
+    T = len(timesteps)
+    c0, td = cfg.block_out_channels[0], cfg.temb_dim
+    sin = bld.seq.hold(sinusoid_table(list(timesteps), c0).to(dev))
+    e1 = bld.seq.hold(torch.empty(T, td, device=dev))
+    emb = bld.seq.hold(torch.empty(T, td, device=dev))
+    bld.add(O.linear_small_m(sin, ws.f32mat("time_embedding.linear_1"), ws.bias("time_embedding.linear_1"), e1,
+                             M=T, N=td, K=c0, act_out=1), "time_embedding.linear_1")
+    bld.add(O.linear_small_m(e1, ws.f32mat("time_embedding.linear_2"), ws.bias("time_embedding.linear_2"), emb,
+                             M=T, N=td, K=td), "time_embedding.linear_2")
+    table = {}
+    for name, cout in unet_resnet_names(cfg):
+        t = bld.seq.hold(torch.empty(T, cout, device=dev))
+        bld.add(O.linear_small_m(emb, ws.f32mat(f"{name}.time_emb_proj"), ws.bias(f"{name}.time_emb_proj"), t,
+                                 M=T, N=cout, K=td, act_in=1), f"{name}.time_emb_proj")
+        table[name] = t
+    return table
+
+
+def emit_unet_forward(bld, cfg, ctx, rgb_latent, x_latent, eps_out, temb_table, step, B, h, w):
+    """One UNet forward: eps_out[B,4,h,w] = unet(cat(rgb_latent, x_latent), t_step, ctx).
+    rgb_latent is [1,4,h,w] (shared by all members) or [B,4,h,w]."""
+    ws = bld.ws
+    boc = list(cfg.block_out_channels)
+    n = len(boc)
+
+    def trow(name, cout):
+        return temb_table[name].data_ptr() + step * cout * 4
+
+    c0 = boc[0]
+    x = bld.new(B, h, w, c0)
+    cin = ws.sd["conv_in.weight"].shape[1]
+    bld.add(O.conv_cin_small(rgb_latent, x_latent, ws.small_conv("conv_in"), ws.bias("conv_in"), x.t, B=B,
+                             H=h, W=w, C0=cin - 4, C1=4, Cout=c0, bcast0=rgb_latent.shape[0] == 1), "conv_in")
+    skips = [x]
+    force_size = any(d % (2 ** (n - 1)) != 0 for d in (h, w))
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            name = f"down_blocks.{i}.resnets.{j}"
+            y = bld.resnet(x, name, boc[i], 1e-5, trow(name, boc[i]))
+            if i < n - 1:
+                y = bld.transformer(y, f"down_blocks.{i}.attentions.{j}", cfg.heads[i], ctx)
+            x = y
+            skips.append(x)
+        if i < n - 1:
+            x = bld.conv3x3(x, f"down_blocks.{i}.downsamplers.0.conv", boc[i], stride=2, pad=1)
+            skips.append(x)
+    name = "mid_block.resnets.0"
+    y = bld.resnet(x, name, boc[-1], 1e-5, trow(name, boc[-1]))
+    y = bld.transformer(y, "mid_block.attentions.0", cfg.heads[-1], ctx)
+    name = "mid_block.resnets.1"
+    x2 = bld.resnet(y, name, boc[-1], 1e-5, trow(name, boc[-1]))
+    bld.free(y)
+    x = x2  # the pre-mid x is still referenced by skips[-1]
+    rheads = list(cfg.heads)[::-1]
+    for (i, j, _rin, _skip, cout) in unet_up_resnet_channels(cfg):
+        skip = skips.pop()
+        cat = bld.new(B, x.H, x.W, x.C + skip.C)
+        bld.add(O.concat_c(x.t, skip.t, cat.t, M=x.M, C1=x.C, C2=skip.C), f"up_blocks.{i}.cat.{j}")
+        bld.free(x, skip)
+        name = f"up_blocks.{i}.resnets.{j}"
+        y = bld.resnet(cat, name, cout, 1e-5, trow(name, cout))
+        bld.free(cat)
+        if i > 0:
+            y = bld.transformer(y, f"up_blocks.{i}.attentions.{j}", rheads[i], ctx)
+        x = y
+        if j == cfg.layers_per_block and i < n - 1:
+            if force_size:
+                up = (skips[-1].H, skips[-1].W)
+            else:
+                up = (2 * x.H, 2 * x.W)
+            y = bld.conv3x3(x, f"up_blocks.{i}.upsamplers.0.conv", cout, up=up)
+            bld.free(x)
+            x = y
+    g = bld.group_norm(x, "conv_norm_out", 1e-5, True)
+    bld.free(x)
+    bld.add(O.conv_cout_small(g.t, ws.small_conv("conv_out"), ws.bias("conv_out"), eps_out, B=B, H=h, W=w,
+                              Cin=c0, Cout=cfg.out_channels), "conv_out")
+    bld.free(g)
+
+
+# ------------------------------------------------------------------------------------------ VAE
+
+def emit_vae_encode(bld, cfg: VAEConfig, rgb, lat_out, B, H, W):
+    """lat_out[B,4,H/8,W/8] = 0.18215 * mean(quant_conv(encoder(rgb)))  (fp32 NCHW in/out).
+    quant_conv (1x1) and the posterior-mean selection are composed into the encoder's conv_out."""
+    ws = bld.ws
+    boc = list(cfg.block_out_channels)
+    x = bld.new(B, H, W, boc[0])
+    bld.add(O.conv_cin_small(rgb, None, ws.small_conv("encoder.conv_in"), ws.bias("encoder.conv_in"), x.t,
+                             B=B, H=H, W=W, C0=3, C1=0, Cout=boc[0]), "encoder.conv_in")
+    for i, c in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            y = bld.resnet(x, f"encoder.down_blocks.{i}.resnets.{j}", c, 1e-6)
+            bld.free(x)
+            x = y
+        if i < len(boc) - 1:
+            y = bld.conv3x3(x, f"encoder.down_blocks.{i}.downsamplers.0.conv", c, stride=2, pad=0)
+            bld.free(x)
+            x = y
+    x = emit_vae_mid(bld, x, "encoder.mid_block")
+    g = bld.group_norm(x, "encoder.conv_norm_out", 1e-6, True)
+    bld.free(x)
+    L4 = cfg.latent_channels
+
+    def composed():
+        wc = ws.sd["encoder.conv_out.weight"].double()          # [2L, C, 3, 3]
+        bc = ws.sd["encoder.conv_out.bias"].double()
+        wq = ws.sd["quant_conv.weight"].double().reshape(2 * L4, 2 * L4)[:L4]   # mean rows
+        bq = ws.sd["quant_conv.bias"].double()[:L4]
+        w = torch.einsum("om,mcyx->ocyx", wq, wc)
+        b = wq @ bc + bq
+        return Wm.f32(Wm.pack_small_conv(w.float()), bld.dev), Wm.f32(b.float(), bld.dev)
+    wcomp, bcomp = ws._memo(("enc_tail",), composed)
+    bld.add(O.conv_cout_small(g.t, wcomp, bcomp, lat_out, B=B, H=g.H, W=g.W, Cin=g.C, Cout=L4,
+                              scale=LATENT_SCALE), "encoder.conv_out+quant_conv")
+    bld.free(g)
+    return g.H, g.W
+
+
+def emit_vae_mid(bld, x, name):
+    y = bld.resnet(x, f"{name}.resnets.0", x.C, 1e-6)
+    bld.free(x)
+    z = bld.vae_attention(y, f"{name}.attentions.0")
+    bld.free(y)
+    out = bld.resnet(z, f"{name}.resnets.1", z.C, 1e-6)
+    bld.free(z)
+    return out
+
+
+def emit_vae_decode(bld, cfg: VAEConfig, latent, out, B, h, w, post):
+    """out = tail(decoder(post_quant_conv(latent / 0.18215))); ``post`` fuses the pipeline's
+    pointwise tail (depth: mean/clip/shift -> [B,1,H,W]; normals: clip/normalise -> [B,3,H,W])."""
+    ws = bld.ws
+    rev = list(cfg.block_out_channels)[::-1]
+    L4 = cfg.latent_channels
+    z = bld.raw(B * L4 * h * w * 4)
+    bld.add(O.latent_1x1(latent, ws.f32mat("post_quant_conv"), ws.bias("post_quant_conv"), z, B=B, Ci=L4,
+                         Co=L4, HW=h * w, scale=1.0 / LATENT_SCALE), "post_quant_conv")
+    x = bld.new(B, h, w, rev[0])
+    bld.add(O.conv_cin_small(z, None, ws.small_conv("decoder.conv_in"), ws.bias("decoder.conv_in"), x.t, B=B,
+                             H=h, W=w, C0=L4, C1=0, Cout=rev[0]), "decoder.conv_in")
+    bld.free(z)
+    x = emit_vae_mid(bld, x, "decoder.mid_block")
+    for i, c in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            y = bld.resnet(x, f"decoder.up_blocks.{i}.resnets.{j}", c, 1e-6)
+            bld.free(x)
+            x = y
+        if i < len(rev) - 1:
+            y = bld.conv3x3(x, f"decoder.up_blocks.{i}.upsamplers.0.conv", c, up=(2 * x.H, 2 * x.W))
+            bld.free(x)
+            x = y
+    g = bld.group_norm(x, "decoder.conv_norm_out", 1e-6, True)
+    bld.free(x)
+    bld.add(O.conv_cout_small(g.t, ws.small_conv("decoder.conv_out"), ws.bias("decoder.conv_out"), out, B=B,
+                              H=g.H, W=g.W, Cin=g.C, Cout=3, post=post), "decoder.conv_out")
+    bld.free(g)
+    return g.H, g.W

@@ -1,0 +1,204 @@
+"""Engine handles that stand where the reference's ``unet`` / ``vae`` diffusers modules stand
+(``register_modules`` at marigold_depth_pipeline.py:133-139).  They own the device-resident
+weights and a cache of native programs keyed by problem shape; calling them runs HIP kernels
+only (there is no torch fallback: without the HIP library construction fails).
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib as L
+from . import engine as E
+from . import ops as O
+from .arch import UNetConfig, VAEConfig, unet_param_shapes, vae_param_shapes
+
+
+def _check_state_dict(sd, shapes, what):
+    missing = [k for k in shapes if k not in sd]
+    if missing:
+        raise KeyError(f"{what}: state dict lacks {len(missing)} tensors, e.g. {missing[:4]}")
+    for k, s in shapes.items():
+        if tuple(sd[k].shape) != tuple(s):
+            raise ValueError(f"{what}: {k} has shape {tuple(sd[k].shape)}, expected {tuple(s)}")
+
+
+def _device_index(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("the Marigold HIP engine runs on an MI355X only (device must be 'cuda[:i]')")
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+class _EngineModule:
+    compute_dtype = torch.bfloat16
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.ws = None
+        self.pool = None
+        self._programs = {}
+
+    @property
+    def dtype(self):
+        return self.compute_dtype
+
+    def to(self, device):
+        idx = _device_index(device)
+        L.init(idx)
+        self.device = torch.device("cuda", idx)
+        self.ws = E.WeightStore(self.sd, self.device)
+        self.pool = E.Pool(self.device)
+        self._programs = {}
+        return self
+
+    def _require_device(self):
+        if self.ws is None:
+            raise RuntimeError(f"{type(self).__name__}: call .to('cuda') first")
+
+    def workspace_bytes(self):
+        return 0 if self.pool is None else self.pool.bytes
+
+
+class DenoiseProgram:
+    """One native program = T x (UNet forward + scheduler update) for fixed (B, h, w, timesteps)."""
+
+    def __init__(self, seq, rgb_latent, x, eps, noises, n_fwd_ops, n_prologue_ops):
+        self.seq, self.rgb_latent, self.x, self.eps, self.noises = seq, rgb_latent, x, eps, noises
+        self.n_fwd_ops, self.n_prologue_ops = n_fwd_ops, n_prologue_ops
+
+    def run(self):
+        self.seq.run()
+
+
+class UNet2DConditionModelHIP(_EngineModule):
+    """SD-v2 UNet (8-channel conv_in).  ``__call__`` mirrors
+    ``unet(sample, t, encoder_hidden_states=ctx).sample`` (marigold_depth_pipeline.py:461-463);
+    ``denoise_program`` builds the whole T-step loop (:455-468) as one program."""
+
+    def __init__(self, state_dict, config: UNetConfig = UNetConfig()):
+        super().__init__()
+        _check_state_dict(state_dict, unet_param_shapes(config), "UNet")
+        self.sd = state_dict
+        self.config = config
+        self._ctx = None
+
+    def set_context(self, ctx):
+        """ctx: the empty-prompt embedding [1,2,D] (or [2,D]); constant per checkpoint."""
+        ctx = ctx.detach().float().cpu().reshape(-1, ctx.shape[-1])
+        if ctx.shape != (2, self.config.cross_attention_dim):
+            raise ValueError(f"expected a 2-token context of width {self.config.cross_attention_dim}, "
+                             f"got {tuple(ctx.shape)}")
+        if self._ctx is None or not torch.equal(self._ctx, ctx):
+            self._ctx = ctx
+            self._programs = {}
+            if self.ws is not None:
+                for k in [k for k in self.ws.cache if k[0] == "x"]:
+                    del self.ws.cache[k]
+
+    def denoise_program(self, B, h, w, scheduler, n_steps, rgb_broadcast=True, with_scheduler=True,
+                        timesteps=None):
+        self._require_device()
+        if self._ctx is None:
+            raise RuntimeError("UNet context not set (set_context)")
+        if timesteps is None:
+            scheduler.set_timesteps(n_steps)
+            timesteps = [int(t) for t in scheduler.timesteps]
+        key = (B, h, w, tuple(timesteps), rgb_broadcast, with_scheduler,
+               scheduler.signature() if with_scheduler else None)
+        if key in self._programs:
+            return self._programs[key]
+        dev = self.device
+        seq = O.OpSeq(f"denoise[B={B},{h}x{w},T={len(timesteps)}]")
+        bld = E.Builder(seq, self.pool, self.ws, self.config.norm_groups)
+        rgb_latent = torch.zeros(1 if rgb_broadcast else B, 4, h, w, device=dev)
+        x = torch.zeros(B, 4, h, w, device=dev)
+        eps = torch.zeros(B, self.config.out_channels, h, w, device=dev)
+        seq.hold(rgb_latent, x, eps)
+        table = E.emit_time_embeddings(bld, self.config, timesteps)
+        n_pro = len(seq)
+        noises = []
+        n_fwd = 0
+        for i in range(len(timesteps)):
+            n0 = len(seq)
+            E.emit_unet_forward(bld, self.config, self._ctx, rgb_latent, x, eps, table, i, B, h, w)
+            n_fwd = len(seq) - n0
+            if with_scheduler:
+                cx, cm, cn = scheduler.step_coefficients(i)
+                nz = None
+                if scheduler.needs_noise(i):
+                    nz = seq.hold(torch.zeros(B, 4, h, w, device=dev))
+                    noises.append(nz)
+                seq.add(O.sched_step(x, eps, nz, x, n=x.numel(), cx=cx, cm=cm, cn=cn), f"scheduler.step[{i}]")
+        seq.keep.extend(bld.persist.values())
+        prog = DenoiseProgram(seq, rgb_latent, x, eps, noises, n_fwd, n_pro)
+        self._programs[key] = prog
+        return prog
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None):
+        """Step-wise mirror (used by parity tests): sample [B,8,h,w] -> .sample [B,4,h,w] fp32."""
+        if encoder_hidden_states is not None:
+            self.set_context(encoder_hidden_states[:1])
+        B, _, h, w = sample.shape
+        prog = self.denoise_program(B, h, w, None, 1, rgb_broadcast=False, with_scheduler=False,
+                                    timesteps=[int(timestep)])
+        s = sample.to(self.device, torch.float32)
+        prog.rgb_latent.copy_(s[:, :4])
+        prog.x.copy_(s[:, 4:])
+        prog.run()
+        return SimpleNamespace(sample=prog.eps.clone())
+
+
+class AutoencoderKLHIP(_EngineModule):
+    """SD AutoencoderKL.  ``encode_rgb_latent`` = 0.18215 * mean(quant_conv(encoder(x)))
+    (marigold_depth_pipeline.py:491-495); ``decode`` = decoder(post_quant_conv(z / 0.18215)) with
+    the pipeline's pointwise tail fused (:510-515, :473-475 / normals :437-440)."""
+
+    def __init__(self, state_dict, config: VAEConfig = VAEConfig()):
+        super().__init__()
+        _check_state_dict(state_dict, vae_param_shapes(config), "VAE")
+        self.sd = state_dict
+        self.config = config
+
+    def _program(self, kind, B, H, W, post=0):
+        key = (kind, B, H, W, post)
+        if key in self._programs:
+            return self._programs[key]
+        dev = self.device
+        seq = O.OpSeq(f"vae.{kind}[B={B},{H}x{W}]")
+        bld = E.Builder(seq, self.pool, self.ws, self.config.norm_groups)
+        if kind == "encode":
+            n_down = len(self.config.block_out_channels) - 1
+            h, w = H, W
+            for _ in range(n_down):
+                h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
+            inp = torch.zeros(B, 3, H, W, device=dev)
+            out = torch.zeros(B, self.config.latent_channels, h, w, device=dev)
+            E.emit_vae_encode(bld, self.config, inp, out, B, H, W)
+        else:
+            f = 2 ** (len(self.config.block_out_channels) - 1)
+            inp = torch.zeros(B, self.config.latent_channels, H, W, device=dev)
+            cout = 1 if post == L.POST_DEPTH else 3
+            out = torch.zeros(B, cout, H * f, W * f, device=dev)
+            E.emit_vae_decode(bld, self.config, inp, out, B, H, W, post)
+        seq.hold(inp, out)
+        seq.keep.extend(bld.persist.values())
+        self._programs[key] = (seq, inp, out)
+        return self._programs[key]
+
+    def encode_rgb_latent(self, rgb):
+        """rgb [B,3,H,W] in [-1,1] (any float dtype, on device) -> scaled latent mean [B,4,h,w] fp32."""
+        self._require_device()
+        B, _, H, W = rgb.shape
+        seq, inp, out = self._program("encode", B, H, W)
+        inp.copy_(rgb)
+        seq.run()
+        return out.clone()
+
+    def decode(self, latent, post=L.POST_NONE):
+        """latent [B,4,h,w] fp32 -> decoded map fp32 ([B,3,H,W], or [B,1,H,W] for POST_DEPTH)."""
+        self._require_device()
+        B, _, h, w = latent.shape
+        seq, inp, out = self._program("decode", B, h, w, post)
+        inp.copy_(latent)
+        seq.run()
+        return out.clone()

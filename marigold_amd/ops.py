@@ -42,13 +42,14 @@ def current_stream_handle():
 
 def igemm(a, w, out, *, B, H, W, Cin, Ho, Wo, N, taps=1, stride=1, pad=0, up=None, bias=None,
           rowvec=None, residual=None, epi=L.EPI_BF16, ldo=None, out2=None, trans_from=-1, ldt=0,
-          batch_z=1, ldr=0, lda=0, ldw=0, zstrides=(0, 0, 0, 0), scale=1.0, variant=0):
+          batch_z=1, ldr=0, lda=0, ldw=0, zstrides=(0, 0, 0, 0), scale=1.0, variant=0,
+          rowvec_bcast=False):
     hu, wu = up if up else (0, 0)
     if ldo is None:
         ldo = N // 2 if epi == L.EPI_GEGLU else N
     return make_op(L.OP_IGEMM,
                    i=[B, H, W, Cin, Ho, Wo, N, taps, stride, pad, hu, wu, epi, ldo, trans_from,
-                      batch_z, ldr, lda, ldt, variant, ldw],
+                      batch_z, ldr, lda, ldt, variant, ldw, int(rowvec_bcast)],
                    f=[scale], p=[a, w, out, bias, rowvec, residual, out2], l=list(zstrides))
 
 

@@ -1,0 +1,344 @@
+"""``MarigoldDepthPipeline`` / ``MarigoldNormalsPipeline`` with the reference's call surface
+(marigold/marigold_depth_pipeline.py:154-338, marigold/marigold_normals_pipeline.py:139-308):
+same arguments, defaults, asserts / exceptions / warnings and output containers, on top of the
+MI355X engine (HIP programs for VAE encode, the whole T-step denoising loop, VAE decode and the
+ensembling).  Differences that are deliberate and documented in DESIGN.md:
+
+* the image is VAE-encoded once per call, not once per ensemble member (the reference encodes E
+  identical copies, :258 / :427);
+* all members of a batch run through one native denoising program (no per-step Python);
+* optional member parallelism over the GPUs of a node (``enable_member_parallel``): members are
+  sharded over ranks and collected with ONE gather (RCCL over xGMI) before aggregation;
+* ``init_latents`` (extension) lets callers supply the initial noise for parity runs.
+"""
+import logging
+from dataclasses import dataclass
+from typing import Dict, Optional, Union
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import _lib as L
+from . import dist as mdist
+from .ensemble import ensemble_depth, ensemble_normals
+from .modules import AutoencoderKLHIP, UNet2DConditionModelHIP
+from .schedulers import DDIMScheduler, LCMScheduler
+from .util.batchsize import find_batch_size
+from .util.image_util import (chw2hwc, colorize_depth_maps, get_tv_resample_method, pil_to_tensor,
+                              resize, resize_max_res)
+
+
+@dataclass
+class MarigoldDepthOutput:
+    """depth_np [H,W] in [0,1]; depth_colored PIL RGB | None; uncertainty [H,W] | None
+    (reference :60-75)."""
+    depth_np: np.ndarray
+    depth_colored: Union[None, Image.Image]
+    uncertainty: Union[None, np.ndarray]
+
+
+@dataclass
+class MarigoldNormalsOutput:
+    """normals_np [3,H,W] unit vectors in [-1,1]; normals_img PIL; uncertainty | None
+    (normals reference :59-74)."""
+    normals_np: np.ndarray
+    normals_img: Image.Image
+    uncertainty: Union[None, np.ndarray]
+
+
+class _MarigoldPipelineBase:
+    latent_scale_factor = 0.18215
+    _kind = "depth"
+    _ckpt_hint = "prs-eth/marigold-depth-v1-1"
+
+    def __init__(self, unet: UNet2DConditionModelHIP, vae: AutoencoderKLHIP,
+                 scheduler: Union[DDIMScheduler, LCMScheduler], text_encoder=None, tokenizer=None,
+                 scale_invariant: Optional[bool] = True, shift_invariant: Optional[bool] = True,
+                 default_denoising_steps: Optional[int] = None,
+                 default_processing_resolution: Optional[int] = None, empty_text_embed=None):
+        self.unet, self.vae, self.scheduler = unet, vae, scheduler
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer
+        self.scale_invariant = scale_invariant
+        self.shift_invariant = shift_invariant
+        self.default_denoising_steps = default_denoising_steps
+        self.default_processing_resolution = default_processing_resolution
+        self.config = dict(scale_invariant=scale_invariant, shift_invariant=shift_invariant,
+                           default_denoising_steps=default_denoising_steps,
+                           default_processing_resolution=default_processing_resolution)
+        self.empty_text_embed = empty_text_embed
+        self._member_group = None
+        self._member_parallel = False
+
+    # ---- diffusers.DiffusionPipeline surface the callers use ---------------------------------
+    @property
+    def device(self):
+        return self.unet.device
+
+    @property
+    def dtype(self):
+        return self.unet.dtype
+
+    def to(self, device):
+        self.unet.to(device)
+        self.vae.to(device)
+        return self
+
+    @classmethod
+    def from_pretrained(cls, path, variant=None, torch_dtype=None, **kw):
+        from .checkpoint import load_pipeline
+        return load_pipeline(cls, path, variant=variant, torch_dtype=torch_dtype, **kw)
+
+    def enable_xformers_memory_efficient_attention(self):
+        """No-op: the engine's attention is already a fused flash kernel (run.py:217-220)."""
+
+    def set_progress_bar_config(self, **kw):
+        pass
+
+    def enable_member_parallel(self, group=None, root=None):
+        """Shard ensemble members over the ranks of ``group`` (torch.distributed; RCCL on GPUs)."""
+        self._member_group = group
+        self._member_parallel = True
+        self._member_root = root
+
+    # ---- reference methods -------------------------------------------------------------------
+    def _check_inference_step(self, n_step: int) -> None:
+        assert n_step >= 1
+        if isinstance(self.scheduler, DDIMScheduler):
+            if "trailing" != self.scheduler.config.timestep_spacing:
+                logging.warning(
+                    f"The loaded `DDIMScheduler` is configured with `timestep_spacing="
+                    f'"{self.scheduler.config.timestep_spacing}"`; the recommended setting is `"trailing"`. '
+                    f"This change is backward-compatible and yields better results. "
+                    f"Consider using `{self._ckpt_hint}` for the best experience.")
+            else:
+                if n_step > 10:
+                    logging.warning(
+                        f"Setting too many denoising steps ({n_step}) may degrade the prediction; consider "
+                        f"relying on the default values.")
+            if not self.scheduler.config.rescale_betas_zero_snr:
+                logging.warning(
+                    f"The loaded `DDIMScheduler` is configured with `rescale_betas_zero_snr="
+                    f"{self.scheduler.config.rescale_betas_zero_snr}`; the recommended setting is True. "
+                    f"Consider using `{self._ckpt_hint}` for the best experience.")
+        elif isinstance(self.scheduler, LCMScheduler):
+            self._lcm_policy(n_step)
+        else:
+            raise RuntimeError(f"Unsupported scheduler type: {type(self.scheduler)}")
+
+    def encode_empty_text(self):
+        """CLIP("") with padding="do_not_pad" -> [1,2,D]; constant per checkpoint, computed once on
+        the host (reference :381-394)."""
+        if self.tokenizer is None or self.text_encoder is None:
+            raise RuntimeError("no text encoder/tokenizer and no precomputed empty_text_embed")
+        text_inputs = self.tokenizer("", padding="do_not_pad", max_length=self.tokenizer.model_max_length,
+                                     truncation=True, return_tensors="pt")
+        with torch.no_grad():
+            self.empty_text_embed = self.text_encoder(text_inputs.input_ids)[0].to(self.dtype)
+
+    def encode_rgb(self, rgb_in: torch.Tensor) -> torch.Tensor:
+        return self.vae.encode_rgb_latent(rgb_in)
+
+    @torch.no_grad()
+    def single_infer(self, rgb_in: torch.Tensor, num_inference_steps: int,
+                     generator: Union[torch.Generator, None], show_pbar: bool = False,
+                     init_latents: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One batched prediction (reference :396-477).  rgb_in [B,3,h,w] in [-1,1]; identical
+        (expanded) rows are encoded once."""
+        device = self.device
+        B = rgb_in.shape[0]
+        shared = B == 1 or rgb_in.stride(0) == 0
+        rgb_in = (rgb_in[:1] if shared else rgb_in).to(device)
+        rgb_latent = self.encode_rgb(rgb_in)                       # [1|B,4,h,w] fp32
+        h, w = rgb_latent.shape[-2:]
+        if init_latents is None:
+            target_latent = torch.randn((B, 4, h, w), device=device, dtype=self.dtype, generator=generator)
+        else:
+            target_latent = init_latents.to(device)
+        if self.empty_text_embed is None:
+            self.encode_empty_text()
+        self.unet.set_context(self.empty_text_embed)
+        prog = self.unet.denoise_program(B, h, w, self.scheduler, num_inference_steps,
+                                         rgb_broadcast=shared)
+        prog.rgb_latent.copy_(rgb_latent)
+        prog.x.copy_(target_latent)
+        for nz in prog.noises:  # LCM consumes the generator once per non-final step (:466-468)
+            nz.copy_(torch.randn(nz.shape, device=device, dtype=self.dtype, generator=generator))
+        prog.run()
+        return self._decode(prog.x)
+
+    def _predict_members(self, rgb_norm, ensemble_size, denoising_steps, batch_size, generator,
+                         init_latents):
+        """All E members of one image -> [E,C,h,w] (on every rank when member-parallel)."""
+        _bs = batch_size if batch_size > 0 else find_batch_size(
+            ensemble_size=ensemble_size, input_res=max(rgb_norm.shape[1:]), dtype=self.dtype)
+        E = ensemble_size
+        members = list(range(E))
+        if self._member_parallel and mdist.world_size(self._member_group) > 1:
+            # every rank draws the full [E,4,h,w] noise (same generator state) and keeps its slice,
+            # so results do not depend on the number of GPUs
+            if init_latents is None:
+                hh, ww = self._latent_hw(rgb_norm.shape[-2:])
+                init_latents = torch.randn((E, 4, hh, ww), device=self.device, dtype=self.dtype,
+                                           generator=generator)
+            members = mdist.shard_members(E, mdist.world_size(self._member_group),
+                                          mdist.rank(self._member_group))
+        preds = []
+        for i in range(0, len(members), _bs):
+            idx = members[i:i + _bs]
+            lat = None if init_latents is None else init_latents[idx]
+            rgb = rgb_norm.expand(len(idx), -1, -1, -1)
+            preds.append(self.single_infer(rgb, denoising_steps, generator, False, lat))
+        local = torch.cat(preds, dim=0) if preds else None
+        if self._member_parallel and mdist.world_size(self._member_group) > 1:
+            C = 1 if self._kind == "depth" else 3
+            hh, ww = rgb_norm.shape[-2:]
+            return mdist.gather_members(local, E, (C, hh, ww), self.device, self._member_group,
+                                        getattr(self, "_member_root", None))
+        return local
+
+    def _latent_hw(self, hw):
+        h, w = hw
+        for _ in range(len(self.vae.config.block_out_channels) - 1):
+            h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
+        return h, w
+
+    def _preprocess(self, input_image, processing_res, resample_method):
+        if isinstance(input_image, Image.Image):
+            input_image = input_image.convert("RGB")
+            rgb = pil_to_tensor(input_image).unsqueeze(0)
+        elif isinstance(input_image, torch.Tensor):
+            rgb = input_image
+        else:
+            raise TypeError(f"Unknown input type: {type(input_image) = }")
+        input_size = rgb.shape
+        assert 4 == rgb.dim() and 3 == input_size[-3], f"Wrong input shape {input_size}, expected [1, rgb, H, W]"
+        if processing_res > 0:
+            rgb = resize_max_res(rgb, max_edge_resolution=processing_res, resample_method=resample_method)
+        rgb_norm = rgb / 255.0 * 2.0 - 1.0
+        rgb_norm = rgb_norm.to(self.dtype)
+        assert rgb_norm.min() >= -1.0 and rgb_norm.max() <= 1.0
+        return rgb_norm, input_size
+
+
+class MarigoldDepthPipeline(_MarigoldPipelineBase):
+    """Affine-invariant monocular depth (reference marigold/marigold_depth_pipeline.py:78-516)."""
+    _kind = "depth"
+    _ckpt_hint = "prs-eth/marigold-depth-v1-1"
+
+    def _lcm_policy(self, n_step):
+        logging.warning("DeprecationWarning: LCMScheduler will not be supported in the future. "
+                        "Consider using `prs-eth/marigold-depth-v1-1` for the best experience.")
+        if n_step > 10:
+            logging.warning(f"Setting too many denoising steps ({n_step}) may degrade the prediction; "
+                            f"consider relying on the default values.")
+
+    def _decode(self, latent):
+        return self.decode_depth(latent)
+
+    def decode_depth(self, depth_latent: torch.Tensor) -> torch.Tensor:
+        """latent -> depth in [0,1], [B,1,H,W] (decode, channel mean, clip, shift fused on device;
+        reference :498-516 + :473-475)."""
+        return self.vae.decode(depth_latent, post=L.POST_DEPTH)
+
+    @torch.no_grad()
+    def __call__(self, input_image: Union[Image.Image, torch.Tensor], denoising_steps: Optional[int] = None,
+                 ensemble_size: int = 1, processing_res: Optional[int] = None, match_input_res: bool = True,
+                 resample_method: str = "bilinear", batch_size: int = 0,
+                 generator: Union[torch.Generator, None] = None, color_map: str = "Spectral",
+                 show_progress_bar: bool = True, ensemble_kwargs: Dict = None,
+                 init_latents: Optional[torch.Tensor] = None) -> MarigoldDepthOutput:
+        if denoising_steps is None:
+            denoising_steps = self.default_denoising_steps
+        if processing_res is None:
+            processing_res = self.default_processing_resolution
+        assert processing_res >= 0
+        assert ensemble_size >= 1
+        self._check_inference_step(denoising_steps)
+        resample = get_tv_resample_method(resample_method)
+        rgb_norm, input_size = self._preprocess(input_image, processing_res, resample)
+
+        target_preds = self._predict_members(rgb_norm, ensemble_size, denoising_steps, batch_size,
+                                             generator, init_latents)
+        if target_preds is None:  # member-parallel non-root rank with a rooted gather
+            return MarigoldDepthOutput(depth_np=None, depth_colored=None, uncertainty=None)
+        if ensemble_size > 1:
+            final_pred, pred_uncert = ensemble_depth(target_preds, scale_invariant=self.scale_invariant,
+                                                     shift_invariant=self.shift_invariant,
+                                                     **(ensemble_kwargs or {}))
+        else:
+            final_pred, pred_uncert = target_preds, None
+        if match_input_res:
+            final_pred = resize(final_pred, input_size[-2:], interpolation=resample, antialias=True)
+        final_pred = final_pred.squeeze().cpu().numpy()
+        if pred_uncert is not None:
+            pred_uncert = pred_uncert.squeeze().cpu().numpy()
+        final_pred = final_pred.clip(0, 1)
+        if color_map is not None:
+            colored = colorize_depth_maps(final_pred, 0, 1, cmap=color_map).squeeze()
+            colored = (colored * 255).astype(np.uint8)
+            depth_colored_img = Image.fromarray(chw2hwc(colored))
+        else:
+            depth_colored_img = None
+        return MarigoldDepthOutput(depth_np=final_pred, depth_colored=depth_colored_img, uncertainty=pred_uncert)
+
+
+class MarigoldNormalsPipeline(_MarigoldPipelineBase):
+    """Surface normals (reference marigold/marigold_normals_pipeline.py:77-479)."""
+    _kind = "normals"
+    _ckpt_hint = "prs-eth/marigold-normals-v1-1"
+
+    def __init__(self, unet, vae, scheduler, text_encoder=None, tokenizer=None,
+                 default_denoising_steps: Optional[int] = None,
+                 default_processing_resolution: Optional[int] = None, empty_text_embed=None):
+        super().__init__(unet, vae, scheduler, text_encoder, tokenizer, None, None, default_denoising_steps,
+                         default_processing_resolution, empty_text_embed)
+        self.config = dict(default_denoising_steps=default_denoising_steps,
+                           default_processing_resolution=default_processing_resolution)
+
+    def _lcm_policy(self, n_step):
+        raise RuntimeError("This pipeline implementation does not support the LCMScheduler. Please refer to "
+                           "the project README.md for instructions about using LCM.")
+
+    def _decode(self, latent):
+        return self.decode_normals(latent)
+
+    def decode_normals(self, normals_latent: torch.Tensor) -> torch.Tensor:
+        """latent -> unit normals [B,3,H,W] (decode, clip, L2 normalise fused; reference :463-479,
+        :437-440)."""
+        return self.vae.decode(normals_latent, post=L.POST_NORMALS)
+
+    @torch.no_grad()
+    def __call__(self, input_image: Union[Image.Image, torch.Tensor], denoising_steps: Optional[int] = None,
+                 ensemble_size: int = 1, processing_res: Optional[int] = None, match_input_res: bool = True,
+                 resample_method: str = "bilinear", batch_size: int = 0,
+                 generator: Union[torch.Generator, None] = None, show_progress_bar: bool = True,
+                 ensemble_kwargs: Dict = None,
+                 init_latents: Optional[torch.Tensor] = None) -> MarigoldNormalsOutput:
+        if denoising_steps is None:
+            denoising_steps = self.default_denoising_steps
+        if processing_res is None:
+            processing_res = self.default_processing_resolution
+        assert processing_res >= 0
+        assert ensemble_size >= 1
+        self._check_inference_step(denoising_steps)
+        resample = get_tv_resample_method(resample_method)
+        rgb_norm, input_size = self._preprocess(input_image, processing_res, resample)
+
+        target_preds = self._predict_members(rgb_norm, ensemble_size, denoising_steps, batch_size,
+                                             generator, init_latents)
+        if target_preds is None:
+            return MarigoldNormalsOutput(normals_np=None, normals_img=None, uncertainty=None)
+        if ensemble_size > 1:
+            final_pred, pred_uncert = ensemble_normals(target_preds, **(ensemble_kwargs or {}))
+        else:
+            final_pred, pred_uncert = target_preds, None
+        if match_input_res:
+            final_pred = resize(final_pred, input_size[-2:], interpolation=resample, antialias=True)
+        final_pred = final_pred.squeeze().cpu().numpy()
+        if pred_uncert is not None:
+            pred_uncert = pred_uncert.squeeze().cpu().numpy()
+        final_pred = final_pred.clip(-1, 1)
+        normals_img = ((final_pred + 1) * 127.5).astype(np.uint8)
+        normals_img = Image.fromarray(chw2hwc(normals_img))
+        return MarigoldNormalsOutput(normals_np=final_pred, normals_img=normals_img, uncertainty=pred_uncert)

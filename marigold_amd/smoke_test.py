@@ -1,0 +1,34 @@
+"""__graft_entry__.smoke(): one tiny depth prediction on the GPU through the public pipeline,
+checked against the CPU oracle (the oracle is only the checker here)."""
+import numpy as np
+import torch
+
+
+def run(device="cuda:0"):
+    import marigold_amd as M
+    from marigold_amd import synthetic as syn
+    from marigold_amd.arch import TINY_UNET, TINY_VAE
+    from oracle import metrics as omet, pipeline as opipe
+    from oracle.schedulers import DDIMScheduler as OracleDDIM
+    from oracle.sd2_unet import UNet2DConditionModel
+    from oracle.sd2_vae import AutoencoderKL
+
+    pipe = M.build_synthetic_pipeline("depth", TINY_UNET, TINY_VAE, default_processing_resolution=0).to(device)
+    img = syn.synthetic_image(64, 128, seed=0)
+    lat0 = syn.synthetic_latents(2, 8, 16, seed=2024)
+    out = pipe(img, denoising_steps=2, ensemble_size=2, processing_res=0, match_input_res=False,
+               color_map=None, show_progress_bar=False, init_latents=lat0)
+    assert out.depth_np.shape == (64, 128) and np.isfinite(out.depth_np).all()
+
+    unet = UNet2DConditionModel(block_out_channels=TINY_UNET.block_out_channels,
+                                attention_head_dim=TINY_UNET.heads,
+                                cross_attention_dim=TINY_UNET.cross_attention_dim).eval()
+    unet.load_state_dict(syn.synthetic_unet_state_dict(TINY_UNET))
+    vae = AutoencoderKL(block_out_channels=TINY_VAE.block_out_channels).eval()
+    vae.load_state_dict(syn.synthetic_vae_state_dict(TINY_VAE))
+    ctx = syn.synthetic_text_embedding(TINY_UNET.cross_attention_dim)
+    ref, _, _ = opipe.predict("depth", unet, vae, OracleDDIM(), img, lat0, ctx, 2)
+    err = omet.affine_invariant_depth_errors(ref.squeeze().numpy(), out.depth_np)
+    print(f"[smoke] depth 64x128 E=2 T=2 vs CPU oracle: {err}")
+    assert err["rmse"] < 0.05, err
+    return err

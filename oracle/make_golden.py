@@ -139,6 +139,20 @@ def make_tiny_golden():
         out["unet_t999"] = unet(x8, torch.tensor(999), ctx.repeat(3, 1, 1)).sample.numpy()
         out["unet_t249"] = unet(x8, torch.tensor(249), ctx.repeat(3, 1, 1)).sample.numpy()
         out["decoded"] = opipe.decode_latent(vae, lat0 * 0.5).numpy()
+        # yardstick for the bf16 engine: the SAME oracle modules run in bf16 on the CPU (what the
+        # reference's reduced-precision path would do); only the rmse vs fp32 is stored.
+        import copy
+        u16 = copy.deepcopy(unet).to(torch.bfloat16)
+        v16 = copy.deepcopy(vae).to(torch.bfloat16)
+        bf = torch.bfloat16
+
+        def rm(a, b):
+            return np.float64(((a.double() - torch.from_numpy(b).double()) ** 2).mean().sqrt())
+        out["bf16_rmse_rgb_latent"] = rm(opipe.encode_rgb(v16, rgb.to(bf)), out["rgb_latent"])
+        for t in (999, 249):
+            y16 = u16(x8.to(bf), torch.tensor(t), ctx.repeat(3, 1, 1).to(bf)).sample
+            out[f"bf16_rmse_unet_t{t}"] = rm(y16, out[f"unet_t{t}"])
+        out["bf16_rmse_decoded"] = rm(opipe.decode_latent(v16, (lat0 * 0.5).to(bf)), out["decoded"])
         # depth v1-1 style: DDIM trailing + zero SNR, v-pred, 4 steps, E=3
         sch = DDIMScheduler()
         tr = []

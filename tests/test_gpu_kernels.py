@@ -349,8 +349,8 @@ def test_ensemble_kernels_vs_oracle(dev, golden_dir):
     stv = torch.from_numpy(param).float().to(dev)
     med = torch.empty(HW, device=dev)
     madd = torch.empty(HW, device=dev)
-    mm = torch.empty(2, device=dev)
-    scr = torch.empty(2 * 512, device=dev)
+    mm = torch.empty(2 + 2 * 10, device=dev)
+    scr = torch.empty(12288, device=dev, dtype=torch.uint8)
     _run(ops.ens_depth_median(dd, stv, med, madd, mm, scr, E=E, HW=HW))
     nbad = (med.cpu() != pred.reshape(-1)).sum().item()
     print(f"[parity] ens_depth_median: {nbad} / {HW} pixels differ from the oracle, "
@@ -358,6 +358,9 @@ def test_ensemble_kernels_vs_oracle(dev, golden_dir):
     assert torch.equal(med.cpu(), pred.reshape(-1)), "median must be bit-exact (fp32, same op order)"
     assert torch.equal(madd.cpu(), mad.reshape(-1))
     assert mm[0].item() == pred.min().item() and mm[1].item() == pred.max().item()
+    pmin, pmax = int(pred.reshape(-1).argmin()), int(pred.reshape(-1).argmax())
+    assert torch.equal(mm[2:2 + E].cpu(), d.reshape(E, HW)[:, pmin])
+    assert torch.equal(mm[2 + E:2 + 2 * E].cpu(), d.reshape(E, HW)[:, pmax])
     _run(ops.ens_depth_norm(med, madd, mm, HW=HW))
     rng = (pred.max() - pred.min()).clamp(min=1e-6)
     _close("ens_depth_norm", med, ((pred - pred.min()) / rng).reshape(-1), tol=1e-6)

@@ -1,0 +1,219 @@
+"""CPU-only checks of the host logic: C-ABI library loads and exports what include/*.h declares,
+scheduler coefficients vs the oracle schedulers, weight re-layout algebra, resize/batch-size
+policy, pipeline error behaviour, member-parallel gather over gloo (world_size 2)."""
+import logging
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    from marigold_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "marigold_hip.h")).read()
+    body = hdr[hdr.index("typedef struct mg_program"):]
+    names = sorted(set(re.findall(r"\b(mg_[a-z0-9_]+)\s*\(", body)))
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in marigold_hip.h but not exported"
+    assert set(names) == set(_lib.EXPORTS)
+    assert lib.mg_abi_version() == _lib.ABI_VERSION
+    import ctypes
+    assert ctypes.sizeof(_lib.MgOp) == 232
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from marigold_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmarigold_hip.so")
+    with pytest.raises(_lib.MarigoldHipError):
+        _lib.load()
+
+
+@pytest.mark.parametrize("kind,kw,n", [
+    ("ddim", dict(), 10), ("ddim", dict(), 4), ("ddim", dict(), 1),
+    ("ddim", dict(timestep_spacing="leading", rescale_betas_zero_snr=False), 10),
+    ("ddim", dict(timestep_spacing="leading", rescale_betas_zero_snr=False, prediction_type="epsilon"), 5),
+    ("ddim", dict(prediction_type="sample"), 3),
+    ("lcm", dict(), 4), ("lcm", dict(), 1), ("lcm", dict(prediction_type="epsilon"), 3)])
+def test_scheduler_coefficients_match_oracle_step(kind, kw, n):
+    from marigold_amd import schedulers as S
+    from oracle import schedulers as OS
+    mine = (S.DDIMScheduler if kind == "ddim" else S.LCMScheduler)(**kw)
+    orc = (OS.DDIMScheduler if kind == "ddim" else OS.LCMScheduler)(**kw)
+    mine.set_timesteps(n)
+    orc.set_timesteps(n)
+    assert mine.timesteps.tolist() == orc.timesteps.tolist()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+    for i, t in enumerate(orc.timesteps):
+        v = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+        gen = torch.Generator().manual_seed(100 + i)
+        ref = orc.step(v, t, x, generator=gen).prev_sample
+        cx, cm, cn = mine.step_coefficients(i)
+        got = cx * x + cm * v
+        if mine.needs_noise(i):
+            gen2 = torch.Generator().manual_seed(100 + i)
+            got = got + cn * torch.randn(v.shape, generator=gen2, dtype=torch.float64)
+        torch.testing.assert_close(got, ref, atol=2e-5, rtol=1e-5)
+        x = ref
+
+
+def test_geglu_interleave_is_a_permutation_with_paired_rows():
+    from marigold_amd import weights as Wm
+    C = 16
+    w = torch.arange(8 * C * 3, dtype=torch.float32).reshape(8 * C, 3)
+    b = torch.arange(8 * C, dtype=torch.float32)
+    wp, bp = Wm.pack_geglu(w, b)
+    assert sorted(bp.tolist()) == b.tolist()
+    for blk in range(8 * C // 16):
+        for j in range(8):
+            assert bp[16 * blk + j] == 8 * blk + j            # u row
+            assert bp[16 * blk + 8 + j] == 4 * C + 8 * blk + j  # its gate row
+    assert torch.equal(wp[:, 0] / 3, bp)
+
+
+def test_cross_attention_collapse_equals_attention():
+    from marigold_amd import weights as Wm
+    from oracle.sd2_unet import Attention
+    torch.manual_seed(0)
+    C, heads, cross = 128, 2, 64
+    att = Attention(C, heads, C // heads, cross_dim=cross).double()
+    ctx = torch.randn(2, cross, dtype=torch.float64)
+    y = torch.randn(50, C, dtype=torch.float64)
+    ref = att(y[None], ctx[None])[0]
+    wqk, vot, npad = Wm.cross_attention_tables(att.to_q.weight, att.to_k.weight, att.to_v.weight,
+                                               att.to_out[0].weight, ctx, heads)
+    s = (y @ wqk.double().t())[:, :2 * heads] * (C // heads) ** -0.5
+    p = torch.softmax(s.reshape(50, heads, 2), dim=-1).reshape(50, 2 * heads)
+    out = p @ vot.double()[:, :2 * heads].t() + att.to_out[0].bias
+    torch.testing.assert_close(out, ref, atol=1e-5, rtol=1e-5)
+    assert npad == 64 and (wqk[2 * heads:] == 0).all()
+
+
+def test_conv_pack_layout():
+    from marigold_amd import weights as Wm
+    w = torch.randn(5, 64, 3, 3)
+    x = torch.randn(1, 64, 6, 6)
+    cols = F.unfold(x, 3, padding=1)                         # [1, 64*9, 36], index c*9 + tap
+    cols = cols.reshape(1, 64, 9, 36).permute(0, 2, 1, 3).reshape(1, 9 * 64, 36)   # tap*64 + c
+    out = Wm.pack_conv3x3(w) @ cols[0]
+    torch.testing.assert_close(out.reshape(5, 6, 6), F.conv2d(x, w, padding=1)[0], atol=1e-4, rtol=1e-4)
+
+
+def test_image_util_and_batchsize():
+    from marigold_amd.util import batchsize, image_util as iu
+    img = torch.randint(0, 255, (1, 3, 384, 512), dtype=torch.uint8)
+    out = iu.resize_max_res(img, 768, iu.get_tv_resample_method("bilinear"))
+    assert out.shape == (1, 3, 576, 768) and out.dtype == torch.uint8     # up-scales, keeps dtype
+    assert iu.resize(img, (384, 512)) is img
+    with pytest.raises(ValueError):
+        iu.get_tv_resample_method("lanczos")
+    assert iu.get_tv_resample_method("nearest") is iu.InterpolationMode.NEAREST_EXACT
+    assert iu.chw2hwc(np.zeros((3, 4, 5))).shape == (4, 5, 3)
+    class _Odd:
+        shape = (1, 2, 3)
+    with pytest.raises(TypeError):
+        iu.chw2hwc(_Odd())
+    col = iu.colorize_depth_maps(np.linspace(0, 1, 12).reshape(3, 4), 0, 1)
+    assert col.shape == (1, 3, 3, 4)
+    if not torch.cuda.is_available():
+        assert batchsize.find_batch_size(10, 768, torch.bfloat16) == 1
+
+
+class _FakeModule:
+    device = torch.device("cpu")
+    dtype = torch.bfloat16
+
+
+def test_pipeline_error_and_warning_behaviour(caplog):
+    import marigold_amd as M
+    from marigold_amd import schedulers as S
+    pipe = M.MarigoldDepthPipeline(_FakeModule(), _FakeModule(), S.DDIMScheduler(timestep_spacing="leading",
+                                                                                rescale_betas_zero_snr=False),
+                                   default_denoising_steps=4, default_processing_resolution=768)
+    with caplog.at_level(logging.WARNING):
+        pipe._check_inference_step(4)
+    assert "trailing" in caplog.text and "rescale_betas_zero_snr" in caplog.text
+    with pytest.raises(AssertionError):
+        pipe._check_inference_step(0)
+    with pytest.raises(AssertionError):
+        pipe(torch.zeros(1, 3, 8, 8, dtype=torch.uint8), processing_res=-1)
+    with pytest.raises(AssertionError):
+        pipe(torch.zeros(1, 3, 8, 8, dtype=torch.uint8), ensemble_size=0)
+    with pytest.raises(TypeError):
+        pipe(np.zeros((8, 8, 3)), processing_res=0)
+    with pytest.raises(AssertionError):
+        pipe(torch.zeros(3, 8, 8, dtype=torch.uint8), processing_res=0)
+    with pytest.raises(ValueError):
+        pipe(torch.zeros(1, 3, 8, 8, dtype=torch.uint8), resample_method="lanczos")
+    pipe.scheduler = object()
+    with pytest.raises(RuntimeError):
+        pipe._check_inference_step(1)
+    npipe = M.MarigoldNormalsPipeline(_FakeModule(), _FakeModule(), S.LCMScheduler())
+    with pytest.raises(RuntimeError):
+        npipe._check_inference_step(4)
+    dpipe = M.MarigoldDepthPipeline(_FakeModule(), _FakeModule(), S.LCMScheduler())
+    with caplog.at_level(logging.WARNING):
+        dpipe._check_inference_step(4)
+    assert "LCMScheduler will not be supported" in caplog.text
+    assert M.MarigoldPipeline is M.MarigoldDepthPipeline
+    assert M.MarigoldDepthPipeline.latent_scale_factor == 0.18215
+
+
+def test_ensemble_argument_validation_without_gpu():
+    from marigold_amd import ensemble as ens
+    x = torch.rand(3, 1, 8, 8)
+    with pytest.raises(ValueError):
+        ens.ensemble_depth(x, False, True)
+    with pytest.raises(ValueError):
+        ens.ensemble_depth(x[:, 0], True, True)
+    with pytest.raises(ValueError):
+        ens.ensemble_depth(x, True, True, reduction="max")
+    with pytest.raises(ValueError):
+        ens.ensemble_normals(torch.rand(3, 2, 8, 8))
+    with pytest.raises(ValueError):
+        ens.ensemble_normals(torch.rand(3, 3, 8, 8), reduction="median")
+
+
+def _gloo_worker(rank, world, port, E, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from marigold_amd import dist as md
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = md.shard_members(E, world, rank)
+        local = torch.stack([torch.full((1, 4, 6), float(e)) for e in mine]) if mine else None
+        full = md.gather_members(local, E, (1, 4, 6), torch.device("cpu"), root=None)
+        rooted = md.gather_members(local, E, (1, 4, 6), torch.device("cpu"), root=1)
+        ok = torch.equal(full[:, 0, 0, 0], torch.arange(E, dtype=torch.float32))
+        ok &= (rooted is None) == (rank != 1)
+        if rooted is not None:
+            ok &= torch.equal(rooted, full)
+        q.put((rank, bool(ok), mine))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("E", [2, 5])
+def test_member_parallel_gather_gloo_world2(E):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + E
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, E, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    owned = sorted(e for _, _, m in res for e in m)
+    assert owned == list(range(E))
