@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""Headline benchmark: depth maps/sec @768x768, ensemble_size=10, 10 DDIM steps (BASELINE.json).
+
+One "step" = one full ``MarigoldDepthPipeline.__call__`` on one synthetic 768x768 image: VAE encode
+(once), E=10 members x T=10 (UNet forward + DDIM update) as ONE native program, VAE decode of all
+members, on-device ensembling, D2H of the final [768,768] fp32 map (color_map=None, like
+script/depth/infer.py).  The image is already resident in HBM when the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU; the E members of every map are sharded over the ranks, collected with
+ONE gather (RCCL over xGMI) and aggregated on rank 0 ("strong" scaling: the work per map is fixed).
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).  Weights are seeded synthetic
+tensors in the real SD-v2 architecture (no checkpoints / network here); arithmetic is bf16 with fp32
+accumulation.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ensemble", type=int, default=10)
+    ap.add_argument("--denoise", type=int, default=10)
+    ap.add_argument("--res", type=int, default=768)
+    ap.add_argument("--kind", default="depth", choices=["depth", "normals"])
+    ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the denoising loop as a hipGraph")
+    ap.add_argument("--dump-ops", default="", help="write the per-op timing table to this file")
+    return ap.parse_args()
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(args, usd, vsd, ucfg, vcfg, ctx, members):
+    """The CPU oracle (restatement of the reference's diffusers path) timed on the host cores, on a
+    bounded sample: 1 UNet forward at the full 96x96 latent, VAE encode/decode at 256x256 scaled by
+    pixel count, and the reference's ensemble_depth algorithm (BFGS evaluation count from a 192x192
+    run x the cost of one evaluation at full size).  Reported, never used by the product path."""
+    import torch
+    from oracle import ensemble as oens
+    from oracle.sd2_unet import UNet2DConditionModel
+    from oracle.sd2_vae import AutoencoderKL
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    E, T, res = args.ensemble, args.denoise, args.res
+    lat = res // 8
+    t = {}
+    with torch.no_grad():
+        unet = UNet2DConditionModel(block_out_channels=ucfg.block_out_channels, attention_head_dim=ucfg.heads,
+                                    cross_attention_dim=ucfg.cross_attention_dim).eval()
+        unet.load_state_dict(usd)
+        x = torch.randn(1, 8, lat, lat)
+        t0 = time.perf_counter()
+        unet(x, torch.tensor(999), ctx)
+        t["unet_fwd"] = time.perf_counter() - t0
+        del unet
+        vae = AutoencoderKL(block_out_channels=vcfg.block_out_channels).eval()
+        vae.load_state_dict(vsd)
+        sres = min(res, 256)
+        scale = (res / sres) ** 2
+        img = torch.rand(1, 3, sres, sres) * 2 - 1
+        t0 = time.perf_counter()
+        h = vae.quant_conv(vae.encoder(img))
+        t["vae_encode"] = (time.perf_counter() - t0) * scale
+        z = h[:, :4]
+        t0 = time.perf_counter()
+        vae.decoder(vae.post_quant_conv(z))
+        t["vae_decode"] = (time.perf_counter() - t0) * scale
+        del vae
+        t["ensemble"] = 0.0
+        n_eval = 0
+        if E > 1 and members is not None and args.kind == "depth":
+            m = members.float().cpu()
+            small = torch.nn.functional.interpolate(m, (192, 192), mode="nearest-exact")
+            calls = [0]
+            orig = oens.depth_cost
+
+            def counting(*a, **k):
+                calls[0] += 1
+                return orig(*a, **k)
+            oens.depth_cost = counting
+            try:
+                _, _, p = oens.ensemble_depth(small, True, True, return_param=True)
+            finally:
+                oens.depth_cost = orig
+            n_eval = calls[0]
+            t0 = time.perf_counter()
+            for _ in range(5):
+                orig(p, m, True, True, "median", 0.02)
+            t["ensemble"] = (time.perf_counter() - t0) / 5 * n_eval
+    per_map = E * (t["vae_encode"] + T * t["unet_fwd"] + t["vae_decode"]) + t["ensemble"]
+    return {"value": 1.0 / per_map, "unit": "depth maps/s", "cores": cores, "kind": "port",
+            "sample": (f"CPU oracle fp32: 1 UNet fwd @{lat}x{lat} latent ({t['unet_fwd']:.2f}s) + VAE enc/dec "
+                       f"@{min(res, 256)}^2 scaled x{scale:.0f} by pixels ({t['vae_encode']:.1f}s/{t['vae_decode']:.1f}s) "
+                       f"+ reference ensemble_depth ({n_eval} BFGS cost evals from a 192^2 run x one eval @{res}^2 = "
+                       f"{t['ensemble']:.1f}s); extrapolated as E*(enc+T*unet+dec)+ens = {per_map:.0f}s/map"),
+            "seconds_per_map": per_map}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import marigold_amd as M
+    from marigold_amd import opstats, synthetic as syn
+    from marigold_amd.arch import TINY_UNET, TINY_VAE, UNetConfig, VAEConfig
+    from marigold_amd.modules import AutoencoderKLHIP, UNet2DConditionModelHIP
+    from marigold_amd.schedulers import DDIMScheduler
+
+    ucfg, vcfg = (TINY_UNET, TINY_VAE) if args.tiny else (UNetConfig(), VAEConfig())
+    t0 = time.perf_counter()
+    usd = syn.synthetic_unet_state_dict(ucfg)
+    vsd = syn.synthetic_vae_state_dict(vcfg)
+    ctx = syn.synthetic_text_embedding(ucfg.cross_attention_dim)
+    cls = M.MarigoldDepthPipeline if args.kind == "depth" else M.MarigoldNormalsPipeline
+    pipe = cls(unet=UNet2DConditionModelHIP(usd, ucfg), vae=AutoencoderKLHIP(vsd, vcfg),
+               scheduler=DDIMScheduler(), empty_text_embed=ctx, default_denoising_steps=args.denoise,
+               default_processing_resolution=0).to(dev)
+    if world > 1:
+        pipe.enable_member_parallel(root=0)
+    if rank == 0:
+        log(f"[bench] synthetic weights + pipeline ready in {time.perf_counter() - t0:.1f}s "
+            f"(host cores {os.cpu_count()})")
+    img = syn.synthetic_image(args.res, args.res, seed=0).to(dev)   # resident in HBM before timing
+    torch.manual_seed(2024)
+    kw = dict(denoising_steps=args.denoise, ensemble_size=args.ensemble, processing_res=0,
+              match_input_res=True, show_progress_bar=False)
+    if args.kind == "depth":
+        kw["color_map"] = None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for i in range(args.warmup):
+        t1 = time.perf_counter()
+        out = pipe(img, **kw)
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"[bench] warmup {i}: {time.perf_counter() - t1:.3f}s")
+    if args.graph:
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for prog in pipe.unet._programs.values():
+                prog.seq.capture()
+        torch.cuda.synchronize()
+        out = pipe(img, **kw)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipe(img, **kw)
+    barrier()
+    dt = time.perf_counter() - t1
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        res = out.depth_np if args.kind == "depth" else out.normals_np
+        assert res is not None and res.shape[-2:] == (args.res, args.res)
+        import numpy as np
+        assert np.isfinite(res).all()
+
+    # ---- per-kernel-class roofline from HIP-event timings of every launch (rank 0) --------------
+    kernels, roof, stages, flops_per_map = {}, None, {}, 0
+    if rank == 0 and not args.no_profile:
+        progs = [("denoise", p.seq) for p in pipe.unet._programs.values()] + \
+                [(f"vae.{k[0]}", v[0]) for k, v in pipe.vae._programs.items()]
+        all_ops, all_ms, rows = [], [], []
+        for name, seq in progs:
+            cap = seq._captured
+            if cap:   # profile the plain launch sequence, not the graph
+                continue
+            ms = seq.profile()
+            all_ops += seq.ops
+            all_ms += ms
+            stages[name] = {"ms": round(sum(ms), 3), "gflop": round(opstats.program_flops(seq.ops) / 1e9, 1),
+                            "launches": len(ms)}
+            rows += [(name, lab, m, op) for lab, m, op in zip(seq.labels, ms, seq.ops)]
+        kernels = opstats.summarize(all_ops, all_ms)
+        flops_per_map = sum(d["flops"] for d in kernels.values())
+        if args.dump_ops:
+            os.makedirs(os.path.dirname(os.path.abspath(args.dump_ops)), exist_ok=True)
+            with open(args.dump_ops, "w") as f:
+                f.write("stage\tlabel\tclass\tms\tGFLOP\tMB\tTFLOP/s\tGB/s\n")
+                for name, lab, m, op in rows:
+                    c, fl, by = opstats.op_cost(op)
+                    s = max(m, 1e-6) * 1e-3
+                    f.write(f"{name}\t{lab}\t{c}\t{m:.4f}\t{fl / 1e9:.2f}\t{by / 1e6:.2f}\t{fl / s / 1e12:.1f}\t{by / s / 1e9:.0f}\n")
+        if kernels:
+            dom = max(kernels, key=lambda c: kernels[c]["ms"])
+            d = kernels[dom]
+            if opstats.BOUND.get(dom) == "mfma":
+                roof = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2),
+                        "peak": opstats.MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(d["tflops"] / opstats.MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches_per_map": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                        "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 2)}
+            else:
+                roof = {"bound": "hbm", "kernel": dom, "achieved": round(d["gbs"], 1),
+                        "peak": opstats.HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(d["gbs"] / opstats.HBM_PEAK_GBS, 4), "traffic": None,
+                        "launches_per_map": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
+            for d in kernels.values():
+                for k in ("ms", "tflops", "gbs"):
+                    d[k] = round(d[k], 3)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        members = None
+        if args.ensemble > 1 and args.kind == "depth":
+            rgb = (img.float() / 255.0 * 2.0 - 1.0).cpu().expand(args.ensemble, -1, -1, -1)
+            members = pipe.single_infer(rgb, args.denoise, None)
+        t1 = time.perf_counter()
+        cpu = cpu_baseline(args, usd, vsd, ucfg, vcfg, ctx, members)
+        log(f"[bench] cpu baseline took {time.perf_counter() - t1:.1f}s")
+
+    if rank == 0:
+        value = args.steps / dt
+        line = {
+            "metric": f"{args.kind} maps/sec @{args.res}x{args.res}, ens={args.ensemble}, {args.denoise} DDIM steps",
+            "value": round(value, 4), "unit": f"{args.kind} maps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": (f"marigold-{args.kind}-v1-1 architecture (SD-v2 UNet 865.9M + AutoencoderKL), "
+                                    f"{args.res}x{args.res}, ensemble_size={args.ensemble}, {args.denoise} DDIM steps "
+                                    f"(trailing, zero-SNR, v-prediction), seeded synthetic weights"
+                                    + (" [TINY ARCH - plumbing only]" if args.tiny else "")),
+                       "members_per_gpu": -(-args.ensemble // world), "parallelism": f"member-parallel x{world}",
+                       "hipgraph": bool(args.graph)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "algorithmic_tflop_per_map": round(flops_per_map / 1e12, 2),
+            "pipeline_tflops": round(flops_per_map * value / 1e12, 1),
+            "pipeline_mfma_frac": round(flops_per_map * value / 1e12 / opstats.MFMA_PEAK_TFLOPS, 4),
+            "stages": stages,
+            "kernels": kernels,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,6 +149,9 @@ int mg_launch(const mg_op* op, void* stream);
 mg_program* mg_program_create(const mg_op* ops, int n_ops);
 int mg_program_num_ops(const mg_program* prog);
 int mg_program_run(mg_program* prog, void* stream);
+/* Check every op of the program against its kernel's shape / alignment contract WITHOUT touching
+ * the device (no GPU needed): 0 = launchable, else the first violation in mg_last_error(). */
+int mg_program_validate(mg_program* prog);
 int mg_program_run_range(mg_program* prog, int first, int count, void* stream);
 /* Capture the program into a hipGraph on `stream` and replay that on later runs. */
 int mg_program_capture(mg_program* prog, void* stream);

@@ -280,19 +280,19 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       a.sQ = op->l[0]; a.sK = op->l[1]; a.sVt = op->l[2]; a.sO = op->l[3];
       a.scale_log2 = op->f[0] * 1.4426950408889634f;
       a.nqb = (a.Ntok + FA_QB - 1) / FA_QB;
-      MG_REQUIRE(g_zero_page, "flash_attn64: mg_init() not called");
+      MG_REQUIRE(g_zero_page || g_dry_run, "flash_attn64: mg_init() not called");
       MG_REQUIRE(a.Q && a.K && a.Vt && a.O, "flash_attn64: null pointer");
       MG_REQUIRE(a.B > 0 && a.heads > 0 && a.Ntok > 0, "flash_attn64: empty problem");
       MG_REQUIRE(a.ldvt % 64 == 0 && a.ldvt >= a.Ntok, "flash_attn64: ldvt must be a multiple of 64 >= Ntok");
       MG_REQUIRE(a.ldq % 8 == 0 && a.ldo % 4 == 0, "flash_attn64: bad leading dims");
       const long long grid = (long long)a.nqb * a.heads * a.B;
-      hipLaunchKernelGGL(flash_attn64_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
+      MG_LAUNCH(flash_attn64_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
       break;
     }
     case MG_OP_SOFTMAX_ROWS: {
       const int R = op->i[0], ncols = op->i[1], lds_ = op->i[2], ldp = op->i[3];
       MG_REQUIRE(R > 0 && ncols > 0 && lds_ % 4 == 0 && ldp % 4 == 0 && ldp >= ncols, "softmax_rows: bad dims");
-      hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(256), 0, s, (const float*)op->p[0],
+      MG_LAUNCH(softmax_rows_kernel, dim3(R), dim3(256), 0, s, (const float*)op->p[0],
                          (bf16_t*)op->p[1], ncols, (long long)lds_, (long long)ldp);
       break;
     }
@@ -302,12 +302,12 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       MG_REQUIRE(M > 0 && pairs > 0 && ldp % 2 == 0 && 2 * pairs <= ldp && lds_ % 2 == 0, "softmax_pairs: bad dims");
       const long long total = M * (ldp / 2);
       const int grid = (int)min((total + 255) / 256, (long long)4096);
-      hipLaunchKernelGGL(softmax_pairs_kernel, dim3(grid), dim3(256), 0, s, (const float*)op->p[0],
+      MG_LAUNCH(softmax_pairs_kernel, dim3(grid), dim3(256), 0, s, (const float*)op->p[0],
                          (bf16_t*)op->p[1], M, pairs, lds_, ldp, op->f[0]);
       break;
     }
     default: MG_REQUIRE(false, "attention: bad op kind %d", op->kind);
   }
-  MG_CHECK_HIP(hipGetLastError());
+  if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
   return 0;
 }

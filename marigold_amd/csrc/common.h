@@ -46,6 +46,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 extern void* g_zero_page;  // >= 256 zero bytes in device memory (mg_init)
+// Dry run (mg_program_validate): every launcher checks its op's shape / alignment contract and
+// returns before touching the device - the CPU test-suite validates full-size programs with it.
+extern thread_local bool g_dry_run;
+#define MG_LAUNCH(...)                                   \
+  do {                                                   \
+    if (!g_dry_run) hipLaunchKernelGGL(__VA_ARGS__);     \
+  } while (0)
 void mg_set_error(const char* fmt, ...);
 #define MG_CHECK_HIP(expr)                                                         \
   do {                                                                             \

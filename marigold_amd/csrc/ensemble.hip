@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ 
 
 template <int E_>
 void launch_median(const mg_op* op, int nblk, hipStream_t s) {
-  hipLaunchKernelGGL(depth_median_kernel<E_>, dim3(nblk), dim3(256), 0, s, (const float*)op->p[0],
+  MG_LAUNCH(depth_median_kernel<E_>, dim3(nblk), dim3(256), 0, s, (const float*)op->p[0],
                      (const float*)op->p[1], (float*)op->p[2], (float*)op->p[3], (float*)op->p[5],
                      (long long*)((char*)op->p[5] + 8 * ENS_BLOCKS), op->i[0], op->l[0], op->i[1], op->i[2],
                      op->p[1] != nullptr);
@@ -286,9 +286,9 @@ int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
       const long long HW = op->l[0];
       MG_REQUIRE(E >= 1 && E <= EMAX, "ens_depth_stats: E %d out of range [1,%d]", E, EMAX);
       const int nblk = (int)min((HW + 255) / 256, (long long)128);
-      hipLaunchKernelGGL(depth_stats_kernel, dim3(nblk, E), dim3(256), 0, s, (const float*)op->p[0],
+      MG_LAUNCH(depth_stats_kernel, dim3(nblk, E), dim3(256), 0, s, (const float*)op->p[0],
                          (double*)op->p[1], E, HW);
-      hipLaunchKernelGGL(depth_stats_final_kernel, dim3(1), dim3(256), 0, s, (const double*)op->p[1],
+      MG_LAUNCH(depth_stats_final_kernel, dim3(1), dim3(256), 0, s, (const double*)op->p[1],
                          (double*)op->p[2], E, nblk, HW);
       break;
     }
@@ -303,7 +303,7 @@ int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
       else if (E <= 10) launch_median<10>(op, nblk, s);
       else if (E <= 16) launch_median<16>(op, nblk, s);
       else launch_median<EMAX>(op, nblk, s);
-      hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, s, (const float*)op->p[5],
+      MG_LAUNCH(minmax_final_kernel, dim3(1), dim3(64), 0, s, (const float*)op->p[5],
                          (const long long*)((char*)op->p[5] + 8 * ENS_BLOCKS), (const float*)op->p[0],
                          (float*)op->p[4], nblk, E, HW);
       break;
@@ -311,7 +311,7 @@ int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
     case MG_OP_ENS_DEPTH_NORM: {
       const long long HW = op->l[0];
       const int nblk = (int)min((HW + 255) / 256, (long long)2048);
-      hipLaunchKernelGGL(depth_norm_kernel, dim3(nblk), dim3(256), 0, s, (float*)op->p[0], (float*)op->p[1],
+      MG_LAUNCH(depth_norm_kernel, dim3(nblk), dim3(256), 0, s, (float*)op->p[0], (float*)op->p[1],
                          (const float*)op->p[2], HW, op->i[0]);
       break;
     }
@@ -320,12 +320,12 @@ int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
       const long long HW = op->l[0];
       MG_REQUIRE(E >= 1, "ens_normals: E must be >= 1");
       const int nblk = (int)min((HW + 255) / 256, (long long)2048);
-      hipLaunchKernelGGL(normals_kernel, dim3(nblk), dim3(256), 0, s, (const float*)op->p[0],
+      MG_LAUNCH(normals_kernel, dim3(nblk), dim3(256), 0, s, (const float*)op->p[0],
                          (float*)op->p[1], (float*)op->p[2], E, HW, op->i[1]);
       break;
     }
     default: MG_REQUIRE(false, "ensemble: bad op kind %d", op->kind);
   }
-  MG_CHECK_HIP(hipGetLastError());
+  if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -311,7 +311,7 @@ int launch_variant(const IgemmArgs& a, int batch_z, hipStream_t s) {
   constexpr int LDS = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   auto kern = igemm_kernel<BM, BN, WGM, WGN, GLDS>;
-  if (!attr_set) {
+  if (!attr_set && !g_dry_run) {
     MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
@@ -322,8 +322,8 @@ int launch_variant(const IgemmArgs& a, int batch_z, hipStream_t s) {
   MG_REQUIRE(grid > 0 && grid < (1ll << 31), "igemm: bad grid %lld", grid);
   if (a.trans_from >= 0)
     MG_REQUIRE(a.trans_from % BN == 0, "igemm: trans_from %d not a multiple of BN %d", a.trans_from, BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), LDS, s, b);
-  MG_CHECK_HIP(hipGetLastError());
+  MG_LAUNCH(kern, dim3((unsigned)grid), dim3(NT), LDS, s, b);
+  if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
@@ -358,7 +358,7 @@ int mg_launch_igemm(const mg_op* op, hipStream_t s) {
   a.cpt = a.Cin / 64;
   a.KT = a.taps * a.cpt;
   a.tiles_m = a.tiles_n = 0;
-  MG_REQUIRE(g_zero_page, "igemm: mg_init() not called");
+  MG_REQUIRE(g_zero_page || g_dry_run, "igemm: mg_init() not called");
   MG_REQUIRE(a.A && a.Wt && (a.out || a.out2), "igemm: null pointer");
   MG_REQUIRE(a.taps == 1 || a.taps == 9, "igemm: taps must be 1 or 9 (got %d)", a.taps);
   MG_REQUIRE(a.Cin > 0 && a.Cin % 64 == 0, "igemm: Cin %d must be a multiple of 64", a.Cin);

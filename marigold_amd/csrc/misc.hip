@@ -196,7 +196,7 @@ int mg_launch_misc(const mg_op* op, hipStream_t s) {
       const dim3 grid((unsigned)((npix + 255) / 256));
 #define CIN_CASE(N)                                                                              \
   case N:                                                                                        \
-    hipLaunchKernelGGL(conv_cin_small_kernel<N>, grid, dim3(256), 0, s, (const float*)op->p[0],  \
+    MG_LAUNCH(conv_cin_small_kernel<N>, grid, dim3(256), 0, s, (const float*)op->p[0],  \
                        (const float*)op->p[1], (const float*)op->p[2], (const float*)op->p[3],   \
                        (bf16_t*)op->p[4], B, H, W, C0, Cout, op->i[6]);                          \
     break;
@@ -215,7 +215,7 @@ int mg_launch_misc(const mg_op* op, hipStream_t s) {
       const float osc = op->f[0] == 0.f ? 1.f : op->f[0];
 #define COUT_CASE(N)                                                                             \
   case N:                                                                                        \
-    hipLaunchKernelGGL(conv_cout_small_kernel<N>, grid, dim3(256), 0, s, (const bf16_t*)op->p[0], \
+    MG_LAUNCH(conv_cout_small_kernel<N>, grid, dim3(256), 0, s, (const bf16_t*)op->p[0], \
                        (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], B, H, W, \
                        Cin, op->i[5], osc);                                                      \
     break;
@@ -232,14 +232,14 @@ int mg_launch_misc(const mg_op* op, hipStream_t s) {
       MG_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0, "concat_c: channel counts must be multiples of 8");
       const long long total = M * ((C1 + C2) / 8);
       const int grid = (int)min((total + 255) / 256, (long long)8192);
-      hipLaunchKernelGGL(concat_c_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)op->p[0],
+      MG_LAUNCH(concat_c_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)op->p[0],
                          (const bf16_t*)op->p[1], (bf16_t*)op->p[2], M, C1, C2);
       break;
     }
     case MG_OP_SCHED_STEP: {
       const long long n = op->l[0];
       const int grid = (int)min((n + 255) / 256, (long long)4096);
-      hipLaunchKernelGGL(sched_step_kernel, dim3(grid), dim3(256), 0, s, (const float*)op->p[0],
+      MG_LAUNCH(sched_step_kernel, dim3(grid), dim3(256), 0, s, (const float*)op->p[0],
                          (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], n,
                          op->f[0], op->f[1], op->f[2]);
       break;
@@ -247,7 +247,7 @@ int mg_launch_misc(const mg_op* op, hipStream_t s) {
     case MG_OP_LINEAR_SMALL_M: {
       const int M = op->i[0], N = op->i[1], K = op->i[2];
       MG_REQUIRE(M > 0 && M < 65536 && N > 0 && K > 0, "linear_small_m: bad dims");
-      hipLaunchKernelGGL(linear_small_m_kernel, dim3((N + 3) / 4, M), dim3(256), 0, s,
+      MG_LAUNCH(linear_small_m_kernel, dim3((N + 3) / 4, M), dim3(256), 0, s,
                          (const float*)op->p[0], (const float*)op->p[1], (const float*)op->p[2],
                          (float*)op->p[3], M, N, K, op->i[3], op->i[4], op->i[5] > 0 ? op->i[5] : N);
       break;
@@ -257,19 +257,19 @@ int mg_launch_misc(const mg_op* op, hipStream_t s) {
       const long long HW = op->i[3];
       const long long total = (long long)B * HW;
       const int grid = (int)min((total + 255) / 256, (long long)4096);
-      hipLaunchKernelGGL(latent_1x1_kernel, dim3(grid), dim3(256), 0, s, (const float*)op->p[0],
+      MG_LAUNCH(latent_1x1_kernel, dim3(grid), dim3(256), 0, s, (const float*)op->p[0],
                          (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], B, Ci, Co,
                          HW, op->f[0] == 0.f ? 1.f : op->f[0]);
       break;
     }
     case MG_OP_MEMSET:
-      MG_CHECK_HIP(hipMemsetAsync(op->p[0], op->i[0], (size_t)op->l[0], s));
+      if (!g_dry_run) MG_CHECK_HIP(hipMemsetAsync(op->p[0], op->i[0], (size_t)op->l[0], s));
       break;
     case MG_OP_COPY:
-      MG_CHECK_HIP(hipMemcpyAsync(op->p[1], op->p[0], (size_t)op->l[0], hipMemcpyDeviceToDevice, s));
+      if (!g_dry_run) MG_CHECK_HIP(hipMemcpyAsync(op->p[1], op->p[0], (size_t)op->l[0], hipMemcpyDeviceToDevice, s));
       break;
     default: MG_REQUIRE(false, "misc: bad op kind %d", op->kind);
   }
-  MG_CHECK_HIP(hipGetLastError());
+  if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
   return 0;
 }

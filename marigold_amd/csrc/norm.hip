@@ -203,14 +203,14 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
       const int B = op->i[0], HW = op->i[1], C = op->i[2], chunks = op->i[3];
       MG_REQUIRE(C % 8 == 0 && C <= 256 * 8 * GN_NV, "gn_stats: unsupported C %d", C);
       MG_REQUIRE(B > 0 && HW > 0 && chunks > 0 && chunks <= HW, "gn_stats: bad dims");
-      hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B), dim3(256), 2 * C * sizeof(float), s,
+      MG_LAUNCH(gn_stats_kernel, dim3(chunks, B), dim3(256), 2 * C * sizeof(float), s,
                          (const bf16_t*)op->p[0], (float*)op->p[1], HW, C, chunks);
       break;
     }
     case MG_OP_GN_FINALIZE: {
       const int B = op->i[0], C = op->i[1], groups = op->i[2], chunks = op->i[3], HW = op->i[4];
       MG_REQUIRE(C % groups == 0, "gn_finalize: C %d not divisible by groups %d", C, groups);
-      hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, s,
+      MG_LAUNCH(gn_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, s,
                          (const float*)op->p[0], (const float*)op->p[1], (const float*)op->p[2],
                          (float*)op->p[3], B, C, groups, chunks, HW, op->f[0]);
       break;
@@ -220,20 +220,20 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
       MG_REQUIRE(C % 8 == 0, "gn_apply: C %d must be a multiple of 8", C);
       const long long nvec = (long long)B * HW * (C / 8);
       const int grid = (int)min((nvec + 255) / 256, (long long)256 * 16);
-      hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)op->p[0],
+      MG_LAUNCH(gn_apply_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)op->p[0],
                          (const float*)op->p[1], (bf16_t*)op->p[2], nvec, HW, C, op->i[3]);
       break;
     }
     case MG_OP_LAYERNORM: {
       const int M = op->i[0], C = op->i[1];
       MG_REQUIRE(C % 8 == 0 && C <= 64 * 8 * LN_NV, "layernorm: unsupported C %d", C);
-      hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s,
+      MG_LAUNCH(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s,
                          (const bf16_t*)op->p[0], (const float*)op->p[1], (const float*)op->p[2],
                          (bf16_t*)op->p[3], M, C, op->f[0]);
       break;
     }
     default: MG_REQUIRE(false, "norm: bad op kind %d", op->kind);
   }
-  MG_CHECK_HIP(hipGetLastError());
+  if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
   return 0;
 }

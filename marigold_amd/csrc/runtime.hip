@@ -12,6 +12,7 @@
 #include "common.h"
 
 void* g_zero_page = nullptr;
+thread_local bool g_dry_run = false;
 static thread_local char g_err[512] = "";
 static std::mutex g_init_mutex;
 static int g_device = -1;
@@ -126,6 +127,14 @@ int mg_program_run_range(mg_program* prog, int first, int count, void* stream) {
     }
   }
   return 0;
+}
+
+int mg_program_validate(mg_program* prog) {
+  MG_REQUIRE(prog, "mg_program_validate: null program");
+  g_dry_run = true;
+  const int rc = mg_program_run_range(prog, 0, (int)prog->ops.size(), nullptr);
+  g_dry_run = false;
+  return rc;
 }
 
 int mg_program_run(mg_program* prog, void* stream) {

@@ -51,6 +51,15 @@ class _EngineModule:
         self._programs = {}
         return self
 
+    def dry(self):
+        """Host-only mode for contract checks (tests): programs are built against CPU buffers and
+        can be ``validate()``d, never run."""
+        self.device = torch.device("cpu")
+        self.ws = E.WeightStore(self.sd, self.device)
+        self.pool = E.Pool(self.device)
+        self._programs = {}
+        return self
+
     def _require_device(self):
         if self.ws is None:
             raise RuntimeError(f"{type(self).__name__}: call .to('cuda') first")

@@ -195,6 +195,11 @@ class OpSeq:
         L.check(lib.mg_program_run(prog, stream if stream is not None else current_stream_handle()),
                 f"mg_program_run({self.name})")
 
+    def validate(self):
+        """Dry-run every op through its launcher's contract checks (works without a GPU)."""
+        lib = L.load()
+        L.check(lib.mg_program_validate(self.compile()), f"mg_program_validate({self.name})")
+
     def run_eager(self, stream=None):
         for op in self.ops:
             launch(op, stream)

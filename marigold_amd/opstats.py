@@ -1,0 +1,98 @@
+"""Algorithmic work of one ``mg_op`` (FLOPs = 2 x MACs of the contraction; bytes = one read of
+every input + one write of every output, weights counted once per launch) and the kernel class
+it runs on.  bench.py turns per-op HIP-event timings into per-class achieved TFLOP/s / GB/s
+against the gfx950 rooflines; DESIGN.md quotes the same formulas.
+"""
+from . import _lib as L
+
+MFMA_PEAK_TFLOPS = 2500.0   # bf16 dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0       # HBM3E spec (6.29 TB/s measured streaming)
+
+CLASS = {
+    L.OP_IGEMM: "igemm_mfma", L.OP_FLASH_ATTN64: "flash_attn64", L.OP_GN_STATS: "groupnorm",
+    L.OP_GN_FINALIZE: "groupnorm", L.OP_GN_APPLY: "groupnorm", L.OP_LAYERNORM: "layernorm",
+    L.OP_SOFTMAX_ROWS: "softmax", L.OP_SOFTMAX_PAIRS: "softmax",
+    L.OP_CONV_CIN_SMALL: "boundary_conv", L.OP_CONV_COUT_SMALL: "boundary_conv",
+    L.OP_CONCAT_C: "concat", L.OP_SCHED_STEP: "scheduler_step", L.OP_LINEAR_SMALL_M: "time_embedding",
+    L.OP_LATENT_1X1: "boundary_conv", L.OP_ENS_DEPTH_STATS: "ensemble", L.OP_ENS_DEPTH_MEDIAN: "ensemble",
+    L.OP_ENS_DEPTH_NORM: "ensemble", L.OP_ENS_NORMALS: "ensemble", L.OP_MEMSET: "memops", L.OP_COPY: "memops",
+}
+BOUND = {"igemm_mfma": "mfma", "flash_attn64": "mfma"}   # everything else is HBM-bound streaming
+
+
+def op_cost(op):
+    """-> (class name, algorithmic FLOPs, algorithmic HBM bytes) of one launch."""
+    k, i, l = op.kind, op.i, op.l
+    cls = CLASS.get(k, "other")
+    flops = byts = 0
+    if k == L.OP_IGEMM:
+        B, H, W, Cin, Ho, Wo, N, taps = (i[j] for j in range(8))
+        epi, bz = i[12], max(1, i[15])
+        M, K = B * Ho * Wo, taps * Cin
+        flops = 2 * M * N * K * bz
+        n_out = N // 2 if epi == L.EPI_GEGLU else N
+        osz = 4 if epi == L.EPI_F32 else 2
+        byts = bz * (B * H * W * Cin * 2 + N * K * 2 + M * n_out * osz)
+        if op.p[5]:
+            byts += bz * M * n_out * 2   # fused residual read
+    elif k == L.OP_FLASH_ATTN64:
+        B, heads, T = i[0], i[1], i[2]
+        flops = 4 * B * heads * T * T * 64
+        byts = 4 * B * heads * T * 64 * 2
+    elif k == L.OP_GN_STATS:
+        byts = i[0] * i[1] * i[2] * 2
+    elif k == L.OP_GN_APPLY:
+        byts = 2 * i[0] * i[1] * i[2] * 2
+    elif k == L.OP_LAYERNORM:
+        byts = 2 * i[0] * i[1] * 2
+    elif k == L.OP_SOFTMAX_ROWS:
+        byts = i[0] * i[1] * 4 + i[0] * i[3] * 2
+    elif k == L.OP_SOFTMAX_PAIRS:
+        byts = i[0] * i[2] * 4 + i[0] * i[3] * 2
+    elif k == L.OP_CONV_CIN_SMALL:
+        B, H, W, C0, C1, Cout = (i[j] for j in range(6))
+        flops = 2 * B * H * W * 9 * (C0 + C1) * Cout
+        byts = B * H * W * ((C0 + C1) * 4 + Cout * 2)
+    elif k == L.OP_CONV_COUT_SMALL:
+        B, H, W, Cin, Cout = (i[j] for j in range(5))
+        flops = 2 * B * H * W * 9 * Cin * Cout
+        byts = B * H * W * (Cin * 2 + Cout * 4)
+    elif k == L.OP_CONCAT_C:
+        byts = 2 * i[0] * (i[1] + i[2]) * 2
+    elif k == L.OP_SCHED_STEP:
+        byts = (4 if op.p[2] else 3) * l[0] * 4
+    elif k == L.OP_LINEAR_SMALL_M:
+        flops = 2 * i[0] * i[1] * i[2]
+        byts = i[1] * i[2] * 4
+    elif k == L.OP_LATENT_1X1:
+        byts = i[0] * (i[1] + i[2]) * i[3] * 4
+    elif k in (L.OP_ENS_DEPTH_STATS, L.OP_ENS_DEPTH_MEDIAN):
+        byts = i[0] * l[0] * 4
+    elif k == L.OP_ENS_DEPTH_NORM:
+        byts = 2 * l[0] * 4
+    elif k == L.OP_ENS_NORMALS:
+        byts = (i[0] + 1) * 3 * l[0] * 4
+    elif k in (L.OP_MEMSET, L.OP_COPY):
+        byts = l[0]
+    return cls, flops, byts
+
+
+def summarize(ops, ms):
+    """Aggregate per-op (cost, time) into {class: {launches, ms, flops, bytes, tflops, gbs}}."""
+    out = {}
+    for op, t in zip(ops, ms):
+        cls, f, b = op_cost(op)
+        d = out.setdefault(cls, dict(launches=0, ms=0.0, flops=0, bytes=0))
+        d["launches"] += 1
+        d["ms"] += float(t)
+        d["flops"] += f
+        d["bytes"] += b
+    for d in out.values():
+        s = max(d["ms"], 1e-9) * 1e-3
+        d["tflops"] = d["flops"] / s / 1e12
+        d["gbs"] = d["bytes"] / s / 1e9
+    return out
+
+
+def program_flops(ops):
+    return sum(op_cost(op)[1] for op in ops)

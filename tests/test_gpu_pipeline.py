@@ -123,7 +123,8 @@ def test_denoise_loop_and_single_infer_vs_golden(tiny, gold):
     from oracle import metrics as omet
     _, lat0, rgb = _inputs()
     pipe = _engine_pipe(tiny, "depth", S.DDIMScheduler())
-    d = pipe.single_infer(rgb.expand(3, -1, -1, -1).cuda(), 4, None, False, init_latents=lat0)
+    # expanded (stride-0) rows = one shared image: encoded once, rgb_broadcast program
+    d = pipe.single_infer(rgb.expand(3, -1, -1, -1), 4, None, False, init_latents=lat0)
     prog = tiny["eunet"].denoise_program(3, 8, 16, pipe.scheduler, 4, rgb_broadcast=True)
     _report("denoise x_T->x_0 (DDIM trailing, 4 steps)", prog.x, torch.from_numpy(gold["depth_ddim4_latents"][-1]),
             floor=2e-2)
@@ -139,7 +140,7 @@ def test_denoise_loop_and_single_infer_vs_golden(tiny, gold):
     _report("single_infer depth (leading, 3 steps)", d10, torch.from_numpy(gold["depth_leading3"]), floor=1e-2)
     # normals
     pn = _engine_pipe(tiny, "normals", S.DDIMScheduler())
-    n = pn.single_infer(rgb.expand(3, -1, -1, -1).cuda(), 2, None, False, init_latents=lat0)
+    n = pn.single_infer(rgb.expand(3, -1, -1, -1), 2, None, False, init_latents=lat0)
     refn = torch.from_numpy(gold["normals_ddim2"])
     ang = np.concatenate([omet.angular_error_deg(n[e].cpu(), refn[e]) for e in range(3)])
     print(f"[parity] normals angular error: mean {ang.mean():.3f} deg, p99 {np.percentile(ang, 99):.3f} deg")

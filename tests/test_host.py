@@ -217,3 +217,40 @@ def test_member_parallel_gather_gloo_world2(E):
     assert all(ok for _, ok, _ in res), res
     owned = sorted(e for _, _, m in res for e in m)
     assert owned == list(range(E))
+
+
+def test_full_size_programs_validate_without_gpu():
+    """The SD-v2 UNet (B=10 members, 96x96 latent, 2 DDIM steps) and the AutoencoderKL programs at
+    768x768 are emitted against host buffers and every op is checked against its kernel's
+    shape/alignment contract through the C ABI (mg_program_validate) - no device needed.  Also pins
+    the algorithmic FLOPs per member used for the roofline."""
+    from marigold_amd import opstats
+    from marigold_amd.arch import UNetConfig, VAEConfig, unet_param_shapes, vae_param_shapes
+    from marigold_amd.modules import AutoencoderKLHIP, UNet2DConditionModelHIP
+    from marigold_amd.schedulers import DDIMScheduler
+    ucfg, vcfg = UNetConfig(), VAEConfig()
+    usd = {k: torch.zeros(s) for k, s in unet_param_shapes(ucfg).items()}
+    vsd = {k: torch.zeros(s) for k, s in vae_param_shapes(vcfg).items()}
+    unet = UNet2DConditionModelHIP(usd, ucfg).dry()
+    unet.set_context(torch.zeros(1, 2, 1024))
+    B = 10
+    prog = unet.denoise_program(B, 96, 96, DDIMScheduler(), 2)
+    prog.seq.validate()
+    per_fwd = opstats.program_flops(prog.seq.ops[prog.n_prologue_ops:]) / 2 / B / 1e9
+    # SURVEY: 2137.7 GF with the full cross-attention; the 2-token collapse removes ~51 GF
+    assert 2050 < per_fwd < 2140, per_fwd
+    vae = AutoencoderKLHIP(vsd, vcfg).dry()
+    seq, _, _ = vae._program("encode", 1, 768, 768)
+    seq.validate()
+    assert abs(opstats.program_flops(seq.ops) / 1e9 - 2609.1) < 5
+    seq, _, _ = vae._program("decode", 2, 96, 96, 1)
+    seq.validate()
+    assert abs(opstats.program_flops(seq.ops) / 2 / 1e9 - 5754.3) < 5
+    # odd sizes (C1: 384x512 input up-scaled to 576x768 -> 72x96 latent) and a contract violation
+    unet.denoise_program(1, 72, 96, DDIMScheduler(timestep_spacing="leading", rescale_betas_zero_snr=False), 1).seq.validate()
+    from marigold_amd import _lib as L, ops as O
+    bad = O.OpSeq("bad")
+    buf = torch.zeros(64, dtype=torch.uint8)
+    bad.add(O.linear(buf, buf, buf, M=4, K=40, N=8), "K not a multiple of 64")
+    with pytest.raises(L.MarigoldHipError, match="multiple of 64"):
+        bad.validate()
