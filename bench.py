@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the denoising loop as a hipGraph")
     ap.add_argument("--dump-ops", default="", help="write the per-op timing table to this file")
+    ap.add_argument("--cpu-baseline-only", default="", help=argparse.SUPPRESS)  # internal: child mode
+    ap.add_argument("--cpu-baseline-timeout", type=int, default=240)
     return ap.parse_args()
 
 
@@ -47,16 +49,24 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(args, usd, vsd, ucfg, vcfg, ctx, members):
+def cpu_baseline(args, members_path):
     """The CPU oracle (restatement of the reference's diffusers path) timed on the host cores, on a
     bounded sample: 1 UNet forward at the full 96x96 latent, VAE encode/decode at 256x256 scaled by
     pixel count, and the reference's ensemble_depth algorithm (BFGS evaluation count from a 192x192
     run x the cost of one evaluation at full size).  Reported, never used by the product path."""
+    import numpy as np
     import torch
+    from marigold_amd import synthetic as syn
+    from marigold_amd.arch import TINY_UNET, TINY_VAE, UNetConfig, VAEConfig
+    from marigold_amd.util.host import cpu_model, usable_cores
     from oracle import ensemble as oens
     from oracle.sd2_unet import UNet2DConditionModel
     from oracle.sd2_vae import AutoencoderKL
-    cores = os.cpu_count() or 1
+    ucfg, vcfg = (TINY_UNET, TINY_VAE) if args.tiny else (UNetConfig(), VAEConfig())
+    usd, vsd = syn.synthetic_unet_state_dict(ucfg), syn.synthetic_vae_state_dict(vcfg)
+    ctx = syn.synthetic_text_embedding(ucfg.cross_attention_dim)
+    members = torch.from_numpy(np.load(members_path)) if members_path and os.path.exists(members_path) else None
+    cores = usable_cores()
     torch.set_num_threads(cores)
     E, T, res = args.ensemble, args.denoise, args.res
     lat = res // 8
@@ -105,7 +115,7 @@ def cpu_baseline(args, usd, vsd, ucfg, vcfg, ctx, members):
                 orig(p, m, True, True, "median", 0.02)
             t["ensemble"] = (time.perf_counter() - t0) / 5 * n_eval
     per_map = E * (t["vae_encode"] + T * t["unet_fwd"] + t["vae_decode"]) + t["ensemble"]
-    return {"value": 1.0 / per_map, "unit": "depth maps/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / per_map, "unit": f"{args.kind} maps/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
             "sample": (f"CPU oracle fp32: 1 UNet fwd @{lat}x{lat} latent ({t['unet_fwd']:.2f}s) + VAE enc/dec "
                        f"@{min(res, 256)}^2 scaled x{scale:.0f} by pixels ({t['vae_encode']:.1f}s/{t['vae_decode']:.1f}s) "
                        f"+ reference ensemble_depth ({n_eval} BFGS cost evals from a 192^2 run x one eval @{res}^2 = "
@@ -115,6 +125,9 @@ def cpu_baseline(args, usd, vsd, ucfg, vcfg, ctx, members):
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print("CPU_BASELINE " + json.dumps(cpu_baseline(args, args.cpu_baseline_only)), flush=True)
+        return
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -237,12 +250,28 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        members = None
+        # the oracle runs in a child process under a hard timeout: it is a reported baseline and must
+        # never be able to stall the benchmark (or share threads / memory with the timed process)
+        import subprocess
+        import tempfile
+        mpath = os.path.join(tempfile.gettempdir(), f"marigold_bench_members_{os.getpid()}.npy")
         if args.ensemble > 1 and args.kind == "depth":
             rgb = (img.float() / 255.0 * 2.0 - 1.0).cpu().expand(args.ensemble, -1, -1, -1)
-            members = pipe.single_infer(rgb, args.denoise, None)
+            import numpy as np
+            np.save(mpath, pipe.single_infer(rgb, args.denoise, None).float().cpu().numpy())
         t1 = time.perf_counter()
-        cpu = cpu_baseline(args, usd, vsd, ucfg, vcfg, ctx, members)
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", mpath, "--ensemble", str(args.ensemble),
+               "--denoise", str(args.denoise), "--res", str(args.res), "--kind", args.kind] + (["--tiny"] if args.tiny else [])
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout,
+                               env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+            got = [ln for ln in r.stdout.splitlines() if ln.startswith("CPU_BASELINE ")]
+            cpu = json.loads(got[-1][len("CPU_BASELINE "):]) if got else {"value": None, "error": r.stderr[-400:]}
+        except subprocess.TimeoutExpired:
+            cpu = {"value": None, "error": f"cpu baseline exceeded {args.cpu_baseline_timeout}s and was stopped"}
+        finally:
+            if os.path.exists(mpath):
+                os.remove(mpath)
         log(f"[bench] cpu baseline took {time.perf_counter() - t1:.1f}s")
 
     if rank == 0:

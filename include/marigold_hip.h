@@ -38,7 +38,8 @@ enum mg_op_kind {
    *  i[6] N  i[7] taps(1|9)  i[8] stride  i[9] pad  i[10] Hu  i[11] Wu (virtual nearest-
    *  upsampled input size, 0 = none)  i[12] epilogue (MG_EPI_*)  i[13] ldo  i[14] trans_from
    *  (columns >= this go to out2 as [img][n-trans_from][ldt] transposed; -1 = none)
-   *  i[15] batch_z  i[16] ldr  i[17] lda  i[18] ldt  i[19] tile variant (0 = auto)  i[20] ldw
+   *  i[15] batch_z  i[16] ldr  i[17] lda  i[18] ldt  i[19] tile variant (0 = auto; 1..13 force a
+ *  generation-1 tile, 20..28 a generation-2 tile - used by the tuning sweep)  i[20] ldw
    *  i[21] rowvec broadcast (1 = a single [N] row shared by every image)
    *  l[0..3] z-strides (elements) of A, Wt, out, residual      f[0] scale on the accumulator */
   MG_OP_IGEMM = 1,
@@ -57,7 +58,8 @@ enum mg_op_kind {
   /* Self-attention core, head dim 64, bf16 MFMA flash attention with LDS-staged K / V^T
    * tiles (replaces diffusers Attention / SDPA / xformers, run.py:217-220).
    *  p[0] Q bf16 (row stride ldq)  p[1] K (row stride ldq)  p[2] Vt bf16 [B][heads*64][ldvt]
-   *  p[3] O bf16 (row stride ldo); i: B, heads, Ntok, ldq, ldo, ldvt ;
+   *  p[3] O bf16 (row stride ldo); i: B, heads, Ntok, ldq, ldo, ldvt, variant (0 = current
+ *  kernel, 1 = generation-1 kernel kept for A/B runs) ;
    *  l[0] q batch stride l[1] k batch stride l[2] vt batch stride l[3] o batch stride;
    *  f[0] softmax scale */
   MG_OP_FLASH_ATTN64 = 6,
@@ -139,6 +141,10 @@ typedef struct mg_program mg_program;
 int mg_abi_version(void);
 const char* mg_last_error(void);
 int mg_init(int device);                 /* idempotent; allocates the zero page */
+/* GEMM kernel generation in force (2; 1 with MARIGOLD_IGEMM_GEN=1) and the GEGLU weight-row
+ * interleave (32 / 16) the host must pack ff.net.0.proj with. */
+int mg_igemm_generation(void);
+int mg_geglu_interleave(void);
 int mg_device_info(int* cu_count, int* lds_bytes, int64_t* hbm_bytes, char* arch, int arch_len);
 
 /* One launch (also the body of mg_program_run) */

@@ -24,7 +24,7 @@ POST_NONE, POST_DEPTH, POST_NORMALS = 0, 1, 2
 OP_NAMES = {v: k[3:].lower() for k, v in list(globals().items()) if k.startswith("OP_")}
 
 EXPORTS = [
-    "mg_abi_version", "mg_last_error", "mg_init", "mg_device_info", "mg_launch",
+    "mg_abi_version", "mg_last_error", "mg_init", "mg_igemm_generation", "mg_geglu_interleave", "mg_device_info", "mg_launch",
     "mg_program_create", "mg_program_num_ops", "mg_program_run", "mg_program_validate", "mg_program_run_range",
     "mg_program_capture", "mg_program_profile", "mg_program_destroy", "mg_conv2d_igemm",
     "mg_sched_step", "mg_ensemble_normals", "mg_event_create", "mg_event_record",
@@ -59,6 +59,8 @@ def load():
         raise MarigoldHipError(f"{LIB_PATH} lacks ABI symbols: {missing}")
     lib.mg_last_error.restype = ctypes.c_char_p
     lib.mg_launch.argtypes = [ctypes.POINTER(MgOp), ctypes.c_void_p]
+    lib.mg_igemm_generation.restype = ctypes.c_int
+    lib.mg_geglu_interleave.restype = ctypes.c_int
     lib.mg_conv2d_igemm.argtypes = [ctypes.POINTER(MgOp), ctypes.c_void_p]
     lib.mg_program_create.restype = ctypes.c_void_p
     lib.mg_program_create.argtypes = [ctypes.POINTER(MgOp), ctypes.c_int]

@@ -189,6 +189,203 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(const FaArgs a) {
   }
 }
 
+// ---- generation 2 ------------------------------------------------------------------------------
+// Same tiling and data flow as above; what changed is the per-tile VALU bill (the first profile had
+// the kernel at 14 % of the MFMA roof with ~350 VALU instructions per 16 MFMAs):
+//   * softmax in ONE fma + one bare v_exp_f32 per score: p = exp2(s*c - m*c) (c = scale*log2 e),
+//     the running max is tracked on the raw scores;
+//   * P -> bf16 with v_cvt_pk_bf16_f32 (16 instructions per tile instead of ~100 of integer rounding);
+//   * the O / l rescale is skipped (wave-uniform branch) on tiles where no lane's max moved;
+//   * 3-deep K / V^T ring with counted vmcnt + raw s_barrier (tile kt+2 in flight while kt computes).
+typedef __attribute__((ext_vector_type(2))) __bf16 fa_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float fa_f32x2_t;
+__device__ __forceinline__ uint32_t fa_cvt_pk(float lo, float hi) {
+  fa_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, fa_bf16x2_t));
+}
+
+constexpr int FA2_NSTAGE = 3;
+
+__global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[FA2_NSTAGE * FA_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = bid % a.nqb;
+  const int bh = bid / a.nqb;
+  const int h = bh % a.heads, b = bh / a.heads;
+
+  const bf16_t* Qb = a.Q + (long long)b * a.sQ + h * 64;
+  const bf16_t* Kb = a.K + (long long)b * a.sK + h * 64;
+  const bf16_t* Vb = a.Vt + (long long)b * a.sVt + (long long)h * 64 * a.ldvt;
+  const char* zero = (const char*)a.zero;
+
+  const int q_row = qb * FA_QB + wave * 32 + l31;
+  const int q_ld = q_row < a.Ntok ? q_row : a.Ntok - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(Qb + (long long)q_ld * a.ldq + ks * 16 + half * 8));
+
+  // per-thread staging sources (2 chunks of K, 2 of V^T per tile), advanced by one tile per issue
+  const char* k_src[2];
+  const char* v_src[2];
+  int k_row[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ci = it * 256 + tid;
+    const int r = ci >> 3;
+    const int q = (ci & 7) ^ ((r >> 1) & 7);
+    k_row[it] = r;
+    k_src[it] = (const char*)(Kb + (long long)r * a.ldq + q * 8);
+    v_src[it] = (const char*)(Vb + (long long)r * a.ldvt + q * 8);
+  }
+  const long long k_step = (long long)FA_KB * a.ldq * 2;  // bytes per key tile
+  int i_k0 = 0;                                            // first key of the next tile to issue
+  auto issue = [&](int stage) {
+    char* sb = smem + stage * FA_STAGE;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const char* src = (i_k0 + k_row[it] < a.Ntok) ? k_src[it] : zero;
+      glds16(src, sb + (it * 256 + wave * 64) * 16);
+      k_src[it] += k_step;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      glds16(v_src[it], sb + FA_KB * 128 + (it * 256 + wave * 64) * 16);
+      v_src[it] += FA_KB * 2;
+    }
+    i_k0 += FA_KB;
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;  // raw-score units
+  const float c = a.scale_log2;
+
+  const int nkt = (a.Ntok + FA_KB - 1) / FA_KB;
+  issue(0);
+  if (nkt > 1) issue(1);
+  int st_c = 0, st_i = 2;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nkt) issue(st_i);
+    const char* sK = smem + st_c * FA_STAGE;
+    const char* sV = sK + FA_KB * 128;
+
+    // ---- S^T = K Q^T : two 32-key sub-tiles ----
+    f32x16 s[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t2][r] = 0.f;
+      const int row = t2 * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int q = ks * 2 + half;
+        const bf16x8 kf = __builtin_bit_cast(
+            bf16x8, *(const uint4*)(sK + row * 128 + ((q ^ ((row >> 1) & 7)) << 4)));
+        s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t2], 0, 0, 0);
+      }
+    }
+    // ---- online softmax; lane owns query l31, keys (r&3)+8(r>>2)+4*half of each sub-tile ----
+    const int kbase = kt * FA_KB;
+    if (kbase + FA_KB > a.Ntok) {  // ragged last tile: mask keys beyond Ntok
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= a.Ntok) s[t2][r] = -1e30f;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t2][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (__any(mx > m_run)) {  // some lane's running max moves: rescale O and l (alpha = 1 elsewhere)
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    const float mc = -m_run * c;
+    float ps = 0.f;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t2][r], c, mc));
+        s[t2][r] = p;
+        ps += p;
+      }
+    l_run += ps;
+
+    // ---- O^T += V^T P^T : k-step (t2, sh) covers keys 32*t2 + 16*sh + [0,16) ----
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) {
+        uint4 pw;
+        pw.x = fa_cvt_pk(s[t2][8 * sh + 0], s[t2][8 * sh + 1]);
+        pw.y = fa_cvt_pk(s[t2][8 * sh + 2], s[t2][8 * sh + 3]);
+        pw.z = fa_cvt_pk(s[t2][8 * sh + 4], s[t2][8 * sh + 5]);
+        pw.w = fa_cvt_pk(s[t2][8 * sh + 6], s[t2][8 * sh + 7]);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+        const int c0 = 4 * t2 + 2 * sh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int row = dt * 32 + l31;
+          const int sw = (row >> 1) & 7;
+          const uint2 v0 = *(const uint2*)(sV + row * 128 + ((c0 ^ sw) << 4) + 8 * half);
+          const uint2 v1 = *(const uint2*)(sV + row * 128 + (((c0 + 1) ^ sw) << 4) + 8 * half);
+          uint4 vw;
+          vw.x = v0.x; vw.y = v0.y; vw.z = v1.x; vw.w = v1.y;
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+    st_c = (st_c + 1 == FA2_NSTAGE) ? 0 : st_c + 1;
+    st_i = (st_i + 1 == FA2_NSTAGE) ? 0 : st_i + 1;
+  }
+  // ---- finalize: O[q][d] = o^T / l; lane^32 exchange -> 8 consecutive d per lane, 16-byte stores ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  bf16_t* orow = a.O + (long long)b * a.sO + (long long)q_row * a.ldo + h * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g0 = o[dt][8 * gp + j] * inv, g1 = o[dt][8 * gp + 4 + j] * inv;
+        const float recv = __shfl_xor(half ? g0 : g1, 32);
+        v[j] = half ? recv : g0;
+        v[4 + j] = half ? g1 : recv;
+      }
+      if (q_row < a.Ntok) {
+        uint4 pk;
+        pk.x = fa_cvt_pk(v[0], v[1]); pk.y = fa_cvt_pk(v[2], v[3]);
+        pk.z = fa_cvt_pk(v[4], v[5]); pk.w = fa_cvt_pk(v[6], v[7]);
+        *(uint4*)(orow + dt * 32 + 16 * gp + 8 * half) = pk;
+      }
+    }
+}
+
 // one workgroup per row; fp32 scores -> bf16 probabilities, pad columns zeroed
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S,
                                                            bf16_t* __restrict__ P, int ncols,
@@ -286,7 +483,10 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       MG_REQUIRE(a.ldvt % 64 == 0 && a.ldvt >= a.Ntok, "flash_attn64: ldvt must be a multiple of 64 >= Ntok");
       MG_REQUIRE(a.ldq % 8 == 0 && a.ldo % 4 == 0, "flash_attn64: bad leading dims");
       const long long grid = (long long)a.nqb * a.heads * a.B;
-      MG_LAUNCH(flash_attn64_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
+      // i[6]: 0 = generation 2 (needs 16-byte aligned O rows), 1 = generation 1
+      const bool v2ok = (a.ldo % 8 == 0) && ((uintptr_t)a.O % 16 == 0) && (a.sO % 8 == 0);
+      if (op->i[6] == 1 || !v2ok) MG_LAUNCH(flash_attn64_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
+      else MG_LAUNCH(flash_attn64_v2_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
       break;
     }
     case MG_OP_SOFTMAX_ROWS: {

@@ -45,7 +45,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return start + idx;
 }
 
-extern void* g_zero_page;  // >= 256 zero bytes in device memory (mg_init)
+#define MG_ZERO_BYTES (128 * 1024)
+extern void* g_zero_page;  // MG_ZERO_BYTES zero bytes in device memory (mg_init): padding source
 // Dry run (mg_program_validate): every launcher checks its op's shape / alignment contract and
 // returns before touching the device - the CPU test-suite validates full-size programs with it.
 extern thread_local bool g_dry_run;
@@ -72,6 +73,8 @@ void mg_set_error(const char* fmt, ...);
 
 // launchers (one per .hip file)
 int mg_launch_igemm(const mg_op* op, hipStream_t s);
+int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant);  // -1: shape needs generation 1
+extern int g_igemm_gen;  // 2 (default) | 1 (env MARIGOLD_IGEMM_GEN=1)
 int mg_launch_norm(const mg_op* op, hipStream_t s);
 int mg_launch_attention(const mg_op* op, hipStream_t s);
 int mg_launch_misc(const mg_op* op, hipStream_t s);

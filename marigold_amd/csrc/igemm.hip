@@ -20,6 +20,7 @@
 //     asymmetric padding are folded into the im2col addressing.
 //   * workgroup ids are remapped XCD-aware so tiles sharing activation rows share an L2.
 #include "common.h"
+extern "C" int mg_igemm_generation(void);
 
 namespace {
 
@@ -330,6 +331,14 @@ int launch_variant(const IgemmArgs& a, int batch_z, hipStream_t s) {
 }  // namespace
 
 int mg_launch_igemm(const mg_op* op, hipStream_t s) {
+  {
+    const int v = op->i[19];
+    if ((v == 0 && mg_igemm_generation() == 2) || v >= 20) {
+      const int rc = mg_launch_igemm2(op, s, v);
+      if (rc >= 0) return rc;
+      MG_REQUIRE(op->i[12] != MG_EPI_GEGLU, "igemm: GEGLU shape unsupported by the generation-2 kernel");
+    }
+  }
   IgemmArgs a;
   a.A = (const bf16_t*)op->p[0];
   a.Wt = (const bf16_t*)op->p[1];

@@ -1,0 +1,449 @@
+// Implicit-GEMM bf16 MFMA kernel, generation 2 (the default): same contract as igemm.hip
+// (MG_OP_IGEMM in include/marigold_hip.h: conv3x3 / conv1x1 / Linear / batched GEMM replacing the
+// torch conv2d / linear / matmul calls inside diffusers' UNet2DConditionModel / AutoencoderKL,
+// reference call sites marigold/marigold_depth_pipeline.py:461-463, 491-492, 512-513).
+//
+// What changed against generation 1, all of it aimed at the two things the first profile showed
+// (UNet GEMMs at 14 % of the MFMA roof, the loop draining its DMA queue at every barrier):
+//   * NSTAGE-deep LDS ring filled by global_load_lds_dwordx4 with COUNTED `s_waitcnt vmcnt(N)` and a
+//     raw `s_barrier`: up to NSTAGE-1 K tiles stay in flight across the barrier (one barrier per
+//     K step).  All LDS lives in one dynamic array so hipcc adds no vmcnt(0) of its own.
+//   * im2col addressing is hoisted: per-row source pointers are rebuilt once per TAP (branch-free,
+//     padding rows point at a zero region), the per-K-step work is one 64-bit add per row.
+//   * the transposed (V^T) section is a template parameter (own launch) - no dual code path, the
+//     256x128 tile needs ~120 VGPRs.
+//   * epilogue: a lane^32 exchange regroups the MFMA accumulators so every lane owns 8 consecutive
+//     output channels of one pixel -> 16-byte NHWC stores / residual loads (32-byte for fp32),
+//     v_cvt_pk_bf16_f32 instead of integer rounding.  GEGLU pairs u/gate rows 16 apart (32-row
+//     interleave, weights.py::pack_geglu) so it keeps the 16-byte stores too.
+#include "common.h"
+
+namespace {
+
+struct Igemm2Args {
+  const bf16_t* A;
+  const bf16_t* Wt;
+  void* out;
+  const float* bias;
+  const float* rowvec;
+  const bf16_t* res;
+  const void* zero;
+  int H, W, Cin, Ho, Wo, N, taps, stride, pad, Hu, Wu, epi, ldo, ldr, lda, ldt, ldw;
+  int M, rows_per_img, tiles_m, tiles_n, cpt, KT, rv_stride, up2, ctr;
+  long long sA, sW, sO, sR;
+  float scale;
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {  // v_cvt_pk_bf16_f32 (RNE)
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// TRANS = false: weights are the MFMA "A" operand, pixels "B": acc[ni][mi][4g+j] = C[m = mb+l31][n = nb+8g+4h+j]
+// TRANS = true : pixels "A", weights "B":                      acc[ni][mi][4g+j] = C[m = mb+8g+4h+j][n = nb+l31]
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS>
+__global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args a) {
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
+  constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
+  constexpr int LOADS = A_IT + B_IT;  // LDS-DMA instructions per wave per K tile
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int D = NSTAGE - 1;       // prefetch distance (tiles in flight)
+  static_assert(A_IT >= 1 && B_IT >= 1 && MI >= 1 && NI >= 1, "tile too small for the block");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_z = a.tiles_m * a.tiles_n;
+  const int z = bid / per_z;
+  const int t = bid - z * per_z;
+  const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bf16_t* __restrict__ Ab = a.A + (long long)z * a.sA;
+  const bf16_t* __restrict__ Wb = a.Wt + (long long)z * a.sW;
+  const char* zero = (const char*)a.zero;
+
+  // ---- staging rows owned by this thread (fixed over the K loop) ----
+  int a_by[A_IT], a_bx[A_IT], a_qoff[A_IT];
+  long long a_img[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int ci = it * NT + tid;
+    const int r = ci >> 3, p = ci & 7;
+    a_qoff[it] = (p ^ ((r >> 1) & 7)) * 8;
+    const int m = m0 + r;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
+    const int img = mm / a.rows_per_img;
+    const int rem = mm - img * a.rows_per_img;
+    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    a_by[it] = ok ? oy * a.stride - a.pad : -(1 << 28);  // rows beyond M never pass the bounds test
+    a_bx[it] = ox * a.stride - a.pad;
+    a_img[it] = (long long)img * a.H * a.W;
+  }
+  const char* b_ptr[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int ci = it * NT + tid;
+    const int r = ci >> 3, p = ci & 7;
+    const int n = n0 + r;
+    b_ptr[it] = (n < a.N) ? (const char*)(Wb + (long long)n * a.ldw + (p ^ ((r >> 1) & 7)) * 8) : zero;
+  }
+  const char* a_ptr[A_IT];
+  const int hb = a.Hu ? a.Hu : a.H, wb = a.Hu ? a.Wu : a.W;  // bounds in (virtual) input space
+  auto tap_setup = [&](int tap) {
+    int dy = 0, dx = 0;
+    if (a.taps == 9) { dy = tap / 3; dx = tap - dy * 3; }
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      int iy = a_by[it] + dy, ix = a_bx[it] + dx;
+      const bool ok = (unsigned)iy < (unsigned)hb && (unsigned)ix < (unsigned)wb;
+      if (a.Hu) {
+        if (a.up2) { iy >>= 1; ix >>= 1; }
+        else { iy = ok ? (iy * a.H) / a.Hu : 0; ix = ok ? (ix * a.W) / a.Wu : 0; }
+      }
+      const char* pv = (const char*)(Ab + (a_img[it] + (long long)iy * a.W + ix) * a.lda + a_qoff[it]);
+      a_ptr[it] = ok ? pv : zero;
+    }
+  };
+  int i_tap = 0, i_c = 0;  // (tap, channel tile) of the NEXT tile to issue
+  tap_setup(0);
+  auto issue = [&](int stage) {
+    char* sbase = smem + stage * STAGE;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      glds16(a_ptr[it], sbase + (it * NT + wave * 64) * 16);
+      a_ptr[it] += 128;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      glds16(b_ptr[it], sbase + BM * 128 + (it * NT + wave * 64) * 16);
+      b_ptr[it] += 128;
+    }
+    if (++i_c == a.cpt) {
+      i_c = 0;
+      ++i_tap;
+      if (i_tap < a.taps) tap_setup(i_tap);
+    }
+  };
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  int rowA[MI], rowB[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) rowA[mi] = wm * TM + mi * 32 + l31;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) rowB[ni] = wn * TN + ni * 32 + l31;
+
+  const int KT = a.KT;
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < KT) issue(d);
+  int st_c = 0;                 // stage holding tile kt
+  int st_i = D % NSTAGE;        // stage receiving tile kt + D
+  for (int kt = 0; kt < KT; ++kt) {
+    // tile kt has landed once at most min(D-1, KT-1-kt) younger tiles are still outstanding
+    const int younger = KT - 1 - kt;
+    if (D >= 3 && younger >= 2) wait_vmcnt<2 * LOADS>();
+    else if (D >= 2 && younger >= 1) wait_vmcnt<LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // everyone's part of tile kt landed; everyone left stage st_i
+    if (kt + D < KT) issue(st_i);
+    const char* sA = smem + st_c * STAGE;
+    const char* sB = sA + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int q = ks * 2 + half;
+      bf16x8 fa[MI], fb[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int r = rowA[mi];
+        fa[mi] = __builtin_bit_cast(bf16x8, *(const uint4*)(sA + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int r = rowB[ni];
+        fb[ni] = __builtin_bit_cast(bf16x8, *(const uint4*)(sB + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          if constexpr (!TRANS)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+          else
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[ni][mi], 0, 0, 0);
+        }
+    }
+    st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
+    st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+  }
+
+  // ---------------- epilogue ----------------
+  const float scale = a.scale;
+  if constexpr (!TRANS) {
+    if (a.epi == MG_EPI_GEGLU) {
+      // Weight rows are interleaved in 32-row groups (weights.py::pack_geglu): rows [32i,32i+16) =
+      // u(16i..16i+15), rows [32i+16,32i+32) = their gates.  acc groups g = 0,1 are u(16i+8g+4h+j),
+      // g = 2,3 the gates of the same channels; a lane^32 exchange then leaves 8 consecutive output
+      // channels per lane -> one 16-byte store per (mi, ni).
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * TM + mi * 32 + l31;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int nb = n0 + wn * TN + ni * 32;
+          const bool nok = nb < a.N;
+          float r[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int nu = nb + 4 * half + j;
+            float u0 = acc[ni][mi][j] * scale, u1 = acc[ni][mi][4 + j] * scale;
+            float t0 = acc[ni][mi][8 + j] * scale, t1 = acc[ni][mi][12 + j] * scale;
+            if (a.bias && nok) {
+              u0 += a.bias[nu]; u1 += a.bias[nu + 8]; t0 += a.bias[nu + 16]; t1 += a.bias[nu + 24];
+            }
+            const float o0 = u0 * gelu_erf_f(t0);  // channel 16i + 4h + j
+            const float o1 = u1 * gelu_erf_f(t1);  // channel 16i + 8 + 4h + j
+            const float recv = __shfl_xor(half ? o0 : o1, 32);
+            r[j] = half ? recv : o0;
+            r[4 + j] = half ? o1 : recv;
+          }
+          if (m < a.M && nok) {
+            const int oc = (nb >> 1) + 8 * half;  // 16 output channels per 32 weight rows
+            uint4 pk;
+            pk.x = cvt_pk_bf16(r[0], r[1]); pk.y = cvt_pk_bf16(r[2], r[3]);
+            pk.z = cvt_pk_bf16(r[4], r[5]); pk.w = cvt_pk_bf16(r[6], r[7]);
+            *(uint4*)((bf16_t*)a.out + (long long)z * a.sO + (long long)m * a.ldo + oc) = pk;
+          }
+        }
+      }
+      return;
+    }
+  }
+  // lane^32 exchange: afterwards v[0..7] are 8 consecutive "inner" indices (inner = n, or m when
+  // TRANS) starting at 16*gp + 8*half, for the lane's outer index l31.
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int mb = m0 + wm * TM + mi * 32, nb = n0 + wn * TN + ni * 32;
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g0 = acc[ni][mi][8 * gp + j], g1 = acc[ni][mi][8 * gp + 4 + j];
+          const float recv = __shfl_xor(half ? g0 : g1, 32);
+          v[j] = half ? recv : g0;
+          v[4 + j] = half ? g1 : recv;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= scale;
+        if constexpr (!TRANS) {
+          const int m = mb + l31, n = nb + 16 * gp + 8 * half;
+          if (m < a.M && n < a.N) {
+            if (a.bias) {
+              const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
+              v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+              v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            if (a.rowvec) {
+              const float* rv = a.rowvec + (long long)(m / a.rows_per_img) * a.rv_stride + n;
+              const float4 r0 = *(const float4*)rv, r1 = *(const float4*)(rv + 4);
+              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+              v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            }
+            if (a.epi == MG_EPI_F32) {
+              float* o = (float*)a.out + (long long)z * a.sO + (long long)m * a.ldo + n;
+              *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+              *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+              if (a.res) {
+                const uint4 r4 = *(const uint4*)(a.res + (long long)z * a.sR + (long long)m * a.ldr + n);
+                v[0] += bflo(r4.x); v[1] += bfhi(r4.x); v[2] += bflo(r4.y); v[3] += bfhi(r4.y);
+                v[4] += bflo(r4.z); v[5] += bfhi(r4.z); v[6] += bflo(r4.w); v[7] += bfhi(r4.w);
+              }
+              uint4 pk;
+              pk.x = cvt_pk_bf16(v[0], v[1]); pk.y = cvt_pk_bf16(v[2], v[3]);
+              pk.z = cvt_pk_bf16(v[4], v[5]); pk.w = cvt_pk_bf16(v[6], v[7]);
+              *(uint4*)((bf16_t*)a.out + (long long)z * a.sO + (long long)m * a.ldo + n) = pk;
+            }
+          }
+        } else {
+          // transposed store: out[z][img][n][tok], 8 consecutive tokens per lane
+          const int n = nb + l31, m = mb + 16 * gp + 8 * half;
+          if (n < a.N && m < a.M) {
+            const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += bv;
+            const int img = m / a.rows_per_img;
+            const int tok = m - img * a.rows_per_img;
+            if (tok + 8 <= a.rows_per_img && (a.rows_per_img & 7) == 0) {
+              bf16_t* o = (bf16_t*)a.out + (long long)z * a.sO + ((long long)img * a.ctr + n) * a.ldt + tok;
+              uint4 pk;
+              pk.x = cvt_pk_bf16(v[0], v[1]); pk.y = cvt_pk_bf16(v[2], v[3]);
+              pk.z = cvt_pk_bf16(v[4], v[5]); pk.w = cvt_pk_bf16(v[6], v[7]);
+              *(uint4*)o = pk;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int mj = m + j;
+                if (mj < a.M) {
+                  const int im = mj / a.rows_per_img;
+                  const int tk = mj - im * a.rows_per_img;
+                  ((bf16_t*)a.out)[(long long)z * a.sO + ((long long)im * a.ctr + n) * a.ldt + tk] = f2bf(v[j]);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS>
+int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int LDS = NSTAGE * (BM + BN) * 128;
+  static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
+  static bool attr_set = false;
+  auto kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS>;
+  if (!attr_set && !g_dry_run) {
+    MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  Igemm2Args b = a;
+  b.tiles_m = (a.M + BM - 1) / BM;
+  b.tiles_n = (a.N + BN - 1) / BN;
+  const long long grid = (long long)b.tiles_m * b.tiles_n * batch_z;
+  MG_REQUIRE(grid > 0 && grid < (1ll << 31), "igemm: bad grid %lld", grid);
+  MG_LAUNCH(kern, dim3((unsigned)grid), dim3(NT), LDS, s, b);
+  if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <bool TRANS>
+int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) {
+  switch (variant) {
+    case 20: return launch2<256, 128, 4, 2, 3, TRANS>(a, batch_z, s);
+    case 21: return launch2<128, 128, 2, 2, 2, TRANS>(a, batch_z, s);
+    case 22: return launch2<128, 128, 4, 2, 3, TRANS>(a, batch_z, s);
+    case 23: return launch2<64, 64, 2, 2, 2, TRANS>(a, batch_z, s);
+    case 24: return launch2<256, 64, 4, 2, 3, TRANS>(a, batch_z, s);
+    case 25: return launch2<128, 64, 2, 2, 3, TRANS>(a, batch_z, s);
+    case 26: return launch2<256, 128, 4, 2, 2, TRANS>(a, batch_z, s);
+    case 27: return launch2<128, 128, 2, 2, 3, TRANS>(a, batch_z, s);
+    case 28: return launch2<128, 128, 2, 2, 4, TRANS>(a, batch_z, s);
+    default: MG_REQUIRE(false, "igemm: unknown v2 tile variant %d", variant);
+  }
+  return 0;
+}
+
+}  // namespace
+
+int mg_igemm_auto_variant(long long M, int N, int batch_z);
+
+// Generation-2 entry: returns -1 when the op needs the generation-1 kernel (unsupported shape).
+int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
+  Igemm2Args a;
+  a.A = (const bf16_t*)op->p[0];
+  a.Wt = (const bf16_t*)op->p[1];
+  a.out = op->p[2];
+  a.bias = (const float*)op->p[3];
+  a.rowvec = (const float*)op->p[4];
+  a.res = (const bf16_t*)op->p[5];
+  void* out2 = op->p[6];
+  a.zero = g_zero_page;
+  const int B = op->i[0];
+  a.H = op->i[1]; a.W = op->i[2]; a.Cin = op->i[3]; a.Ho = op->i[4]; a.Wo = op->i[5];
+  a.N = op->i[6]; a.taps = op->i[7]; a.stride = op->i[8]; a.pad = op->i[9];
+  a.Hu = op->i[10]; a.Wu = op->i[11]; a.epi = op->i[12]; a.ldo = op->i[13];
+  const int trans_from = op->i[14];
+  const int batch_z = op->i[15] > 0 ? op->i[15] : 1;
+  a.ldr = op->i[16] > 0 ? op->i[16] : a.N;
+  a.lda = op->i[17] > 0 ? op->i[17] : a.Cin;
+  a.ldt = op->i[18];
+  a.ldw = op->i[20] > 0 ? op->i[20] : a.taps * a.Cin;
+  a.rv_stride = op->i[21] ? 0 : a.N;
+  a.sA = op->l[0]; a.sW = op->l[1]; a.sO = op->l[2]; a.sR = op->l[3];
+  a.scale = op->f[0] == 0.f ? 1.f : op->f[0];
+  a.rows_per_img = a.Ho * a.Wo;
+  a.M = B * a.rows_per_img;
+  a.cpt = a.Cin / 64;
+  a.KT = a.taps * a.cpt;
+  a.up2 = (a.Hu == 2 * a.H) && (a.Wu == 2 * a.W);
+  a.ctr = 0;
+  a.tiles_m = a.tiles_n = 0;
+  MG_REQUIRE(g_zero_page || g_dry_run, "igemm: mg_init() not called");
+  MG_REQUIRE(a.A && a.Wt && (a.out || out2), "igemm: null pointer");
+  MG_REQUIRE(a.taps == 1 || a.taps == 9, "igemm: taps must be 1 or 9 (got %d)", a.taps);
+  MG_REQUIRE(a.Cin > 0 && a.Cin % 64 == 0, "igemm: Cin %d must be a multiple of 64", a.Cin);
+  MG_REQUIRE(a.N > 0 && a.N % 4 == 0, "igemm: N %d must be a multiple of 4", a.N);
+  MG_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "igemm: lda/ldw must be multiples of 8");
+  MG_REQUIRE(a.M > 0 && a.stride >= 1, "igemm: empty problem");
+  MG_REQUIRE(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.Wt % 16 == 0), "igemm: A/Wt need 16-B alignment");
+  // generation-2 preconditions (16-byte epilogue accesses, zero-region reach)
+  const bool geglu = a.epi == MG_EPI_GEGLU;
+  if (a.N % 8 != 0 || a.ldo % 8 != 0 || (a.res && a.ldr % 8 != 0)) return -1;
+  if ((long long)a.Cin * 2 + 256 > MG_ZERO_BYTES || (long long)a.taps * a.Cin * 2 + 256 > MG_ZERO_BYTES) return -1;
+  if (geglu && a.N % 32 != 0) return -1;
+  if (a.out && ((uintptr_t)a.out % 16 != 0)) return -1;
+  if (a.res && ((uintptr_t)a.res % 16 != 0)) return -1;
+  int rc = 0;
+  const int nmain = trans_from >= 0 ? trans_from : a.N;
+  if (nmain > 0) {
+    Igemm2Args m = a;
+    m.N = nmain;
+    const int v = variant ? variant : mg_igemm_auto_variant(m.M, m.N, batch_z);
+    rc = dispatch_tile<false>(m, batch_z, v, s);
+    if (rc) return rc;
+  }
+  if (trans_from >= 0) {
+    MG_REQUIRE(out2 && a.ldt > 0 && a.ldt % 8 == 0, "igemm: bad transposed section");
+    MG_REQUIRE(trans_from % 8 == 0 && (uintptr_t)out2 % 16 == 0, "igemm: transposed section misaligned");
+    Igemm2Args tns = a;
+    tns.out = out2;
+    tns.Wt = a.Wt + (long long)trans_from * a.ldw;
+    tns.bias = a.bias ? a.bias + trans_from : nullptr;
+    tns.N = a.N - trans_from;
+    tns.ctr = a.N - trans_from;
+    tns.rowvec = nullptr;
+    tns.res = nullptr;
+    tns.epi = MG_EPI_BF16;
+    const int v = variant ? variant : mg_igemm_auto_variant(tns.M, tns.N, batch_z);
+    rc = dispatch_tile<true>(tns, batch_z, v, s);
+  }
+  return rc;
+}
+
+// Tile choice.  256x128 (8 waves, 3-stage ring) whenever it fills the chip; smaller tiles for the
+// deep UNet levels where M is a few thousand pixels.
+int mg_igemm_auto_variant(long long M, int N, int batch_z) {
+  const long long t256 = ((M + 255) / 256) * ((N + 127) / 128) * batch_z;
+  const long long t128 = ((M + 127) / 128) * ((N + 127) / 128) * batch_z;
+  if (t256 >= 200) return 20;
+  if (t128 >= 160) return 27;
+  return 23;
+}

@@ -4,6 +4,7 @@
 // denoising loop of marigold_depth_pipeline.py:455-468 becomes ONE mg_program_run call.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -13,6 +14,7 @@
 
 void* g_zero_page = nullptr;
 thread_local bool g_dry_run = false;
+int g_igemm_gen = 2;
 static thread_local char g_err[512] = "";
 static std::mutex g_init_mutex;
 static int g_device = -1;
@@ -59,6 +61,18 @@ static int dispatch(const mg_op* op, hipStream_t s) {
 extern "C" {
 
 int mg_abi_version(void) { return MG_ABI_VERSION; }
+
+// GEMM kernel generation in force (2 unless MARIGOLD_IGEMM_GEN=1) and the GEGLU weight-row
+// interleave it expects (the host packs ff.net.0.proj accordingly).
+static void read_gen_env() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  const char* e = getenv("MARIGOLD_IGEMM_GEN");
+  if (e && e[0] == '1') g_igemm_gen = 1;
+}
+int mg_igemm_generation(void) { read_gen_env(); return g_igemm_gen; }
+int mg_geglu_interleave(void) { read_gen_env(); return g_igemm_gen == 1 ? 16 : 32; }
 const char* mg_last_error(void) { return g_err; }
 
 int mg_init(int device) {
@@ -75,8 +89,8 @@ int mg_init(int device) {
   if (g_zero_page && g_device == device) return 0;
   MG_REQUIRE(g_device < 0 || g_device == device,
              "mg_init: one process drives one GPU (already bound to device %d)", g_device);
-  MG_CHECK_HIP(hipMalloc(&g_zero_page, 4096));
-  MG_CHECK_HIP(hipMemset(g_zero_page, 0, 4096));
+  MG_CHECK_HIP(hipMalloc(&g_zero_page, MG_ZERO_BYTES));
+  MG_CHECK_HIP(hipMemset(g_zero_page, 0, MG_ZERO_BYTES));
   g_device = device;
   return 0;
 }

@@ -1,19 +1,34 @@
 """Test-time ensembling on the GPU - same functions, arguments, defaults and errors as the
 reference's marigold/util/ensemble.py (``ensemble_depth`` :39-196, ``ensemble_normals``
-:199-249), but every per-pixel pass is a HIP kernel (csrc/ensemble.hip):
+:199-249), with every per-pixel pass a HIP kernel (csrc/ensemble.hip).
 
-* the E(E-1)/2 pairwise-RMSE reductions of the alignment cost (:142-144, one ``.item()`` sync
-  each in the reference) collapse to a closed form in the per-member means and the centred
-  E x E second-moment matrix, gathered ONCE per call;
+What the reference's optimiser actually does (and what is reproduced here)
+--------------------------------------------------------------------------
+``compute_param`` (:154-173) hands ``scipy.optimize.minimize(BFGS, tol=1e-6, maxiter=50)`` a cost
+with NO gradient, so scipy takes forward differences with the absolute step h = 2^-26 = 1.49e-8
+- but the cost first casts the parameters to the fp32 depth dtype (``torch.from_numpy(s).to(depth)``,
+:109-114).  A perturbed parameter therefore only changes the cost if ``fp32(p_i + h) != fp32(p_i)``:
+the finite difference equals  dcost/dp_i * k_i,  k_i = (fp32(p_i + h) - fp32(p_i)) / h.  For the
+scales (s_i = 1/range_i >= 1, fp32 spacing 1.2e-7 >> h, init values on the fp32 grid) k_i == 0:
+**the reference never moves the scales off ``init_param``; it optimises the shifts only**, and
+those only while |t_i| is small enough for h to survive the rounding ([probed]: on every golden
+case s_final / s_init == 1 exactly).  Taken literally the cost has a degenerate global optimum
+(all s -> 0 costs just the 0.02 regulariser), so an "exact" optimiser collapses the ensemble; the
+reference is only meaningful because of this quantisation.  This module keeps it: the BFGS sees
+f(fp32(p)) and the analytic gradient multiplied by k (== the reference's finite differences in exact
+arithmetic), without the reference's fp32 summation noise.  Result: identical scales, shifts
+optimised at least as far as the reference gets (its noise stops it early), deterministic output.
+
+How it runs on the device
+-------------------------
+* the E(E-1)/2 pairwise-RMSE reductions of the cost (:142-144, one ``.item()`` sync each in the
+  reference) are a closed form of the per-member means and the centred E x E second-moment
+  matrix, gathered ONCE per call by ``MG_OP_ENS_DEPTH_STATS``;
 * the only per-evaluation pixel work is the fused align -> median -> min/max kernel of the
-  regulariser (:146-150); it also reports the raw member values at the extremal pixels, so the
-  cost comes with its exact (sub)gradient and scipy's BFGS needs ~1 evaluation per iteration
-  instead of 2E+1 finite-difference evaluations;
+  regulariser (:146-150, ``MG_OP_ENS_DEPTH_MEDIAN``); it also reports the raw member values at the
+  extremal pixels, from which the host forms the exact (sub)gradient - one kernel pair per BFGS
+  evaluation instead of 2E+1 cost evaluations x (E(E-1)/2 + 2) host syncs;
 * final align -> median (+MAD) -> normalise never leaves the device.
-
-The optimiser's trajectory therefore differs from the reference's (whose finite-difference
-gradients of an fp32 cost are rounding-noise driven and end in "precision loss"); the contract
-is: achieved cost <= reference cost (+eps) and the aligned output within tolerance.
 """
 import numpy as np
 import torch
@@ -21,6 +36,7 @@ import torch
 from . import ops as O
 
 _SCRATCH_BYTES = 12288
+_FD_STEP = 1.4901161193847656e-08   # scipy's forward-difference step (sqrt(eps)), absolute
 
 
 def _check_depth_args(depth, reduction, scale_invariant, shift_invariant):
@@ -32,26 +48,62 @@ def _check_depth_args(depth, reduction, scale_invariant, shift_invariant):
         raise ValueError("Pure shift-invariant ensembling is not supported.")
 
 
-class DepthAligner:
-    """Cost / gradient of the reference's alignment objective for one stack of members."""
+def _q32(p):
+    """The fp32 cast the reference applies to the parameters inside its cost (:109-114)."""
+    return np.asarray(p, dtype=np.float64).astype(np.float32).astype(np.float64)
 
-    def __init__(self, d32, scale_invariant, shift_invariant, reduction, regularizer_strength):
-        E = d32.shape[0]
-        self.E, self.HW = E, d32.shape[2] * d32.shape[3]
-        self.d = d32.reshape(E, self.HW).contiguous()
-        self.affine = scale_invariant and shift_invariant
-        self.red = 0 if reduction == "median" else 1
-        self.lam = float(regularizer_strength)
-        dev = d32.device
+
+def fd_survival(p):
+    """k_i = (fp32(p_i + h) - fp32(p_i)) / h: how much of scipy's forward-difference step survives
+    the reference's fp32 parameter cast (0 for |p_i| >~ 0.25, i.e. always for the scales)."""
+    p = np.asarray(p, dtype=np.float64)
+    return (_q32(p + _FD_STEP) - _q32(p)) / _FD_STEP
+
+
+class HipStatsBackend:
+    """The two device passes the aligner needs, as HIP kernels."""
+
+    def __init__(self, d, reduction, affine):
+        E, HW = d.shape
+        self.d, self.E, self.HW = d, E, HW
+        self.red, self.affine = reduction, affine
+        dev = d.device
         self.scratch = torch.empty(_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
         self.mm = torch.empty(2 + 2 * E, dtype=torch.float32, device=dev)
         self.st = torch.empty(2 * E, dtype=torch.float32, device=dev)
+
+    def stats(self):
+        E = self.E
+        dev = self.d.device
         sscratch = torch.empty(128 * E * 35, dtype=torch.float64, device=dev)
         stats = torch.empty(3 * E + E * E, dtype=torch.float64, device=dev)
         O.launch(O.ens_depth_stats(self.d, sscratch, stats, E=E, HW=self.HW))
         st = stats.cpu().numpy()
-        self.dmin, self.dmax, self.mean = st[:E], st[E:2 * E], st[2 * E:3 * E]
-        self.C = st[3 * E:].reshape(E, E)
+        return st[:E], st[E:2 * E], st[2 * E:3 * E], st[3 * E:].reshape(E, E)
+
+    def regulariser(self, s32, t32):
+        """(min, max of the ensembled aligned prediction, raw member values at those two pixels)."""
+        E = self.E
+        self.st.copy_(torch.from_numpy(np.concatenate([s32, t32]).astype(np.float32)))
+        O.launch(O.ens_depth_median(self.d, self.st, None, None, self.mm, self.scratch, E=E, HW=self.HW,
+                                    reduction=self.red, has_shift=self.affine))
+        r = self.mm.cpu().numpy().astype(np.float64)
+        return r[0], r[1], r[2:2 + E], r[2 + E:]
+
+
+class DepthAligner:
+    """Cost / gradient of the reference's alignment objective for one stack of members
+    (``backend`` supplies the two pixel passes; the default runs them as HIP kernels)."""
+
+    def __init__(self, d32, scale_invariant, shift_invariant, reduction, regularizer_strength, backend=None):
+        E = d32.shape[0]
+        self.E, self.HW = E, d32.shape[2] * d32.shape[3]
+        self.affine = scale_invariant and shift_invariant
+        self.red = 0 if reduction == "median" else 1
+        self.lam = float(regularizer_strength)
+        self.backend = backend if backend is not None else HipStatsBackend(
+            d32.reshape(E, self.HW).contiguous(), self.red, self.affine)
+        self.dmin, self.dmax, self.mean, self.C = self.backend.stats()
         self.n_eval = 0
 
     def init_param(self):
@@ -67,19 +119,11 @@ class DepthAligner:
             return p[:self.E], p[self.E:]
         return p, np.zeros(self.E)
 
-    def regulariser_stats(self, p):
-        """(min, max of the ensembled prediction, raw member values at those two pixels)."""
-        s, t = self._split(np.asarray(p, dtype=np.float64))
-        self.st.copy_(torch.from_numpy(np.concatenate([s, t]).astype(np.float32)))
-        O.launch(O.ens_depth_median(self.d, self.st, None, None, self.mm, self.scratch, E=self.E,
-                                    HW=self.HW, reduction=self.red, has_shift=self.affine))
-        r = self.mm.cpu().numpy().astype(np.float64)
-        return r[0], r[1], r[2:2 + self.E], r[2 + self.E:]
-
     def cost_and_grad(self, p):
+        """Exact cost and gradient at the fp32-cast parameters."""
         self.n_eval += 1
         E = self.E
-        s, t = self._split(np.asarray(p, dtype=np.float64))
+        s, t = self._split(_q32(p))
         u = s * self.mean + t
         C = self.C
         q = (s[:, None] ** 2) * np.diag(C)[:, None] + (s[None, :] ** 2) * np.diag(C)[None, :] \
@@ -97,9 +141,9 @@ class DepthAligner:
                    + 2.0 * du * self.mean[:, None])).sum(axis=1)
         gt = (w * 2.0 * du).sum(axis=1)
         if self.lam > 0:
-            mn, mx, dmn, dmx = self.regulariser_stats(p)
-            cost += (abs(0.0 - mn) + abs(1.0 - mx)) * self.lam
             s32, t32 = s.astype(np.float32), t.astype(np.float32)
+            mn, mx, dmn, dmx = self.backend.regulariser(s32, t32)
+            cost += (abs(0.0 - mn) + abs(1.0 - mx)) * self.lam
             for val, draw, sign in ((mn, dmn, np.sign(mn)), (mx, dmx, -np.sign(1.0 - mx))):
                 a = (draw.astype(np.float32) * s32 + t32)
                 if self.red == 0:  # lower-middle median: which member is it at that pixel?
@@ -115,6 +159,12 @@ class DepthAligner:
 
     def cost(self, p):
         return self.cost_and_grad(p)[0]
+
+    def reference_fd_objective(self, p):
+        """(f, g) as the reference's scipy call sees them: g_i = analytic gradient x the share of the
+        forward-difference step that survives the fp32 parameter cast."""
+        f, g = self.cost_and_grad(p)
+        return f, g * fd_survival(p)
 
 
 def ensemble_depth(depth, scale_invariant=True, shift_invariant=True, output_uncertainty=False,
@@ -137,7 +187,7 @@ def ensemble_depth(depth, scale_invariant=True, shift_invariant=True, output_unc
             d_align = torch.nn.functional.interpolate(d, (int(H * f), int(W * f)), mode="nearest-exact")
         al = DepthAligner(d_align, scale_invariant, shift_invariant, reduction, regularizer_strength)
         p0 = al.init_param()
-        res = scipy.optimize.minimize(al.cost_and_grad, p0, jac=True, method="BFGS", tol=tol,
+        res = scipy.optimize.minimize(al.reference_fd_objective, p0, jac=True, method="BFGS", tol=tol,
                                       options={"maxiter": max_iter, "disp": False})
         p = res.x
         s, t = al._split(p)

