@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the denoising loop as a hipGraph")
     ap.add_argument("--dump-ops", default="", help="write the per-op timing table to this file")
     ap.add_argument("--cpu-baseline-only", default="", help=argparse.SUPPRESS)  # internal: child mode
-    ap.add_argument("--cpu-baseline-timeout", type=int, default=240)
+    ap.add_argument("--cpu-baseline-timeout", type=int, default=200)
     return ap.parse_args()
 
 
@@ -66,7 +66,7 @@ def cpu_baseline(args, members_path):
     usd, vsd = syn.synthetic_unet_state_dict(ucfg), syn.synthetic_vae_state_dict(vcfg)
     ctx = syn.synthetic_text_embedding(ucfg.cross_attention_dim)
     members = torch.from_numpy(np.load(members_path)) if members_path and os.path.exists(members_path) else None
-    cores = usable_cores()
+    cores = min(usable_cores(), 64)   # one socket's worth: torch's CPU kernels stop scaling beyond
     torch.set_num_threads(cores)
     E, T, res = args.ensemble, args.denoise, args.res
     lat = res // 8

@@ -41,6 +41,7 @@ enum mg_op_kind {
    *  i[15] batch_z  i[16] ldr  i[17] lda  i[18] ldt  i[19] tile variant (0 = auto; 1..13 force a
  *  generation-1 tile, 20..28 a generation-2 tile - used by the tuning sweep)  i[20] ldw
    *  i[21] rowvec broadcast (1 = a single [N] row shared by every image)
+ *  i[22] un-padded N for FLOP accounting (0 = N; ignored by the kernel)
    *  l[0..3] z-strides (elements) of A, Wt, out, residual      f[0] scale on the accumulator */
   MG_OP_IGEMM = 1,
   /* GroupNorm, 3 launches (stats partials -> per-(b,c) scale/shift -> apply [+SiLU]).
@@ -102,6 +103,10 @@ enum mg_op_kind {
    * marigold_depth_pipeline.py:510-512).  p[0] in f32 [B][Ci][HW] p[1] W f32 [Co][Ci]
    * p[2] b f32 p[3] out f32 [B][Co][HW] ; i: B,Ci,Co,HW ; f[0] input scale */
   MG_OP_LATENT_1X1 = 14,
+  /* Pointwise tail of a small-Cout convolution computed by MG_OP_IGEMM into a padded fp32 buffer:
+   * out NCHW = post(in[m][0..Cout) * f[0]) with the MG_POST_* tails of MG_OP_CONV_COUT_SMALL.
+   *  p[0] in f32 [B*HW][ldi]  p[1] out f32 NCHW ; i: B, HW, Cout, ldi, post ; f[0] scale */
+  MG_OP_POST_NCHW = 15,
   /* Test-time ensembling (marigold/util/ensemble.py).
    * DEPTH_STATS : one pass over [E][HW]: per-member min,max,mean and the centred E x E
    *               second-moment matrix (closed form of the pairwise-RMSE cost, :138-145).

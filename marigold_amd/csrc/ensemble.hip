@@ -208,20 +208,29 @@ __global__ __launch_bounds__(64) void minmax_final_kernel(const float* __restric
                                                           const float* __restrict__ d, float* __restrict__ out,
                                                           int nblk, int E, long long HW) {
   __shared__ long long px[2];
-  if (threadIdx.x == 0) {
-    float mn = blockmm[0], mx = blockmm[1];
-    long long pmn = blockpx[0], pmx = blockpx[1];
-    for (int i = 1; i < nblk; ++i) {
-      const float a = blockmm[2 * i], b = blockmm[2 * i + 1];
-      const long long pa = blockpx[2 * i], pb = blockpx[2 * i + 1];
-      if (a < mn || (a == mn && pa < pmn)) { mn = a; pmn = pa; }
-      if (b > mx || (b == mx && pb < pmx)) { mx = b; pmx = pb; }
-    }
+  // one wave: strided scan of the per-block results, then a lane reduction (ties -> lowest pixel)
+  const int lane = threadIdx.x;
+  float mn = 3.0e38f, mx = -3.0e38f;
+  long long pmn = 0x7fffffffffffffffll, pmx = 0x7fffffffffffffffll;
+  for (int i = lane; i < nblk; i += 64) {
+    const float a = blockmm[2 * i], b = blockmm[2 * i + 1];
+    const long long pa = blockpx[2 * i], pb = blockpx[2 * i + 1];
+    if (a < mn || (a == mn && pa < pmn)) { mn = a; pmn = pa; }
+    if (b > mx || (b == mx && pb < pmx)) { mx = b; pmx = pb; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float omn = __shfl_xor(mn, o), omx = __shfl_xor(mx, o);
+    const long long opmn = __shfl_xor(pmn, o), opmx = __shfl_xor(pmx, o);
+    if (omn < mn || (omn == mn && opmn < pmn)) { mn = omn; pmn = opmn; }
+    if (omx > mx || (omx == mx && opmx < pmx)) { mx = omx; pmx = opmx; }
+  }
+  if (lane == 0) {
     out[0] = mn; out[1] = mx;
     px[0] = pmn; px[1] = pmx;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < E; e += 64) {
+  for (int e = lane; e < E; e += 64) {
     out[2 + e] = d[(long long)e * HW + px[0]];
     out[2 + E + e] = d[(long long)e * HW + px[1]];
   }

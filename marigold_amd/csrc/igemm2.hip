@@ -356,6 +356,7 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
     case 26: return launch2<256, 128, 4, 2, 2, TRANS>(a, batch_z, s);
     case 27: return launch2<128, 128, 2, 2, 3, TRANS>(a, batch_z, s);
     case 28: return launch2<128, 128, 2, 2, 4, TRANS>(a, batch_z, s);
+    case 29: return launch2<128, 32, 4, 1, 3, TRANS>(a, batch_z, s);  // N <= 32 (4 <-> C boundary convs)
     default: MG_REQUIRE(false, "igemm: unknown v2 tile variant %d", variant);
   }
   return 0;
@@ -443,6 +444,7 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
 int mg_igemm_auto_variant(long long M, int N, int batch_z) {
   const long long t256 = ((M + 255) / 256) * ((N + 127) / 128) * batch_z;
   const long long t128 = ((M + 127) / 128) * ((N + 127) / 128) * batch_z;
+  if (N <= 32) return 29;
   if (t256 >= 200) return 20;
   if (t128 >= 160) return 27;
   return 23;

@@ -183,6 +183,43 @@ __global__ __launch_bounds__(256) void latent_1x1_kernel(const float* __restrict
   }
 }
 
+template <int COUT>
+__global__ __launch_bounds__(256) void post_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        long long npix, long long HW, int ldi, int post,
+                                                        float scale) {
+  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < npix;
+       pix += (long long)gridDim.x * 256) {
+    const long long b = pix / HW, p = pix - b * HW;
+    float acc[COUT];
+    const float4 v0 = *(const float4*)(in + pix * ldi);
+    acc[0] = v0.x * scale;
+    if (COUT > 1) acc[1] = v0.y * scale;
+    if (COUT > 2) acc[2] = v0.z * scale;
+    if (COUT > 3) acc[3] = v0.w * scale;
+    if (post == MG_POST_DEPTH) {
+      float m = 0.f;
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) m += acc[co];
+      m = m / (float)COUT;
+      m = fminf(fmaxf(m, -1.f), 1.f);
+      out[b * HW + p] = (m + 1.0f) * 0.5f;
+    } else if (post == MG_POST_NORMALS) {
+      float n2 = 0.f;
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) {
+        acc[co] = fminf(fmaxf(acc[co], -1.f), 1.f);
+        n2 += acc[co] * acc[co];
+      }
+      const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-6f);
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) out[(b * COUT + co) * HW + p] = acc[co] * inv;
+    } else {
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) out[(b * COUT + co) * HW + p] = acc[co];
+    }
+  }
+}
+
 }  // namespace
 
 int mg_launch_misc(const mg_op* op, hipStream_t s) {
@@ -260,6 +297,21 @@ int mg_launch_misc(const mg_op* op, hipStream_t s) {
       MG_LAUNCH(latent_1x1_kernel, dim3(grid), dim3(256), 0, s, (const float*)op->p[0],
                          (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], B, Ci, Co,
                          HW, op->f[0] == 0.f ? 1.f : op->f[0]);
+      break;
+    }
+    case MG_OP_POST_NCHW: {
+      const long long B = op->i[0], HW = op->i[1];
+      const int Cout = op->i[2], ldi = op->i[3], post = op->i[4];
+      MG_REQUIRE(ldi % 4 == 0 && ldi >= Cout, "post_nchw: ldi %d must be a multiple of 4 >= Cout", ldi);
+      const long long npix = B * HW;
+      const int grid = (int)min((npix + 255) / 256, (long long)8192);
+      const float sc = op->f[0] == 0.f ? 1.f : op->f[0];
+      switch (Cout) {
+        case 1: MG_LAUNCH(post_nchw_kernel<1>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
+        case 3: MG_LAUNCH(post_nchw_kernel<3>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
+        case 4: MG_LAUNCH(post_nchw_kernel<4>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
+        default: MG_REQUIRE(false, "post_nchw: unsupported Cout %d (1, 3 or 4)", Cout);
+      }
       break;
     }
     case MG_OP_MEMSET:

@@ -95,6 +95,18 @@ class WeightStore:
     def small_conv(self, name):
         return self._memo(("sc", name), lambda: Wm.f32(Wm.pack_small_conv(self.sd[f"{name}.weight"]), self.device))
 
+    def small_conv_mfma(self, key, w4, bias):
+        """Cout <= 8 conv3x3 as an MFMA GEMM: weights [Cout,Cin,3,3] -> bf16 [8][9*Cin] (rows >= Cout
+        zero), bias fp32 [8]."""
+        def f():
+            co = w4.shape[0]
+            w = torch.zeros(8, 9 * w4.shape[1])
+            w[:co] = Wm.pack_conv3x3(w4.float())
+            b = torch.zeros(8)
+            b[:co] = bias.float()
+            return Wm.bf16(w, self.device), Wm.f32(b, self.device)
+        return self._memo(("scm", key), f)
+
     def geglu(self, name):
         def f():
             w, b = Wm.pack_geglu(self.sd[f"{name}.weight"].float(), self.sd[f"{name}.bias"].float())
@@ -152,7 +164,8 @@ class Builder:
     # ---- primitive layers ----------------------------------------------------------------
     def group_norm(self, x, name, eps, silu):
         C, B, HW = x.C, x.B, x.HW
-        chunks = max(1, min(64, HW // 16))
+        # enough (chunk, image) blocks to cover the 256 CUs a few times over, >= 32 rows per chunk
+        chunks = max(1, min(HW // 32, max(64, 2048 // B)))
         part = self.raw(B * chunks * C * 2 * 4)
         ss = self.raw(B * 2 * C * 4)
         out = self.new(x.B, x.H, x.W, C)
@@ -178,6 +191,16 @@ class Builder:
                          rowvec=rowvec, rowvec_bcast=rowvec is not None,
                          residual=None if residual is None else residual.t), name)
         return out
+
+    def conv_to_nchw(self, x, key, w4, bias, out, cout, post=L.POST_NONE, scale=1.0):
+        """conv3x3 (pad 1) bf16 NHWC -> <= 4 fp32 NCHW channels on the MFMA path: GEMM into a padded
+        fp32 [M][8] buffer, then the pointwise tail (MG_OP_POST_NCHW)."""
+        w8, b8 = self.ws.small_conv_mfma(key, w4, bias)
+        tmp = self.raw(x.M * 8 * 4)
+        self.add(O.igemm(x.t, w8, tmp, B=x.B, H=x.H, W=x.W, Cin=x.C, Ho=x.H, Wo=x.W, N=8, taps=9, stride=1,
+                         pad=1, bias=b8, epi=L.EPI_F32, ldo=8, n_alg=cout), f"{key}")
+        self.add(O.post_nchw(tmp, out, B=x.B, HW=x.HW, Cout=cout, ldi=8, post=post, scale=scale), f"{key}.post")
+        self.free(tmp)
 
     def dense(self, x, wt, bias, N, *, residual=None, out=None, epi=L.EPI_BF16, label="", K=None, out_dtype_bytes=2):
         """x: Act viewed as [M][C]; wt: [N][K] bf16."""
@@ -401,8 +424,7 @@ def emit_unet_forward(bld, cfg, ctx, rgb_latent, x_latent, eps_out, temb_table, 
             x = y
     g = bld.group_norm(x, "conv_norm_out", 1e-5, True)
     bld.free(x)
-    bld.add(O.conv_cout_small(g.t, ws.small_conv("conv_out"), ws.bias("conv_out"), eps_out, B=B, H=h, W=w,
-                              Cin=c0, Cout=cfg.out_channels), "conv_out")
+    bld.conv_to_nchw(g, "conv_out", ws.sd["conv_out.weight"], ws.sd["conv_out.bias"], eps_out, cfg.out_channels)
     bld.free(g)
 
 
@@ -437,10 +459,9 @@ def emit_vae_encode(bld, cfg: VAEConfig, rgb, lat_out, B, H, W):
         bq = ws.sd["quant_conv.bias"].double()[:L4]
         w = torch.einsum("om,mcyx->ocyx", wq, wc)
         b = wq @ bc + bq
-        return Wm.f32(Wm.pack_small_conv(w.float()), bld.dev), Wm.f32(b.float(), bld.dev)
+        return w.float(), b.float()
     wcomp, bcomp = ws._memo(("enc_tail",), composed)
-    bld.add(O.conv_cout_small(g.t, wcomp, bcomp, lat_out, B=B, H=g.H, W=g.W, Cin=g.C, Cout=L4,
-                              scale=LATENT_SCALE), "encoder.conv_out+quant_conv")
+    bld.conv_to_nchw(g, "encoder.conv_out+quant_conv", wcomp, bcomp, lat_out, L4, scale=LATENT_SCALE)
     bld.free(g)
     return g.H, g.W
 
@@ -480,7 +501,7 @@ def emit_vae_decode(bld, cfg: VAEConfig, latent, out, B, h, w, post):
             x = y
     g = bld.group_norm(x, "decoder.conv_norm_out", 1e-6, True)
     bld.free(x)
-    bld.add(O.conv_cout_small(g.t, ws.small_conv("decoder.conv_out"), ws.bias("decoder.conv_out"), out, B=B,
-                              H=g.H, W=g.W, Cin=g.C, Cout=3, post=post), "decoder.conv_out")
+    bld.conv_to_nchw(g, "decoder.conv_out", ws.sd["decoder.conv_out.weight"], ws.sd["decoder.conv_out.bias"],
+                     out, 3, post=post)
     bld.free(g)
     return g.H, g.W

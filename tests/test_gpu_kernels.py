@@ -448,3 +448,33 @@ def test_program_and_graph_replay(dev):
     assert torch.equal(out, ref)
     ms = seq.profile()
     assert len(ms) == 3 and all(m >= 0 for m in ms)
+
+
+def test_small_cout_conv_on_mfma_path(dev):
+    """conv3x3 to <= 4 fp32 NCHW channels = GEMM into a padded fp32 [M][8] buffer (tile variant 29)
+    + MG_OP_POST_NCHW with the pipeline's pointwise tails (depth mean/clip/shift, normals L2)."""
+    from marigold_amd import _lib as L, ops, weights as Wm
+    g = torch.Generator().manual_seed(12)
+    B, H, W, Cin = 2, 20, 28, 128
+    x = _bf(torch.randn(B, Cin, H, W, generator=g))
+    for cout, post in ((3, L.POST_DEPTH), (3, L.POST_NORMALS), (4, L.POST_NONE)):
+        w = _bf(torch.randn(cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+        b = torch.randn(cout, generator=g) * 0.1
+        y = F.conv2d(x, w, b, padding=1) * 0.7
+        if post == L.POST_DEPTH:
+            ref = (y.mean(1, keepdim=True).clamp(-1, 1) + 1) / 2
+        elif post == L.POST_NORMALS:
+            yc = y.clamp(-1, 1)
+            ref = yc / yc.norm(dim=1, keepdim=True).clamp(min=1e-6)
+        else:
+            ref = y
+        w8 = torch.zeros(8, 9 * Cin)
+        w8[:cout] = Wm.pack_conv3x3(w)
+        b8 = torch.zeros(8)
+        b8[:cout] = b
+        tmp = torch.full((B * H * W, 8), float("nan"), device=dev)
+        out = torch.full(ref.shape, float("nan"), device=dev)
+        _run(ops.igemm(_nhwc(x).to(dev, torch.bfloat16), w8.to(dev, torch.bfloat16), tmp, B=B, H=H, W=W, Cin=Cin,
+                       Ho=H, Wo=W, N=8, taps=9, stride=1, pad=1, bias=b8.to(dev), epi=L.EPI_F32, ldo=8))
+        _run(ops.post_nchw(tmp, out, B=B, HW=H * W, Cout=cout, ldi=8, post=post, scale=0.7))
+        _close(f"small_cout_mfma/c{cout}p{post}", out, ref, tol=2e-2)
