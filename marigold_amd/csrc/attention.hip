@@ -206,6 +206,9 @@ __device__ __forceinline__ uint32_t fa_cvt_pk(float lo, float hi) {
 
 constexpr int FA2_NSTAGE = 3;
 
+// SPLIT: the four LDS-DMA pieces of tile kt+2 are issued behind the two QK^T MFMA groups instead
+// of in one burst after the barrier (their issue cost then overlaps the wave's own MFMAs).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[FA2_NSTAGE * FA_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
   }
   const long long k_step = (long long)FA_KB * a.ldq * 2;  // bytes per key tile
   int i_k0 = 0;                                            // first key of the next tile to issue
-  auto issue = [&](int stage) {
+  auto issue_k = [&](int stage) {
     char* sb = smem + stage * FA_STAGE;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -252,6 +255,9 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
       glds16(src, sb + (it * 256 + wave * 64) * 16);
       k_src[it] += k_step;
     }
+  };
+  auto issue_v = [&](int stage) {
+    char* sb = smem + stage * FA_STAGE;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       glds16(v_src[it], sb + FA_KB * 128 + (it * 256 + wave * 64) * 16);
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
     }
     i_k0 += FA_KB;
   };
+  auto issue = [&](int stage) { issue_k(stage); issue_v(stage); };
 
   f32x16 o[2];
 #pragma unroll
@@ -276,7 +283,10 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
     if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nkt) issue(st_i);
+    const bool do_issue = kt + 2 < nkt;
+    if constexpr (!SPLIT) {
+      if (do_issue) issue(st_i);
+    }
     const char* sK = smem + st_c * FA_STAGE;
     const char* sV = sK + FA_KB * 128;
 
@@ -293,6 +303,12 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
         const bf16x8 kf = __builtin_bit_cast(
             bf16x8, *(const uint4*)(sK + row * 128 + ((q ^ ((row >> 1) & 7)) << 4)));
         s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t2], 0, 0, 0);
+      }
+      if constexpr (SPLIT) {
+        if (do_issue) {
+          if (t2 == 0) issue_k(st_i);
+          else issue_v(st_i);
+        }
       }
     }
     // ---- online softmax; lane owns query l31, keys (r&3)+8(r>>2)+4*half of each sub-tile ----
@@ -483,10 +499,12 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       MG_REQUIRE(a.ldvt % 64 == 0 && a.ldvt >= a.Ntok, "flash_attn64: ldvt must be a multiple of 64 >= Ntok");
       MG_REQUIRE(a.ldq % 8 == 0 && a.ldo % 4 == 0, "flash_attn64: bad leading dims");
       const long long grid = (long long)a.nqb * a.heads * a.B;
-      // i[6]: 0 = generation 2 (needs 16-byte aligned O rows), 1 = generation 1
+      // i[6]: 0 = generation 2 with split DMA issue (needs 16-byte aligned O rows), 1 = generation 1,
+      // 2 = generation 2 with burst issue
       const bool v2ok = (a.ldo % 8 == 0) && ((uintptr_t)a.O % 16 == 0) && (a.sO % 8 == 0);
       if (op->i[6] == 1 || !v2ok) MG_LAUNCH(flash_attn64_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
-      else MG_LAUNCH(flash_attn64_v2_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
+      else if (op->i[6] == 2) MG_LAUNCH(flash_attn64_v2_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
+      else MG_LAUNCH(flash_attn64_v2_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);
       break;
     }
     case MG_OP_SOFTMAX_ROWS: {

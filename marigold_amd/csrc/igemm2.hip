@@ -30,6 +30,7 @@ struct Igemm2Args {
   const void* zero;
   int H, W, Cin, Ho, Wo, N, taps, stride, pad, Hu, Wu, epi, ldo, ldr, lda, ldt, ldw;
   int M, rows_per_img, tiles_m, tiles_n, cpt, KT, rv_stride, up2, ctr;
+  int n_begin, n_end;  // output-column range of this launch (tiles start at n_begin, bound n_end <= N)
   long long sA, sW, sO, sR;
   float scale;
 };
@@ -48,7 +49,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // TRANS = false: weights are the MFMA "A" operand, pixels "B": acc[ni][mi][4g+j] = C[m = mb+l31][n = nb+8g+4h+j]
 // TRANS = true : pixels "A", weights "B":                      acc[ni][mi][4g+j] = C[m = mb+8g+4h+j][n = nb+l31]
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS>
+// SPLIT: the LDS-DMA pieces of the next tile are issued in four portions BETWEEN the k-substeps'
+// fragment reads and their MFMAs instead of in one burst after the barrier, so the ~60-100 issue
+// cycles each piece costs overlap the wave's own MFMAs (all waves of a workgroup leave the barrier
+// together - a burst leaves every SIMD's matrix pipe idle at the same time).
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT>
 __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args a) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   const int z = bid / per_z;
   const int t = bid - z * per_z;
   const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BM, n0 = a.n_begin + tile_n * BN;
 
   const bf16_t* __restrict__ Ab = a.A + (long long)z * a.sA;
   const bf16_t* __restrict__ Wb = a.Wt + (long long)z * a.sW;
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
     const int ci = it * NT + tid;
     const int r = ci >> 3, p = ci & 7;
     const int n = n0 + r;
-    b_ptr[it] = (n < a.N) ? (const char*)(Wb + (long long)n * a.ldw + (p ^ ((r >> 1) & 7)) * 8) : zero;
+    b_ptr[it] = (n < a.n_end) ? (const char*)(Wb + (long long)n * a.ldw + (p ^ ((r >> 1) & 7)) * 8) : zero;
   }
   const char* a_ptr[A_IT];
   const int hb = a.Hu ? a.Hu : a.H, wb = a.Hu ? a.Wu : a.W;  // bounds in (virtual) input space
@@ -122,23 +127,28 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   };
   int i_tap = 0, i_c = 0;  // (tap, channel tile) of the NEXT tile to issue
   tap_setup(0);
-  auto issue = [&](int stage) {
+  auto issue_piece = [&](int stage, int idx) {  // idx in [0, LOADS): A pieces first, then B pieces
     char* sbase = smem + stage * STAGE;
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      glds16(a_ptr[it], sbase + (it * NT + wave * 64) * 16);
-      a_ptr[it] += 128;
-    }
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
+    if (idx < A_IT) {
+      glds16(a_ptr[idx], sbase + (idx * NT + wave * 64) * 16);
+      a_ptr[idx] += 128;
+    } else {
+      const int it = idx - A_IT;
       glds16(b_ptr[it], sbase + BM * 128 + (it * NT + wave * 64) * 16);
       b_ptr[it] += 128;
     }
+  };
+  auto advance = [&]() {
     if (++i_c == a.cpt) {
       i_c = 0;
       ++i_tap;
       if (i_tap < a.taps) tap_setup(i_tap);
     }
+  };
+  auto issue = [&](int stage) {
+#pragma unroll
+    for (int idx = 0; idx < LOADS; ++idx) issue_piece(stage, idx);
+    advance();
   };
 
   f32x16 acc[NI][MI];
@@ -168,7 +178,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
     else if (D >= 2 && younger >= 1) wait_vmcnt<LOADS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // everyone's part of tile kt landed; everyone left stage st_i
-    if (kt + D < KT) issue(st_i);
+    const bool do_issue = kt + D < KT;
+    if constexpr (!SPLIT) {
+      if (do_issue) issue(st_i);
+    }
     const char* sA = smem + st_c * STAGE;
     const char* sB = sA + BM * 128;
 #pragma unroll
@@ -185,6 +198,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
         const int r = rowB[ni];
         fb[ni] = __builtin_bit_cast(bf16x8, *(const uint4*)(sB + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)));
       }
+      if constexpr (SPLIT) {
+        if (do_issue) {
+#pragma unroll
+          for (int idx = ks; idx < LOADS; idx += 4) issue_piece(st_i, idx);
+        }
+      }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -194,6 +213,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
           else
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[ni][mi], 0, 0, 0);
         }
+    }
+    if constexpr (SPLIT) {
+      if (do_issue) advance();
     }
     st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
     st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
@@ -213,7 +235,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int nb = n0 + wn * TN + ni * 32;
-          const bool nok = nb < a.N;
+          const bool nok = nb < a.n_end;
           float r[8];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -262,7 +284,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
         for (int j = 0; j < 8; ++j) v[j] *= scale;
         if constexpr (!TRANS) {
           const int m = mb + l31, n = nb + 16 * gp + 8 * half;
-          if (m < a.M && n < a.N) {
+          if (m < a.M && n < a.n_end) {
             if (a.bias) {
               const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
               v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
         } else {
           // transposed store: out[z][img][n][tok], 8 consecutive tokens per lane
           const int n = nb + l31, m = mb + 16 * gp + 8 * half;
-          if (n < a.N && m < a.M) {
+          if (n < a.n_end && m < a.M) {
             const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += bv;
@@ -323,20 +345,20 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT = false>
 int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int LDS = NSTAGE * (BM + BN) * 128;
   static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
   static bool attr_set = false;
-  auto kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS>;
+  auto kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS, SPLIT>;
   if (!attr_set && !g_dry_run) {
     MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   Igemm2Args b = a;
   b.tiles_m = (a.M + BM - 1) / BM;
-  b.tiles_n = (a.N + BN - 1) / BN;
+  b.tiles_n = (a.n_end - a.n_begin + BN - 1) / BN;
   const long long grid = (long long)b.tiles_m * b.tiles_n * batch_z;
   MG_REQUIRE(grid > 0 && grid < (1ll << 31), "igemm: bad grid %lld", grid);
   MG_LAUNCH(kern, dim3((unsigned)grid), dim3(NT), LDS, s, b);
@@ -357,6 +379,12 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
     case 27: return launch2<128, 128, 2, 2, 3, TRANS>(a, batch_z, s);
     case 28: return launch2<128, 128, 2, 2, 4, TRANS>(a, batch_z, s);
     case 29: return launch2<128, 32, 4, 1, 3, TRANS>(a, batch_z, s);  // N <= 32 (4 <-> C boundary convs)
+    case 30: return launch2<256, 256, 2, 4, 2, TRANS>(a, batch_z, s);
+    case 31: return launch2<256, 128, 4, 2, 2, TRANS, true>(a, batch_z, s);
+    case 32: return launch2<128, 128, 2, 2, 2, TRANS, true>(a, batch_z, s);
+    case 33: return launch2<256, 128, 4, 2, 3, TRANS, true>(a, batch_z, s);
+    case 34: return launch2<256, 256, 2, 4, 2, TRANS, true>(a, batch_z, s);
+    case 35: return launch2<128, 64, 2, 2, 3, TRANS, true>(a, batch_z, s);
     default: MG_REQUIRE(false, "igemm: unknown v2 tile variant %d", variant);
   }
   return 0;
@@ -364,7 +392,7 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
 
 }  // namespace
 
-int mg_igemm_auto_variant(long long M, int N, int batch_z);
+int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu);
 
 // Generation-2 entry: returns -1 when the op needs the generation-1 kernel (unsupported shape).
 int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
@@ -414,12 +442,26 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   if (a.res && ((uintptr_t)a.res % 16 != 0)) return -1;
   int rc = 0;
   const int nmain = trans_from >= 0 ? trans_from : a.N;
+  const int K = a.taps * a.Cin;
   if (nmain > 0) {
     Igemm2Args m = a;
     m.N = nmain;
-    const int v = variant ? variant : mg_igemm_auto_variant(m.M, m.N, batch_z);
+    m.n_begin = 0;
+    m.n_end = nmain;
+    // N = 128 k + 64 (the 320-channel UNet level): a 128-wide tiling would waste 1/(2k+1) of the
+    // MFMA work on the ragged last tile -> run the last 64 columns as their own 64-wide launch.
+    const bool split = !variant && !geglu && nmain > 128 && nmain % 128 == 64 &&
+                       ((m.M + 255) / 256) * (nmain / 128) * batch_z >= 200;
+    if (split) m.n_end = nmain - 64;
+    const int v = variant ? variant : mg_igemm_auto_variant(m.M, m.n_end, K, batch_z, geglu);
     rc = dispatch_tile<false>(m, batch_z, v, s);
     if (rc) return rc;
+    if (split) {
+      m.n_begin = nmain - 64;
+      m.n_end = nmain;
+      rc = dispatch_tile<false>(m, batch_z, 25, s);
+      if (rc) return rc;
+    }
   }
   if (trans_from >= 0) {
     MG_REQUIRE(out2 && a.ldt > 0 && a.ldt % 8 == 0, "igemm: bad transposed section");
@@ -429,23 +471,28 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
     tns.Wt = a.Wt + (long long)trans_from * a.ldw;
     tns.bias = a.bias ? a.bias + trans_from : nullptr;
     tns.N = a.N - trans_from;
+    tns.n_begin = 0;
+    tns.n_end = tns.N;
     tns.ctr = a.N - trans_from;
     tns.rowvec = nullptr;
     tns.res = nullptr;
     tns.epi = MG_EPI_BF16;
-    const int v = variant ? variant : mg_igemm_auto_variant(tns.M, tns.N, batch_z);
+    const int v = variant ? variant : mg_igemm_auto_variant(tns.M, tns.N, K, batch_z, 0);
     rc = dispatch_tile<true>(tns, batch_z, v, s);
   }
   return rc;
 }
 
-// Tile choice.  256x128 (8 waves, 3-stage ring) whenever it fills the chip; smaller tiles for the
-// deep UNet levels where M is a few thousand pixels.
-int mg_igemm_auto_variant(long long M, int N, int batch_z) {
-  const long long t256 = ((M + 255) / 256) * ((N + 127) / 128) * batch_z;
-  const long long t128 = ((M + 127) / 128) * ((N + 127) / 128) * batch_z;
+// Tile choice, from the round-1 sweep on MI355X (profiles/r1_sweep_gemm_tiles_flash.log):
+//   * 256x128 / 8 waves / 2 LDS stages wins on the long-K convolutions (870-970 TFLOP/s);
+//   * 128x128 / 4 waves / 2 stages (two workgroups per CU) wins for K <= ~1.5k and the 128-channel
+//     768^2 VAE layers;
+//   * the deep UNet levels (M = a few thousand pixels) need small tiles to fill 256 CUs.
+int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
   if (N <= 32) return 29;
-  if (t256 >= 200) return 20;
-  if (t128 >= 160) return 27;
+  const long long t256 = ((M + 255) / 256) * ((N + 127) / 128) * batch_z;
+  const long long t128x64 = ((M + 127) / 128) * ((N + 63) / 64) * batch_z;
+  if (t256 >= 200) return (K <= 1536 && !geglu) ? 21 : 26;
+  if (t128x64 >= 128) return 25;
   return 23;
 }

@@ -1,6 +1,6 @@
 // GroupNorm (stats partials -> per-(image,channel) scale/shift -> apply [+SiLU]) and LayerNorm
 // on bf16 NHWC activations.  All HBM-bound streaming kernels: 16-byte (8 x bf16) accesses,
-// fp32 statistics, deterministic (no atomics to global memory).
+// fp32 statistics, bit-reproducible (no atomics anywhere).
 // Replaces torch group_norm / silu / layer_norm inside diffusers ResnetBlock2D,
 // Transformer2DModel and BasicTransformerBlock (reached from
 // marigold/marigold_depth_pipeline.py:461-463, 491-492, 512-513).
@@ -11,10 +11,13 @@ namespace {
 constexpr int GN_NV = 4;  // channel vectors per thread: supports C <= 256*8*GN_NV
 
 // grid (chunks, B); block 256.  partials[b][chunk][c][2] = (sum, sumsq) over the chunk's rows.
+// Threads are laid out txn (channel vectors) x tyn (row lanes); every thread keeps fp32 partials
+// of its rows in registers (4 rows in flight), then the row lanes are combined through LDS in a
+// FIXED order - bit-reproducible, no atomics.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x,
                                                        float* __restrict__ partials, int HW, int C,
                                                        int chunks) {
-  extern __shared__ float lds[];  // [C][2]
+  extern __shared__ float lds[];  // [tyn][C][2]
   const int cv = C >> 3;
   const int txn = cv < 256 ? cv : 256;
   const int tyn = 256 / txn;
@@ -23,46 +26,55 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   const int rpc = (HW + chunks - 1) / chunks;
   const int r0 = chunk * rpc;
   const int r1 = min(HW, r0 + rpc);
-  for (int i = threadIdx.x; i < 2 * C; i += 256) lds[i] = 0.f;
-  __syncthreads();
   float s[GN_NV][8], q[GN_NV][8];
 #pragma unroll
   for (int v = 0; v < GN_NV; ++v)
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[v][j] = q[v][j] = 0.f;
-  if (ty < tyn) {
+  const bool active = ty < tyn;
+  if (active) {
     const bf16_t* xb = x + (long long)b * HW * C;
-    for (int r = r0 + ty; r < r1; r += tyn) {
+    auto acc8 = [&](int v, const uint4& u) {
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-      for (int v = 0; v < GN_NV; ++v) {
-        const int vc = tx + v * txn;
-        if (vc < cv) {
-          const uint4 u = *(const uint4*)(xb + (long long)r * C + vc * 8);
-          const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float a = bflo(w[j]), c = bfhi(w[j]);
-            s[v][2 * j] += a; q[v][2 * j] += a * a;
-            s[v][2 * j + 1] += c; q[v][2 * j + 1] += c * c;
-          }
-        }
+      for (int j = 0; j < 4; ++j) {
+        const float a = bflo(w[j]), c = bfhi(w[j]);
+        s[v][2 * j] += a; q[v][2 * j] += a * a;
+        s[v][2 * j + 1] += c; q[v][2 * j + 1] += c * c;
       }
+    };
+#pragma unroll
+    for (int v = 0; v < GN_NV; ++v) {
+      const int vc = tx + v * txn;
+      if (vc >= cv) break;
+      const bf16_t* col = xb + vc * 8;
+      int r = r0 + ty;
+      for (; r + 3 * tyn < r1; r += 4 * tyn) {  // 4 independent 16-byte loads in flight
+        const uint4 u0 = *(const uint4*)(col + (long long)r * C);
+        const uint4 u1 = *(const uint4*)(col + (long long)(r + tyn) * C);
+        const uint4 u2 = *(const uint4*)(col + (long long)(r + 2 * tyn) * C);
+        const uint4 u3 = *(const uint4*)(col + (long long)(r + 3 * tyn) * C);
+        acc8(v, u0); acc8(v, u1); acc8(v, u2); acc8(v, u3);
+      }
+      for (; r < r1; r += tyn) acc8(v, *(const uint4*)(col + (long long)r * C));
     }
 #pragma unroll
     for (int v = 0; v < GN_NV; ++v) {
       const int vc = tx + v * txn;
       if (vc < cv) {
+        float* d = lds + ((long long)ty * C + vc * 8) * 2;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          atomicAdd(&lds[(vc * 8 + j) * 2], s[v][j]);
-          atomicAdd(&lds[(vc * 8 + j) * 2 + 1], q[v][j]);
-        }
+        for (int j = 0; j < 8; ++j) { d[2 * j] = s[v][j]; d[2 * j + 1] = q[v][j]; }
       }
     }
   }
   __syncthreads();
   float* out = partials + ((long long)b * chunks + chunk) * 2 * C;
-  for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = lds[i];
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float t = 0.f;
+    for (int y = 0; y < tyn; ++y) t += lds[(long long)y * 2 * C + i];
+    out[i] = t;
+  }
 }
 
 // one wave per (b, group); writes ss[b][0][c] = scale, ss[b][1][c] = shift
@@ -203,7 +215,8 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
       const int B = op->i[0], HW = op->i[1], C = op->i[2], chunks = op->i[3];
       MG_REQUIRE(C % 8 == 0 && C <= 256 * 8 * GN_NV, "gn_stats: unsupported C %d", C);
       MG_REQUIRE(B > 0 && HW > 0 && chunks > 0 && chunks <= HW, "gn_stats: bad dims");
-      MG_LAUNCH(gn_stats_kernel, dim3(chunks, B), dim3(256), 2 * C * sizeof(float), s,
+      const int cvv = C / 8, tynn = 256 / (cvv < 256 ? cvv : 256);
+      MG_LAUNCH(gn_stats_kernel, dim3(chunks, B), dim3(256), (size_t)tynn * 2 * C * sizeof(float), s,
                          (const bf16_t*)op->p[0], (float*)op->p[1], HW, C, chunks);
       break;
     }

@@ -164,8 +164,9 @@ class Builder:
     # ---- primitive layers ----------------------------------------------------------------
     def group_norm(self, x, name, eps, silu):
         C, B, HW = x.C, x.B, x.HW
-        # enough (chunk, image) blocks to cover the 256 CUs a few times over, >= 32 rows per chunk
-        chunks = max(1, min(HW // 32, max(64, 2048 // B)))
+        # ~768 (chunk, image) blocks: covers the 256 CUs three times over while keeping the
+        # second-level reduction (gn_finalize) short; >= 32 rows per chunk
+        chunks = max(1, min(HW // 32, max(16, 768 // B)))
         part = self.raw(B * chunks * C * 2 * 4)
         ss = self.raw(B * 2 * C * 4)
         out = self.new(x.B, x.H, x.W, C)

@@ -78,6 +78,14 @@ CONV_CASES = [
     ("g2_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 20),
     ("g2_up_to_size", 1, 4, 6, 64, 64, 1, 1, (7, 11), 23),
     ("g2_big_k", 1, 12, 12, 1280, 128, 1, 1, None, 20),
+    ("g2_256x256", 2, 16, 24, 128, 320, 1, 1, None, 30),
+    ("g2_split_256x128", 2, 16, 24, 128, 192, 1, 1, None, 31),
+    ("g2_split_128x128", 2, 12, 20, 320, 320, 1, 1, None, 32),
+    ("g2_split_3stage", 2, 16, 24, 128, 128, 2, 1, None, 33),
+    ("g2_split_256x256", 2, 16, 24, 192, 320, 1, 1, (32, 48), 34),
+    ("g2_split_128x64", 1, 9, 7, 128, 64, 1, 1, None, 35),
+    ("g2_auto_split_n320", 10, 72, 72, 64, 320, 1, 1, None, 0),   # 128k+64 columns: main + 64-wide tail launch
+    ("g2_auto_small_m", 2, 12, 12, 128, 640, 1, 1, None, 0),
 ]
 
 
@@ -120,7 +128,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = torch.randn(N, generator=g) * 0.1
     ref = x @ w.t() + b
-    for variant in (0, 1, 2, 3, 4, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28):
+    for variant in (0, 1, 2, 3, 4, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N,
                         bias=b.to(dev), variant=variant))
@@ -233,7 +241,7 @@ def test_flash_attn64(dev, B, heads, T):
     qkd = qkv.to(dev, torch.bfloat16)
     vt = torch.zeros(B, C, ldvt, device=dev, dtype=torch.bfloat16)
     vt[:, :, :T] = v.permute(0, 2, 1).to(dev, torch.bfloat16)
-    for variant in (0, 1):   # 0 = generation-2 kernel (default), 1 = generation 1
+    for variant in (0, 1, 2):   # 0 = generation 2 + split DMA issue (default), 1 = generation 1, 2 = gen 2 burst
         out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.flash_attn64(qkd, qkd[:, :, C:], vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C,
                               ldvt=ldvt, sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125,
@@ -254,7 +262,7 @@ def test_flash_attn64_spiky_scores(dev):
     ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
     qkv = torch.cat([q, k], dim=-1).to(dev, torch.bfloat16)
     vt = v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16)
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.flash_attn64(qkv, qkv[:, :, C:], vt, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T,
                               sq=0, sk=0, svt=0, so=0, scale=0.125, variant=variant))
