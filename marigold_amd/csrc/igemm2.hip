@@ -448,20 +448,9 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
     m.N = nmain;
     m.n_begin = 0;
     m.n_end = nmain;
-    // N = 128 k + 64 (the 320-channel UNet level): a 128-wide tiling would waste 1/(2k+1) of the
-    // MFMA work on the ragged last tile -> run the last 64 columns as their own 64-wide launch.
-    const bool split = !variant && !geglu && nmain > 128 && nmain % 128 == 64 &&
-                       ((m.M + 255) / 256) * (nmain / 128) * batch_z >= 200;
-    if (split) m.n_end = nmain - 64;
     const int v = variant ? variant : mg_igemm_auto_variant(m.M, m.n_end, K, batch_z, geglu);
     rc = dispatch_tile<false>(m, batch_z, v, s);
     if (rc) return rc;
-    if (split) {
-      m.n_begin = nmain - 64;
-      m.n_end = nmain;
-      rc = dispatch_tile<false>(m, batch_z, 25, s);
-      if (rc) return rc;
-    }
   }
   if (trans_from >= 0) {
     MG_REQUIRE(out2 && a.ldt > 0 && a.ldt % 8 == 0, "igemm: bad transposed section");
@@ -483,16 +472,25 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   return rc;
 }
 
-// Tile choice, from the round-1 sweep on MI355X (profiles/r1_sweep_gemm_tiles_flash.log):
-//   * 256x128 / 8 waves / 2 LDS stages wins on the long-K convolutions (870-970 TFLOP/s);
-//   * 128x128 / 4 waves / 2 stages (two workgroups per CU) wins for K <= ~1.5k and the 128-channel
-//     768^2 VAE layers;
-//   * the deep UNet levels (M = a few thousand pixels) need small tiles to fill 256 CUs.
+// Tile choice, from the round-1 sweeps on MI355X (profiles/r1_sweep*_*.log; TFLOP/s at E = 10):
+//   * 256x256 / 8 waves (wave tile 128x64) when N is a multiple of 256 and there are >= 512 tiles:
+//     VAE 512/256-channel layers 890-1080, GEGLU projections 440-750;
+//   * 128x64 / 4 waves / 3 stages for N = 128k+64 (the 320-channel UNet level: no ragged-tile waste,
+//     750-830) and for the deep levels where M is a few thousand pixels;
+//   * 256x128 / 8 waves / 3 stages for the long-K layers (870-1000), 128x128 / 4 waves / 2 stages
+//     (two workgroups per CU) when K <= 1536;
+//   all with the next tile's LDS-DMA pieces issued between the k-substeps' MFMA groups.
 int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
+  (void)geglu;
   if (N <= 32) return 29;
-  const long long t256 = ((M + 255) / 256) * ((N + 127) / 128) * batch_z;
+  const long long tm256 = (M + 255) / 256;
+  if (N % 256 == 0 && tm256 * (N / 256) * batch_z >= 512) return 34;
+  const long long t256 = tm256 * ((N + 127) / 128) * batch_z;
   const long long t128x64 = ((M + 127) / 128) * ((N + 63) / 64) * batch_z;
-  if (t256 >= 200) return (K <= 1536 && !geglu) ? 21 : 26;
-  if (t128x64 >= 128) return 25;
+  if (t256 >= 200) {
+    if (N % 128 == 64) return 35;
+    return K <= 1536 ? 32 : 33;
+  }
+  if (t128x64 >= 96) return 35;
   return 23;
 }
