@@ -1,0 +1,152 @@
+"""Multi-image inference CLI with the reference's flags and on-disk formats
+(script/depth/run.py:54-135 flags, :165-171 output folders, :270-292 files; script/normals/run.py is
+the same minus ``--color_map``):
+
+  depth   : <out>/depth_npy/<name>_depth.npy      float32 [H,W] in [0,1]
+            <out>/depth_bw/<name>_depth.png        16-bit PNG, value * 65535
+            <out>/depth_colored/<name>_depth_colored.png
+  normals : <out>/normals_npy/<name>_normals.npy  float32 [3,H,W] in [-1,1]
+            <out>/normals_vis/<name>_normals.png   (n + 1) * 127.5
+
+Differences: the engine only runs on an MI355X (there is no CPU / MPS path: ``--apple_silicon`` is
+accepted and refused), and ``--half_precision`` selects the ``fp16`` weight variant of the checkpoint
+like the reference while the arithmetic is the engine's bf16/fp32-accumulate either way.
+"""
+import argparse
+import logging
+import os
+from glob import glob
+
+import numpy as np
+from PIL import Image
+
+EXTENSION_LIST = (".jpg", ".jpeg", ".png")
+_DEFAULT_CKPT = {"depth": "prs-eth/marigold-depth-v1-1", "normals": "prs-eth/marigold-normals-v1-1"}
+_TITLE = {"depth": "Marigold : Monocular Depth Estimation : Multi-image Inference",
+          "normals": "Marigold : Surface Normals Estimation : Multi-image Inference"}
+
+
+def build_parser(kind: str) -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description=_TITLE[kind])
+    p.add_argument("--checkpoint", type=str, default=_DEFAULT_CKPT[kind], help="Checkpoint path or hub name.")
+    p.add_argument("--input_rgb_dir", type=str, required=True, help="Path to the input image folder.")
+    p.add_argument("--output_dir", type=str, required=True, help="Output directory.")
+    p.add_argument("--denoise_steps", type=int, default=None,
+                   help="Diffusion denoising steps; `None` reads the default from the checkpoint.")
+    p.add_argument("--processing_res", type=int, default=None,
+                   help="Resolution the input is resized to before estimation; 0 = native, None = checkpoint default.")
+    p.add_argument("--ensemble_size", type=int, default=1, help="Number of predictions to be ensembled.")
+    p.add_argument("--half_precision", "--fp16", action="store_true",
+                   help="Load the 16-bit weight variant of the checkpoint.")
+    p.add_argument("--output_processing_res", action="store_true",
+                   help="Output at the processing resolution instead of resizing back to the input resolution.")
+    p.add_argument("--resample_method", choices=["bilinear", "bicubic", "nearest"], default="bilinear")
+    if kind == "depth":
+        p.add_argument("--color_map", type=str, default="Spectral", help="Colormap of the depth visualisation.")
+    p.add_argument("--seed", type=int, default=None, help="Reproducibility seed; None = randomised inference.")
+    p.add_argument("--batch_size", type=int, default=0, help="Inference batch size; 0 = automatic.")
+    p.add_argument("--apple_silicon", action="store_true", help="(reference flag; not available on this engine)")
+    return p
+
+
+def list_images(folder):
+    files = sorted(f for f in glob(os.path.join(folder, "*")) if os.path.splitext(f)[1].lower() in EXTENSION_LIST)
+    return files
+
+
+def output_dirs(kind, output_dir):
+    sub = ("depth_colored", "depth_bw", "depth_npy") if kind == "depth" else ("normals_vis", "normals_npy")
+    dirs = {s: os.path.join(output_dir, s) for s in sub}
+    for d in (output_dir, *dirs.values()):
+        os.makedirs(d, exist_ok=True)
+    return dirs
+
+
+def _save(path, writer):
+    if os.path.exists(path):
+        logging.warning(f"Existing file: '{path}' will be overwritten")
+    writer(path)
+
+
+def save_prediction(kind, dirs, rgb_path, out):
+    """Write one prediction in the reference's formats; returns the written paths."""
+    base = os.path.splitext(os.path.basename(rgb_path))[0]
+    written = []
+    if kind == "depth":
+        name = base + "_depth"
+        depth = out.depth_np
+        p = os.path.join(dirs["depth_npy"], f"{name}.npy")
+        _save(p, lambda q: np.save(q, depth))
+        written.append(p)
+        p = os.path.join(dirs["depth_bw"], f"{name}.png")
+        _save(p, lambda q: Image.fromarray((depth * 65535.0).astype(np.uint16)).save(q, mode="I;16"))
+        written.append(p)
+        if out.depth_colored is not None:
+            p = os.path.join(dirs["depth_colored"], f"{name}_colored.png")
+            _save(p, out.depth_colored.save)
+            written.append(p)
+    else:
+        name = base + "_normals"
+        p = os.path.join(dirs["normals_npy"], f"{name}.npy")
+        _save(p, lambda q: np.save(q, out.normals_np))
+        written.append(p)
+        p = os.path.join(dirs["normals_vis"], f"{name}.png")
+        _save(p, out.normals_img.save)
+        written.append(p)
+    return written
+
+
+def main(kind: str, argv=None, pipeline=None) -> int:
+    """``pipeline`` lets tests inject a ready pipeline object; otherwise the checkpoint is loaded."""
+    import torch
+    logging.basicConfig(level=logging.INFO)
+    args = build_parser(kind).parse_args(argv)
+    if args.ensemble_size > 15:
+        logging.warning("Running with large ensemble size will be slow.")
+    match_input_res = not args.output_processing_res
+    if 0 == args.processing_res and match_input_res is False:
+        logging.warning("Processing at native resolution without resizing output might NOT lead to exactly the "
+                        "same resolution, due to the padding and pooling properties of conv layers.")
+    if args.apple_silicon:
+        raise RuntimeError("--apple_silicon: this engine runs on an AMD MI355X only")
+    dirs = output_dirs(kind, args.output_dir)
+    logging.info(f"output dir = {args.output_dir}")
+    files = list_images(args.input_rgb_dir)
+    if not files:
+        logging.error(f"No image found in '{args.input_rgb_dir}'")
+        return 1
+    logging.info(f"Found {len(files)} images")
+    if pipeline is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("no MI355X visible: the Marigold HIP engine has no CPU fallback")
+        import marigold_amd as M
+        cls = M.MarigoldDepthPipeline if kind == "depth" else M.MarigoldNormalsPipeline
+        pipeline = cls.from_pretrained(args.checkpoint, variant="fp16" if args.half_precision else None,
+                                       torch_dtype=torch.float16 if args.half_precision else torch.float32)
+        pipeline.enable_xformers_memory_efficient_attention()   # no-op: attention is always the fused kernel
+        pipeline = pipeline.to("cuda")
+    if kind == "depth":
+        logging.info(f"Loaded depth pipeline: scale_invariant={pipeline.scale_invariant}, "
+                     f"shift_invariant={pipeline.shift_invariant}")
+    else:
+        logging.info("Loaded normals pipeline")
+    logging.info(f"Inference settings: checkpoint = `{args.checkpoint}`, with denoise_steps = "
+                 f"{args.denoise_steps or pipeline.default_denoising_steps}, ensemble_size = {args.ensemble_size}, "
+                 f"processing resolution = {args.processing_res or pipeline.default_processing_resolution}, "
+                 f"seed = {args.seed}" + (f"; color_map = {args.color_map}." if kind == "depth" else ""))
+    device = getattr(pipeline, "device", "cpu")
+    for rgb_path in files:
+        image = Image.open(rgb_path)
+        generator = None
+        if args.seed is not None:
+            generator = torch.Generator(device=device)
+            generator.manual_seed(args.seed)
+        kw = dict(denoising_steps=args.denoise_steps, ensemble_size=args.ensemble_size,
+                  processing_res=args.processing_res, match_input_res=match_input_res,
+                  batch_size=args.batch_size, show_progress_bar=True, resample_method=args.resample_method,
+                  generator=generator)
+        if kind == "depth":
+            kw["color_map"] = args.color_map
+        out = pipeline(image, **kw)
+        save_prediction(kind, dirs, rgb_path, out)
+    return 0

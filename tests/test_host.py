@@ -321,3 +321,55 @@ def test_depth_alignment_gradient_and_fd_survival(golden_dir):
         assert abs(fd - g[k]) < 2e-3 * max(1.0, abs(g[k])), (k, fd, g[k])
     k = ens.fd_survival(np.array([1.25, 3.0, 0.2, 0.01, -0.01, 0.0]))
     assert k[0] == 0 and k[1] == 0 and abs(k[2] - 1) < 1e-6 and abs(k[3] - 1) < 0.07 and abs(k[5] - 1) < 1e-6
+
+
+def test_cli_flags_and_output_formats(tmp_path):
+    """script/{depth,normals}/run.py: the reference's flags, folders, file names and encodings
+    (script/depth/run.py:54-135, 165-171, 270-292), driven with a stand-in pipeline object."""
+    from PIL import Image
+    from marigold_amd import cli
+    from marigold_amd.pipeline import MarigoldDepthOutput, MarigoldNormalsOutput
+    a = cli.build_parser("depth").parse_args(["--input_rgb_dir", "i", "--output_dir", "o", "--fp16", "--seed", "3"])
+    assert a.checkpoint == "prs-eth/marigold-depth-v1-1" and a.half_precision and a.ensemble_size == 1
+    assert a.color_map == "Spectral" and a.resample_method == "bilinear" and a.batch_size == 0
+    assert not hasattr(cli.build_parser("normals").parse_args(["--input_rgb_dir", "i", "--output_dir", "o"]), "color_map")
+    inp = tmp_path / "in"
+    inp.mkdir()
+    Image.fromarray(np.zeros((6, 8, 3), np.uint8)).save(inp / "b.png")
+    Image.fromarray(np.zeros((6, 8, 3), np.uint8)).save(inp / "a.JPG")
+    (inp / "notes.txt").write_text("x")
+    calls = []
+
+    class FakeDepth:
+        scale_invariant = shift_invariant = True
+        default_denoising_steps, default_processing_resolution = 4, 768
+
+        def __call__(self, image, **kw):
+            calls.append(kw)
+            d = np.linspace(0, 1, 48, dtype=np.float32).reshape(6, 8)
+            return MarigoldDepthOutput(d, Image.fromarray(np.zeros((6, 8, 3), np.uint8)), None)
+
+    out = tmp_path / "out"
+    assert cli.main("depth", ["--input_rgb_dir", str(inp), "--output_dir", str(out), "--ensemble_size", "2",
+                              "--output_processing_res"], pipeline=FakeDepth()) == 0
+    assert len(calls) == 2 and calls[0]["ensemble_size"] == 2 and calls[0]["match_input_res"] is False
+    assert calls[0]["color_map"] == "Spectral" and calls[0]["generator"] is None
+    assert np.load(out / "depth_npy" / "a_depth.npy").dtype == np.float32
+    bw = np.array(Image.open(out / "depth_bw" / "b_depth.png"))
+    assert bw.dtype == np.uint16 and bw.max() == 65535 and bw.min() == 0
+    assert (out / "depth_colored" / "a_depth_colored.png").exists()
+
+    class FakeNormals:
+        default_denoising_steps, default_processing_resolution = 4, 768
+
+        def __call__(self, image, **kw):
+            assert "color_map" not in kw
+            n = np.zeros((3, 6, 8), np.float32)
+            n[2] = 1
+            return MarigoldNormalsOutput(n, Image.fromarray(np.zeros((6, 8, 3), np.uint8)), None)
+
+    assert cli.main("normals", ["--input_rgb_dir", str(inp), "--output_dir", str(out)], pipeline=FakeNormals()) == 0
+    assert np.load(out / "normals_npy" / "b_normals.npy").shape == (3, 6, 8)
+    assert (out / "normals_vis" / "a_normals.png").exists()
+    assert cli.main("depth", ["--input_rgb_dir", str(tmp_path / "out"), "--output_dir", str(out)],
+                    pipeline=FakeDepth()) == 1   # no images -> exit code 1 like the reference
