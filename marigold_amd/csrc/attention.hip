@@ -208,16 +208,24 @@ constexpr int FA2_NSTAGE = 3;
 
 // SPLIT: the four LDS-DMA pieces of tile kt+2 are issued behind the two QK^T MFMA groups instead
 // of in one burst after the barrier (their issue cost then overlaps the wave's own MFMAs).
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
+// NW: waves (x 32 queries) per workgroup.  PV: how P reaches the PV MFMA - 0: straight from the
+// QK^T register layout, V^T read as two ds_read_b64 per fragment (2-way LDS bank conflicts);
+// 1 / 2: P regrouped across lane^32 (ds_bpermute / v_permlane32_swap) so a lane holds 8 consecutive
+// keys and V^T is read with one conflict-free ds_read_b128 per fragment.
+template <bool SPLIT, int NW, int PV>
+__global__ __launch_bounds__(NW * 64) void flash_attn64_v2_kernel(const FaArgs a) {
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int ITS = 512 / NT;   // 16-byte staging chunks per thread per K (and per V^T) tile
   __shared__ __attribute__((aligned(16))) char smem[FA2_NSTAGE * FA_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int qb = bid % a.nqb;
-  const int bh = bid / a.nqb;
+  const int nqb = (a.Ntok + QB - 1) / QB;
+  const int qb = bid % nqb;
+  const int bh = bid / nqb;
   const int h = bh % a.heads, b = bh / a.heads;
 
   const bf16_t* Qb = a.Q + (long long)b * a.sQ + h * 64;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
   const bf16_t* Vb = a.Vt + (long long)b * a.sVt + (long long)h * 64 * a.ldvt;
   const char* zero = (const char*)a.zero;
 
-  const int q_row = qb * FA_QB + wave * 32 + l31;
+  const int q_row = qb * QB + wave * 32 + l31;
   const int q_ld = q_row < a.Ntok ? q_row : a.Ntok - 1;
   bf16x8 qf[4];
 #pragma unroll
@@ -233,12 +241,12 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
     qf[ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(Qb + (long long)q_ld * a.ldq + ks * 16 + half * 8));
 
   // per-thread staging sources (2 chunks of K, 2 of V^T per tile), advanced by one tile per issue
-  const char* k_src[2];
-  const char* v_src[2];
-  int k_row[2];
+  const char* k_src[ITS];
+  const char* v_src[ITS];
+  int k_row[ITS];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int ci = it * 256 + tid;
+  for (int it = 0; it < ITS; ++it) {
+    const int ci = it * NT + tid;
     const int r = ci >> 3;
     const int q = (ci & 7) ^ ((r >> 1) & 7);
     k_row[it] = r;
@@ -250,17 +258,17 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
   auto issue_k = [&](int stage) {
     char* sb = smem + stage * FA_STAGE;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < ITS; ++it) {
       const char* src = (i_k0 + k_row[it] < a.Ntok) ? k_src[it] : zero;
-      glds16(src, sb + (it * 256 + wave * 64) * 16);
+      glds16(src, sb + (it * NT + wave * 64) * 16);
       k_src[it] += k_step;
     }
   };
   auto issue_v = [&](int stage) {
     char* sb = smem + stage * FA_STAGE;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      glds16(v_src[it], sb + FA_KB * 128 + (it * 256 + wave * 64) * 16);
+    for (int it = 0; it < ITS; ++it) {
+      glds16(v_src[it], sb + FA_KB * 128 + (it * NT + wave * 64) * 16);
       v_src[it] += FA_KB * 2;
     }
     i_k0 += FA_KB;
@@ -280,8 +288,12 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
   if (nkt > 1) issue(1);
   int st_c = 0, st_i = 2;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kt + 1 < nkt) {
+      if constexpr (ITS == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     const bool do_issue = kt + 2 < nkt;
     if constexpr (!SPLIT) {
@@ -327,7 +339,11 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t2][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    {
+      float m0, m1;  // own and partner (lane^32) maxima, in some order
+      half_swap(mx, mx, m0, m1);
+      mx = fmaxf(m0, m1);
+    }
     if (__any(mx > m_run)) {  // some lane's running max moves: rescale O and l (alpha = 1 elsewhere)
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
@@ -355,21 +371,46 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
     for (int t2 = 0; t2 < 2; ++t2) {
 #pragma unroll
       for (int sh = 0; sh < 2; ++sh) {
-        uint4 pw;
-        pw.x = fa_cvt_pk(s[t2][8 * sh + 0], s[t2][8 * sh + 1]);
-        pw.y = fa_cvt_pk(s[t2][8 * sh + 2], s[t2][8 * sh + 3]);
-        pw.z = fa_cvt_pk(s[t2][8 * sh + 4], s[t2][8 * sh + 5]);
-        pw.w = fa_cvt_pk(s[t2][8 * sh + 6], s[t2][8 * sh + 7]);
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-        const int c0 = 4 * t2 + 2 * sh;
+        bf16x8 pf;
+        if constexpr (PV == 0) {
+          uint4 pw;
+          pw.x = fa_cvt_pk(s[t2][8 * sh + 0], s[t2][8 * sh + 1]);
+          pw.y = fa_cvt_pk(s[t2][8 * sh + 2], s[t2][8 * sh + 3]);
+          pw.z = fa_cvt_pk(s[t2][8 * sh + 4], s[t2][8 * sh + 5]);
+          pw.w = fa_cvt_pk(s[t2][8 * sh + 6], s[t2][8 * sh + 7]);
+          pf = __builtin_bit_cast(bf16x8, pw);
+        } else {
+          // packed pieces: a = keys 8*(2sh)+4h+{0..3}, b = keys 8*(2sh+1)+4h+{0..3} of this lane
+          const uint32_t a0 = fa_cvt_pk(s[t2][8 * sh + 0], s[t2][8 * sh + 1]);
+          const uint32_t a1 = fa_cvt_pk(s[t2][8 * sh + 2], s[t2][8 * sh + 3]);
+          const uint32_t b0 = fa_cvt_pk(s[t2][8 * sh + 4], s[t2][8 * sh + 5]);
+          const uint32_t b1 = fa_cvt_pk(s[t2][8 * sh + 6], s[t2][8 * sh + 7]);
+          uint4 pw;  // 8 consecutive keys 32*t2 + 16*sh + 8*half + [0,8)
+          if constexpr (PV == 2) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            pw.x = r0[0]; pw.y = r1[0]; pw.z = r0[1]; pw.w = r1[1];
+          } else {
+            const uint32_t v0 = __shfl_xor(half ? a0 : b0, 32), v1 = __shfl_xor(half ? a1 : b1, 32);
+            pw.x = half ? v0 : a0; pw.y = half ? v1 : a1;
+            pw.z = half ? b0 : v0; pw.w = half ? b1 : v1;
+          }
+          pf = __builtin_bit_cast(bf16x8, pw);
+        }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const int row = dt * 32 + l31;
           const int sw = (row >> 1) & 7;
-          const uint2 v0 = *(const uint2*)(sV + row * 128 + ((c0 ^ sw) << 4) + 8 * half);
-          const uint2 v1 = *(const uint2*)(sV + row * 128 + (((c0 + 1) ^ sw) << 4) + 8 * half);
           uint4 vw;
-          vw.x = v0.x; vw.y = v0.y; vw.z = v1.x; vw.w = v1.y;
+          if constexpr (PV == 0) {
+            const int c0 = 4 * t2 + 2 * sh;
+            const uint2 v0 = *(const uint2*)(sV + row * 128 + ((c0 ^ sw) << 4) + 8 * half);
+            const uint2 v1 = *(const uint2*)(sV + row * 128 + (((c0 + 1) ^ sw) << 4) + 8 * half);
+            vw.x = v0.x; vw.y = v0.y; vw.z = v1.x; vw.w = v1.y;
+          } else {
+            const int c0 = 4 * t2 + 2 * sh + half;
+            vw = *(const uint4*)(sV + row * 128 + ((c0 ^ sw) << 4));
+          }
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
         }
       }
@@ -378,7 +419,9 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
     st_i = (st_i + 1 == FA2_NSTAGE) ? 0 : st_i + 1;
   }
   // ---- finalize: O[q][d] = o^T / l; lane^32 exchange -> 8 consecutive d per lane, 16-byte stores ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  float l0, l1;
+  half_swap(l_run, l_run, l0, l1);
+  const float l_tot = l0 + l1;
   const float inv = 1.0f / l_tot;
   bf16_t* orow = a.O + (long long)b * a.sO + (long long)q_row * a.ldo + h * 64;
 #pragma unroll
@@ -388,10 +431,7 @@ __global__ __launch_bounds__(256) void flash_attn64_v2_kernel(const FaArgs a) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float g0 = o[dt][8 * gp + j] * inv, g1 = o[dt][8 * gp + 4 + j] * inv;
-        const float recv = __shfl_xor(half ? g0 : g1, 32);
-        v[j] = half ? recv : g0;
-        v[4 + j] = half ? g1 : recv;
+        half_swap(o[dt][8 * gp + j] * inv, o[dt][8 * gp + 4 + j] * inv, v[j], v[4 + j]);
       }
       if (q_row < a.Ntok) {
         uint4 pk;
@@ -499,12 +539,25 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       MG_REQUIRE(a.ldvt % 64 == 0 && a.ldvt >= a.Ntok, "flash_attn64: ldvt must be a multiple of 64 >= Ntok");
       MG_REQUIRE(a.ldq % 8 == 0 && a.ldo % 4 == 0, "flash_attn64: bad leading dims");
       const long long grid = (long long)a.nqb * a.heads * a.B;
-      // i[6]: 0 = generation 2 with split DMA issue (needs 16-byte aligned O rows), 1 = generation 1,
-      // 2 = generation 2 with burst issue
+      // i[6]: 0 = default; 1 = generation 1; 2.. = generation-2 variants kept for the tuning sweep
       const bool v2ok = (a.ldo % 8 == 0) && ((uintptr_t)a.O % 16 == 0) && (a.sO % 8 == 0);
-      if (op->i[6] == 1 || !v2ok) MG_LAUNCH(flash_attn64_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
-      else if (op->i[6] == 2) MG_LAUNCH(flash_attn64_v2_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
-      else MG_LAUNCH(flash_attn64_v2_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);
+      const int var = v2ok ? op->i[6] : 1;
+      const long long g4 = (long long)((a.Ntok + 127) / 128) * a.heads * a.B;
+      const long long g8 = (long long)((a.Ntok + 255) / 256) * a.heads * a.B;
+      switch (var) {
+        case 1: MG_LAUNCH(flash_attn64_kernel, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+        case 2: MG_LAUNCH((flash_attn64_v2_kernel<false, 4, 0>), dim3((unsigned)g4), dim3(256), 0, s, a); break;
+        case 3: MG_LAUNCH((flash_attn64_v2_kernel<true, 8, 0>), dim3((unsigned)g8), dim3(512), 0, s, a); break;
+        case 4: MG_LAUNCH((flash_attn64_v2_kernel<true, 4, 1>), dim3((unsigned)g4), dim3(256), 0, s, a); break;
+        case 5: MG_LAUNCH((flash_attn64_v2_kernel<true, 4, 2>), dim3((unsigned)g4), dim3(256), 0, s, a); break;
+        case 6: MG_LAUNCH((flash_attn64_v2_kernel<true, 8, 2>), dim3((unsigned)g8), dim3(512), 0, s, a); break;
+        case 7: MG_LAUNCH((flash_attn64_v2_kernel<true, 8, 1>), dim3((unsigned)g8), dim3(512), 0, s, a); break;
+        case 8: MG_LAUNCH((flash_attn64_v2_kernel<true, 4, 0>), dim3((unsigned)g4), dim3(256), 0, s, a); break;
+        default:  // sweep (profiles/r1_sweep3_flash.log): 8 waves pay off from a few thousand keys on
+          if (a.Ntok >= 2048) MG_LAUNCH((flash_attn64_v2_kernel<true, 8, 2>), dim3((unsigned)g8), dim3(512), 0, s, a);
+          else MG_LAUNCH((flash_attn64_v2_kernel<true, 4, 2>), dim3((unsigned)g4), dim3(256), 0, s, a);
+          break;
+      }
       break;
     }
     case MG_OP_SOFTMAX_ROWS: {

@@ -43,6 +43,16 @@ __device__ __forceinline__ float gelu_erf_f(float x) {  // exact-erf GELU (diffu
   return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752f));
 }
 
+// lane^32 regroup used by the MFMA epilogues: every lane holds two values g0, g1 (accumulator
+// groups g and g+1 of its 32-lane half); afterwards `lo` = what the lower-half lane of the pair owns
+// first, i.e. for lanes 0-31: (own g0, partner's g0), for lanes 32-63: (partner's g1, own g1).
+// One v_permlane32_swap_b32 (VALU, no LDS traffic).
+__device__ __forceinline__ void half_swap(float g0, float g1, float& first, float& second) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(g0), __float_as_uint(g1), false, false);
+  first = __uint_as_float(r[0]);
+  second = __uint_as_float(r[1]);
+}
+
 // 16-byte async global -> LDS copy.  LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0,

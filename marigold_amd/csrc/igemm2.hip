@@ -53,7 +53,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // fragment reads and their MFMAs instead of in one burst after the barrier, so the ~60-100 issue
 // cycles each piece costs overlap the wave's own MFMAs (all waves of a workgroup leave the barrier
 // together - a burst leaves every SIMD's matrix pipe idle at the same time).
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, bool PF>
 __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args a) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
@@ -184,10 +184,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
     }
     const char* sA = smem + st_c * STAGE;
     const char* sB = sA + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    auto load_frags = [&](int ks, bf16x8(&fa)[MI], bf16x8(&fb)[NI]) {
       const int q = ks * 2 + half;
-      bf16x8 fa[MI], fb[NI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int r = rowA[mi];
@@ -198,12 +196,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
         const int r = rowB[ni];
         fb[ni] = __builtin_bit_cast(bf16x8, *(const uint4*)(sB + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)));
       }
-      if constexpr (SPLIT) {
-        if (do_issue) {
-#pragma unroll
-          for (int idx = ks; idx < LOADS; idx += 4) issue_piece(st_i, idx);
-        }
-      }
+    };
+    auto mfmas = [&](const bf16x8(&fa)[MI], const bf16x8(&fb)[NI]) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -213,6 +207,39 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
           else
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[ni][mi], 0, 0, 0);
         }
+    };
+    auto issue_part = [&](int ks) {
+      if constexpr (SPLIT) {
+        if (do_issue) {
+#pragma unroll
+          for (int idx = ks; idx < LOADS; idx += 4) issue_piece(st_i, idx);
+        }
+      }
+    };
+    if constexpr (PF) {
+      // fragment registers double-buffered: the reads of k-substep ks+1 are in flight while the
+      // MFMAs of ks run (two MFMA groups of cover instead of one)
+      bf16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+      load_frags(0, fa0, fb0);
+      load_frags(1, fa1, fb1);
+      issue_part(0);
+      mfmas(fa0, fb0);
+      load_frags(2, fa0, fb0);
+      issue_part(1);
+      mfmas(fa1, fb1);
+      load_frags(3, fa1, fb1);
+      issue_part(2);
+      mfmas(fa0, fb0);
+      issue_part(3);
+      mfmas(fa1, fb1);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 fa[MI], fb[NI];
+        load_frags(ks, fa, fb);
+        issue_part(ks);
+        mfmas(fa, fb);
+      }
     }
     if constexpr (SPLIT) {
       if (do_issue) advance();
@@ -247,9 +274,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
             }
             const float o0 = u0 * gelu_erf_f(t0);  // channel 16i + 4h + j
             const float o1 = u1 * gelu_erf_f(t1);  // channel 16i + 8 + 4h + j
-            const float recv = __shfl_xor(half ? o0 : o1, 32);
-            r[j] = half ? recv : o0;
-            r[4 + j] = half ? o1 : recv;
+            half_swap(o0, o1, r[j], r[4 + j]);
           }
           if (m < a.M && nok) {
             const int oc = (nb >> 1) + 8 * half;  // 16 output channels per 32 weight rows
@@ -275,10 +300,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float g0 = acc[ni][mi][8 * gp + j], g1 = acc[ni][mi][8 * gp + 4 + j];
-          const float recv = __shfl_xor(half ? g0 : g1, 32);
-          v[j] = half ? recv : g0;
-          v[4 + j] = half ? g1 : recv;
+          half_swap(acc[ni][mi][8 * gp + j], acc[ni][mi][8 * gp + 4 + j], v[j], v[4 + j]);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= scale;
@@ -345,13 +367,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT = false>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT = false, bool PF = false>
 int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int LDS = NSTAGE * (BM + BN) * 128;
   static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
   static bool attr_set = false;
-  auto kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS, SPLIT>;
+  auto kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS, SPLIT, PF>;
   if (!attr_set && !g_dry_run) {
     MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -385,6 +407,10 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
     case 33: return launch2<256, 128, 4, 2, 3, TRANS, true>(a, batch_z, s);
     case 34: return launch2<256, 256, 2, 4, 2, TRANS, true>(a, batch_z, s);
     case 35: return launch2<128, 64, 2, 2, 3, TRANS, true>(a, batch_z, s);
+    case 36: return launch2<256, 128, 4, 2, 3, TRANS, true, true>(a, batch_z, s);
+    case 37: return launch2<128, 64, 2, 2, 3, TRANS, true, true>(a, batch_z, s);
+    case 38: return launch2<256, 256, 2, 4, 2, TRANS, true, true>(a, batch_z, s);
+    case 39: return launch2<128, 128, 2, 2, 2, TRANS, true, true>(a, batch_z, s);
     default: MG_REQUIRE(false, "igemm: unknown v2 tile variant %d", variant);
   }
   return 0;

@@ -128,7 +128,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = torch.randn(N, generator=g) * 0.1
     ref = x @ w.t() + b
-    for variant in (0, 1, 2, 3, 4, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35):
+    for variant in (0, 1, 2, 3, 4, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N,
                         bias=b.to(dev), variant=variant))
@@ -241,7 +241,7 @@ def test_flash_attn64(dev, B, heads, T):
     qkd = qkv.to(dev, torch.bfloat16)
     vt = torch.zeros(B, C, ldvt, device=dev, dtype=torch.bfloat16)
     vt[:, :, :T] = v.permute(0, 2, 1).to(dev, torch.bfloat16)
-    for variant in (0, 1, 2):   # 0 = generation 2 + split DMA issue (default), 1 = generation 1, 2 = gen 2 burst
+    for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):   # 0 = default; 1 = generation 1; 2.. = generation-2 variants
         out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.flash_attn64(qkd, qkd[:, :, C:], vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C,
                               ldvt=ldvt, sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125,
@@ -262,7 +262,7 @@ def test_flash_attn64_spiky_scores(dev):
     ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
     qkv = torch.cat([q, k], dim=-1).to(dev, torch.bfloat16)
     vt = v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16)
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3, 4, 5, 6, 7):
         out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.flash_attn64(qkv, qkv[:, :, C:], vt, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T,
                               sq=0, sk=0, svt=0, so=0, scale=0.125, variant=variant))

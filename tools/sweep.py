@@ -44,7 +44,7 @@ def conv_case(name, B, HW, Cin, N, taps, geglu=False, res=True):
     flops = 2.0 * M * N * K
     rows = {}
     ref = None
-    for v in (0, 21, 26, 30, 31, 32, 33, 34, 25, 35):
+    for v in (0, 33, 34, 35):
         op = O.igemm(x, w, out, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, N=N, taps=taps, stride=1,
                      pad=1 if taps == 9 else 0, bias=bias, residual=r, epi=L.EPI_GEGLU if geglu else L.EPI_BF16,
                      variant=v)
@@ -77,7 +77,7 @@ def flash_case(B, heads, T):
     flops = 4.0 * B * heads * T * T * 64
     res = {}
     ref = None
-    for v in (1, 2, 0):
+    for v in (1, 2, 0, 3, 4, 5, 6, 7):
         op = O.flash_attn64(qkv, qkv.data_ptr() + C * 2, vt, out, B=B, heads=heads, Ntok=T, ldq=2 * C, ldo=C,
                             ldvt=ldvt, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v)
         ms = timeit(lambda: O.launch(op), iters=4)
@@ -85,10 +85,11 @@ def flash_case(B, heads, T):
         if ref is None:
             ref = o.clone()
         res[v] = (ms, flops / ms / 1e9, float((o - ref).abs().max()))
-    print(f"flash B={B} heads={heads} T={T}: gen1 {res[1][1]:.0f} TF/s ({res[1][0]:.3f} ms)  gen2-burst {res[2][1]:.0f}  "
-          f"gen2-split {res[0][1]:.0f} TF/s ({res[0][0]:.3f} ms)  max|gen2-gen1| {res[0][2]:.3g}")
-    return {"B": B, "heads": heads, "T": T, "gen1_tflops": res[1][1], "gen2_burst_tflops": res[2][1],
-            "gen2_tflops": res[0][1]}
+    names = {1: "gen1", 2: "burst", 0: "split(default)", 3: "8w", 4: "b128/shfl", 5: "b128/permlane", 6: "8w+permlane",
+             7: "8w+shfl"}
+    print(f"flash B={B} heads={heads} T={T}: " + "  ".join(f"{names[v]} {res[v][1]:.0f}" for v in res)
+          + "  | max diff vs gen1: " + " ".join(f"{res[v][2]:.2g}" for v in res))
+    return {"B": B, "heads": heads, "T": T, "tflops": {names[v]: res[v][1] for v in res}}
 
 
 def main():
