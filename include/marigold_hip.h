@@ -41,7 +41,7 @@ enum mg_op_kind {
    *  i[15] batch_z  i[16] ldr  i[17] lda  i[18] ldt  i[19] tile variant (0 = auto; 1..13 force a
  *  generation-1 tile, 20..28 a generation-2 tile - used by the tuning sweep)  i[20] ldw
    *  i[21] rowvec broadcast (1 = a single [N] row shared by every image)
- *  i[22] un-padded N for FLOP accounting (0 = N; ignored by the kernel)
+ *  i[22], i[23] un-padded N, K for FLOP accounting (0 = as launched; ignored by the kernel)
    *  l[0..3] z-strides (elements) of A, Wt, out, residual      f[0] scale on the accumulator */
   MG_OP_IGEMM = 1,
   /* GroupNorm, 3 launches (stats partials -> per-(b,c) scale/shift -> apply [+SiLU]).
@@ -107,6 +107,13 @@ enum mg_op_kind {
    * out NCHW = post(in[m][0..Cout) * f[0]) with the MG_POST_* tails of MG_OP_CONV_COUT_SMALL.
    *  p[0] in f32 [B*HW][ldi]  p[1] out f32 NCHW ; i: B, HW, Cout, ldi, post ; f[0] scale */
   MG_OP_POST_NCHW = 15,
+  /* im2col of a 3x3 / pad 1 neighbourhood for the <= 8-channel convolutions at the latent / image
+   * boundary (conv_in of the UNet incl. the torch.cat of marigold_depth_pipeline.py:456-458, of the
+   * VAE encoder and decoder): fp32 NCHW (two sources) -> bf16 [B*H*W][Kp], k = tap*(C0+C1) + c,
+   * columns >= 9*(C0+C1) zero.  The convolution itself is then an MG_OP_IGEMM with K = Kp.
+   *  p[0] src0 f32 [B|1][C0][H][W]  p[1] src1 f32 [B][C1][H][W] | NULL  p[2] out bf16 [B*H*W][Kp];
+   *  i: B,H,W,C0,C1,Kp, src0_broadcast */
+  MG_OP_IM2COL_SMALL = 16,
   /* Test-time ensembling (marigold/util/ensemble.py).
    * DEPTH_STATS : one pass over [E][HW]: per-member min,max,mean and the centred E x E
    *               second-moment matrix (closed form of the pairwise-RMSE cost, :138-145).

@@ -183,6 +183,44 @@ __global__ __launch_bounds__(256) void latent_1x1_kernel(const float* __restrict
   }
 }
 
+// one thread per output pixel: gather the 3x3 x CIN fp32 neighbourhood, round to bf16, write the
+// Kp-wide row with 16-byte stores (reads are coalesced along W, writes are whole rows)
+template <int CIN, int KP>
+__global__ __launch_bounds__(256) void im2col_small_kernel(const float* __restrict__ src0,
+                                                           const float* __restrict__ src1,
+                                                           bf16_t* __restrict__ out, int B, int H, int W,
+                                                           int C0, int bcast0) {
+  const long long hw = (long long)H * W;
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= (long long)B * hw) return;
+  const int b = (int)(pix / hw);
+  const int rem = (int)(pix % hw);
+  const int y = rem / W, x = rem % W;
+  float v[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) v[k] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      if (ok) {
+        v[t * CIN + c] = c < C0 ? src0[((long long)(bcast0 ? 0 : b) * C0 + c) * hw + (long long)iy * W + ix]
+                                : src1[((long long)b * (CIN - C0) + (c - C0)) * hw + (long long)iy * W + ix];
+      }
+    }
+  }
+  uint4* o = (uint4*)(out + pix * KP);
+#pragma unroll
+  for (int k = 0; k < KP; k += 8) {
+    uint4 pk;
+    pk.x = pack2bf(v[k], v[k + 1]); pk.y = pack2bf(v[k + 2], v[k + 3]);
+    pk.z = pack2bf(v[k + 4], v[k + 5]); pk.w = pack2bf(v[k + 6], v[k + 7]);
+    o[k >> 3] = pk;
+  }
+}
+
 template <int COUT>
 __global__ __launch_bounds__(256) void post_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         long long npix, long long HW, int ldi, int post,
@@ -297,6 +335,23 @@ int mg_launch_misc(const mg_op* op, hipStream_t s) {
       MG_LAUNCH(latent_1x1_kernel, dim3(grid), dim3(256), 0, s, (const float*)op->p[0],
                          (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], B, Ci, Co,
                          HW, op->f[0] == 0.f ? 1.f : op->f[0]);
+      break;
+    }
+    case MG_OP_IM2COL_SMALL: {
+      const int B = op->i[0], H = op->i[1], W = op->i[2], C0 = op->i[3], C1 = op->i[4], Kp = op->i[5];
+      const int cin = C0 + C1;
+      MG_REQUIRE(C1 == 0 || op->p[1], "im2col_small: src1 missing");
+      const long long npix = (long long)B * H * W;
+      const dim3 grid((unsigned)((npix + 255) / 256));
+#define I2C_CASE(N, K)                                                                             \
+  if (cin == N && Kp == K) {                                                                       \
+    MG_LAUNCH((im2col_small_kernel<N, K>), grid, dim3(256), 0, s, (const float*)op->p[0],         \
+              (const float*)op->p[1], (bf16_t*)op->p[2], B, H, W, C0, op->i[6]);                   \
+    break;                                                                                         \
+  }
+      I2C_CASE(3, 64) I2C_CASE(4, 64) I2C_CASE(8, 128)
+#undef I2C_CASE
+      MG_REQUIRE(false, "im2col_small: unsupported (Cin %d, Kp %d): (3,64), (4,64) or (8,128)", cin, Kp);
       break;
     }
     case MG_OP_POST_NCHW: {

@@ -77,20 +77,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   }
 }
 
-// one wave per (b, group); writes ss[b][0][c] = scale, ss[b][1][c] = shift
+// one workgroup per (b, group): fixed-order tree over the chunk partials (fp64), then
+// ss[b][0][c] = scale = rstd * gamma, ss[b][1][c] = shift = beta - mean * scale
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           float* __restrict__ ss, int B, int C,
                                                           int groups, int chunks, int HW, float eps) {
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (wid >= B * groups) return;
-  const int b = wid / groups, g = wid % groups;
+  __shared__ double red[2][4];
+  const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cpg = C / groups;
   double s = 0.0, q = 0.0;
   const int n = chunks * cpg;
-  for (int i = lane; i < n; i += 64) {
+  for (int i = threadIdx.x; i < n; i += 256) {
     const int ch = i / cpg, c = g * cpg + (i % cpg);
     const float* p = partials + (((long long)b * chunks + ch) * C + c) * 2;
     s += (double)p[0];
@@ -101,12 +101,16 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     s += __shfl_xor(s, o);
     q += __shfl_xor(q, o);
   }
+  if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
+  __syncthreads();
+  s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   const double cnt = (double)HW * cpg;
   const double mean = s / cnt;
   double var = q / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  for (int i = lane; i < cpg; i += 64) {
+  for (int i = threadIdx.x; i < cpg; i += 256) {
     const int c = g * cpg + i;
     const float sc = rstd * gamma[c];
     ss[((long long)b * 2 + 0) * C + c] = sc;
@@ -223,7 +227,7 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
     case MG_OP_GN_FINALIZE: {
       const int B = op->i[0], C = op->i[1], groups = op->i[2], chunks = op->i[3], HW = op->i[4];
       MG_REQUIRE(C % groups == 0, "gn_finalize: C %d not divisible by groups %d", C, groups);
-      MG_LAUNCH(gn_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, s,
+      MG_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, s,
                          (const float*)op->p[0], (const float*)op->p[1], (const float*)op->p[2],
                          (float*)op->p[3], B, C, groups, chunks, HW, op->f[0]);
       break;

@@ -49,6 +49,7 @@ static int dispatch(const mg_op* op, hipStream_t s) {
     case MG_OP_LINEAR_SMALL_M:
     case MG_OP_LATENT_1X1:
     case MG_OP_POST_NCHW:
+    case MG_OP_IM2COL_SMALL:
     case MG_OP_MEMSET:
     case MG_OP_COPY: return mg_launch_misc(op, s);
     case MG_OP_ENS_DEPTH_STATS:

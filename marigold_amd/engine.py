@@ -107,6 +107,18 @@ class WeightStore:
             return Wm.bf16(w, self.device), Wm.f32(b, self.device)
         return self._memo(("scm", key), f)
 
+    def conv_in_mfma(self, name):
+        """conv3x3 from <= 8 channels as a GEMM over an im2col buffer: [Cout,Cin,3,3] -> bf16
+        [Cout][Kp] with k = tap*Cin + c, zero-padded to Kp (64 or 128)."""
+        def f():
+            w = self.sd[f"{name}.weight"].float()
+            k = 9 * w.shape[1]
+            kp = 64 if k <= 64 else 128
+            wp = torch.zeros(w.shape[0], kp)
+            wp[:, :k] = Wm.pack_conv3x3(w)
+            return Wm.bf16(wp, self.device), kp
+        return self._memo(("cim", name), f)
+
     def geglu(self, name):
         def f():
             w, b = Wm.pack_geglu(self.sd[f"{name}.weight"].float(), self.sd[f"{name}.bias"].float())
@@ -191,6 +203,18 @@ class Builder:
                          N=cout, taps=9, stride=stride, pad=pad, up=up, bias=self.ws.bias(name),
                          rowvec=rowvec, rowvec_bcast=rowvec is not None,
                          residual=None if residual is None else residual.t), name)
+        return out
+
+    def conv_from_nchw(self, src0, src1, name, B, H, W, C0, C1, cout, bcast0=False):
+        """conv3x3 (pad 1) from <= 8 fp32 NCHW channels (two sources = the folded torch.cat of
+        marigold_depth_pipeline.py:456-458) to bf16 NHWC on the MFMA path: im2col + GEMM."""
+        w, kp = self.ws.conv_in_mfma(name)
+        col = self.raw(B * H * W * kp * 2)
+        self.add(O.im2col_small(src0, src1, col, B=B, H=H, W=W, C0=C0, C1=C1, Kp=kp, bcast0=bcast0), f"{name}.im2col")
+        out = self.new(B, H, W, cout)
+        self.add(O.linear(col, w, out.t, M=B * H * W, K=kp, N=cout, bias=self.ws.bias(name),
+                          k_alg=9 * (C0 + C1)), name)
+        self.free(col)
         return out
 
     def conv_to_nchw(self, x, key, w4, bias, out, cout, post=L.POST_NONE, scale=1.0):
@@ -379,10 +403,9 @@ def emit_unet_forward(bld, cfg, ctx, rgb_latent, x_latent, eps_out, temb_table, 
         return temb_table[name].data_ptr() + step * cout * 4
 
     c0 = boc[0]
-    x = bld.new(B, h, w, c0)
     cin = ws.sd["conv_in.weight"].shape[1]
-    bld.add(O.conv_cin_small(rgb_latent, x_latent, ws.small_conv("conv_in"), ws.bias("conv_in"), x.t, B=B,
-                             H=h, W=w, C0=cin - 4, C1=4, Cout=c0, bcast0=rgb_latent.shape[0] == 1), "conv_in")
+    x = bld.conv_from_nchw(rgb_latent, x_latent, "conv_in", B, h, w, cin - 4, 4, c0,
+                           bcast0=rgb_latent.shape[0] == 1)
     skips = [x]
     force_size = any(d % (2 ** (n - 1)) != 0 for d in (h, w))
     for i in range(n):
@@ -436,9 +459,7 @@ def emit_vae_encode(bld, cfg: VAEConfig, rgb, lat_out, B, H, W):
     quant_conv (1x1) and the posterior-mean selection are composed into the encoder's conv_out."""
     ws = bld.ws
     boc = list(cfg.block_out_channels)
-    x = bld.new(B, H, W, boc[0])
-    bld.add(O.conv_cin_small(rgb, None, ws.small_conv("encoder.conv_in"), ws.bias("encoder.conv_in"), x.t,
-                             B=B, H=H, W=W, C0=3, C1=0, Cout=boc[0]), "encoder.conv_in")
+    x = bld.conv_from_nchw(rgb, None, "encoder.conv_in", B, H, W, 3, 0, boc[0])
     for i, c in enumerate(boc):
         for j in range(cfg.layers_per_block):
             y = bld.resnet(x, f"encoder.down_blocks.{i}.resnets.{j}", c, 1e-6)
@@ -486,9 +507,7 @@ def emit_vae_decode(bld, cfg: VAEConfig, latent, out, B, h, w, post):
     z = bld.raw(B * L4 * h * w * 4)
     bld.add(O.latent_1x1(latent, ws.f32mat("post_quant_conv"), ws.bias("post_quant_conv"), z, B=B, Ci=L4,
                          Co=L4, HW=h * w, scale=1.0 / LATENT_SCALE), "post_quant_conv")
-    x = bld.new(B, h, w, rev[0])
-    bld.add(O.conv_cin_small(z, None, ws.small_conv("decoder.conv_in"), ws.bias("decoder.conv_in"), x.t, B=B,
-                             H=h, W=w, C0=L4, C1=0, Cout=rev[0]), "decoder.conv_in")
+    x = bld.conv_from_nchw(z, None, "decoder.conv_in", B, h, w, L4, 0, rev[0])
     bld.free(z)
     x = emit_vae_mid(bld, x, "decoder.mid_block")
     for i, c in enumerate(rev):

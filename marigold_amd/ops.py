@@ -43,13 +43,13 @@ def current_stream_handle():
 def igemm(a, w, out, *, B, H, W, Cin, Ho, Wo, N, taps=1, stride=1, pad=0, up=None, bias=None,
           rowvec=None, residual=None, epi=L.EPI_BF16, ldo=None, out2=None, trans_from=-1, ldt=0,
           batch_z=1, ldr=0, lda=0, ldw=0, zstrides=(0, 0, 0, 0), scale=1.0, variant=0,
-          rowvec_bcast=False, n_alg=0):
+          rowvec_bcast=False, n_alg=0, k_alg=0):
     hu, wu = up if up else (0, 0)
     if ldo is None:
         ldo = N // 2 if epi == L.EPI_GEGLU else N
     return make_op(L.OP_IGEMM,
                    i=[B, H, W, Cin, Ho, Wo, N, taps, stride, pad, hu, wu, epi, ldo, trans_from,
-                      batch_z, ldr, lda, ldt, variant, ldw, int(rowvec_bcast), n_alg],
+                      batch_z, ldr, lda, ldt, variant, ldw, int(rowvec_bcast), n_alg, k_alg],
                    f=[scale], p=[a, w, out, bias, rowvec, residual, out2], l=list(zstrides))
 
 
@@ -110,6 +110,10 @@ def linear_small_m(x, w, b, out, *, M, N, K, act_in=0, act_out=0, ldo=0):
 
 def latent_1x1(x, w, b, out, *, B, Ci, Co, HW, scale=1.0):
     return make_op(L.OP_LATENT_1X1, i=[B, Ci, Co, HW], f=[scale], p=[x, w, b, out])
+
+
+def im2col_small(src0, src1, out, *, B, H, W, C0, C1, Kp, bcast0=False):
+    return make_op(L.OP_IM2COL_SMALL, i=[B, H, W, C0, C1, Kp, int(bcast0)], p=[src0, src1, out])
 
 
 def post_nchw(x, out, *, B, HW, Cout, ldi, post=L.POST_NONE, scale=1.0):

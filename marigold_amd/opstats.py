@@ -14,7 +14,7 @@ CLASS = {
     L.OP_SOFTMAX_ROWS: "softmax", L.OP_SOFTMAX_PAIRS: "softmax",
     L.OP_CONV_CIN_SMALL: "boundary_conv", L.OP_CONV_COUT_SMALL: "boundary_conv",
     L.OP_CONCAT_C: "concat", L.OP_SCHED_STEP: "scheduler_step", L.OP_LINEAR_SMALL_M: "time_embedding",
-    L.OP_LATENT_1X1: "boundary_conv", L.OP_POST_NCHW: "boundary_conv", L.OP_ENS_DEPTH_STATS: "ensemble", L.OP_ENS_DEPTH_MEDIAN: "ensemble",
+    L.OP_LATENT_1X1: "boundary_conv", L.OP_POST_NCHW: "boundary_conv", L.OP_IM2COL_SMALL: "boundary_conv", L.OP_ENS_DEPTH_STATS: "ensemble", L.OP_ENS_DEPTH_MEDIAN: "ensemble",
     L.OP_ENS_DEPTH_NORM: "ensemble", L.OP_ENS_NORMALS: "ensemble", L.OP_MEMSET: "memops", L.OP_COPY: "memops",
 }
 BOUND = {"igemm_mfma": "mfma", "flash_attn64": "mfma"}   # everything else is HBM-bound streaming
@@ -29,7 +29,7 @@ def op_cost(op):
         B, H, W, Cin, Ho, Wo, N, taps = (i[j] for j in range(8))
         epi, bz = i[12], max(1, i[15])
         M, K = B * Ho * Wo, taps * Cin
-        flops = 2 * M * (i[22] or N) * K * bz   # i[22]: un-padded N of the small-Cout convs
+        flops = 2 * M * (i[22] or N) * (i[23] or K) * bz   # i[22] / i[23]: un-padded N / K of the boundary convs
         n_out = N // 2 if epi == L.EPI_GEGLU else N
         osz = 4 if epi == L.EPI_F32 else 2
         byts = bz * (B * H * W * Cin * 2 + N * K * 2 + M * n_out * osz)
@@ -66,6 +66,8 @@ def op_cost(op):
         byts = i[1] * i[2] * 4
     elif k == L.OP_LATENT_1X1:
         byts = i[0] * (i[1] + i[2]) * i[3] * 4
+    elif k == L.OP_IM2COL_SMALL:
+        byts = i[0] * i[1] * i[2] * ((i[3] + i[4]) * 4 + i[5] * 2)
     elif k == L.OP_POST_NCHW:
         byts = i[0] * i[1] * (i[3] + (1 if i[4] == L.POST_DEPTH else i[2])) * 4
     elif k in (L.OP_ENS_DEPTH_STATS, L.OP_ENS_DEPTH_MEDIAN):

@@ -12,7 +12,7 @@ timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -s --timeout=15
 echo "kernels rc=$?" >> gpurun_out/status.log
 timeout 900 python bench.py --steps 4 --warmup 1 --dump-ops gpurun_out/ops_full.tsv > gpurun_out/bench_full.json 2> gpurun_out/bench_full.log
 echo "bench rc=$?" >> gpurun_out/status.log
-timeout 900 python -m pytest tests/test_gpu_pipeline.py -m gpu -q -s --timeout=240 --timeout-method=thread > gpurun_out/t_pipe.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_fullsize.py -m gpu -q -s --timeout=400 --timeout-method=thread > gpurun_out/t_pipe.log 2>&1
 echo "pipeline rc=$?" >> gpurun_out/status.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 echo "smoke rc=$?" >> gpurun_out/status.log

@@ -486,3 +486,30 @@ def test_small_cout_conv_on_mfma_path(dev):
                        Ho=H, Wo=W, N=8, taps=9, stride=1, pad=1, bias=b8.to(dev), epi=L.EPI_F32, ldo=8))
         _run(ops.post_nchw(tmp, out, B=B, HW=H * W, Cout=cout, ldi=8, post=post, scale=0.7))
         _close(f"small_cout_mfma/c{cout}p{post}", out, ref, tol=2e-2)
+
+
+def test_small_cin_conv_on_mfma_path(dev):
+    """conv3x3 from <= 8 fp32 NCHW channels (two sources, first one broadcast) = MG_OP_IM2COL_SMALL +
+    GEMM with K padded to 64 / 128."""
+    from marigold_amd import ops, weights as Wm
+    g = torch.Generator().manual_seed(9)
+    for (B, H, W, C0, C1, Cout, bcast) in ((3, 10, 14, 4, 4, 64, True), (2, 9, 7, 4, 4, 320, False),
+                                           (1, 12, 20, 3, 0, 128, False), (2, 8, 16, 4, 0, 64, False)):
+        a = torch.randn(1 if bcast else B, C0, H, W, generator=g)
+        b = torch.randn(B, C1, H, W, generator=g) if C1 else None
+        w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / math.sqrt(9 * (C0 + C1))
+        bias = torch.randn(Cout, generator=g) * 0.1
+        xin = a.expand(B, -1, -1, -1) if bcast else a
+        if C1:
+            xin = torch.cat([xin, b], dim=1)
+        ref = F.conv2d(_bf(xin), _bf(w), bias, padding=1)
+        k = 9 * (C0 + C1)
+        kp = 64 if k <= 64 else 128
+        wp = torch.zeros(Cout, kp)
+        wp[:, :k] = Wm.pack_conv3x3(_bf(w))
+        col = torch.full((B * H * W, kp), float("nan"), device=dev, dtype=torch.bfloat16)
+        out = torch.full((B, H, W, Cout), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.im2col_small(a.to(dev), b.to(dev) if C1 else None, col, B=B, H=H, W=W, C0=C0, C1=C1, Kp=kp,
+                              bcast0=bcast))
+        _run(ops.linear(col, wp.to(dev, torch.bfloat16), out, M=B * H * W, K=kp, N=Cout, bias=bias.to(dev)))
+        _close(f"small_cin_mfma/{C0}+{C1}->{Cout}", out.float().permute(0, 3, 1, 2), ref)
