@@ -49,6 +49,22 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel class from the rocprofv3 PMC passes of THIS command
+    (scripts/gpu_round.sh pmc: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
+    /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes for gfx950's wide coalesced reads),
+    committed as profiles/r1_pmc_hbm_traffic.json.  PMC counters cannot be read from inside the timed
+    process, so the figure is the one measured offline for the same workload; None if absent."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f).get(kernel_class)
+        return None if t is None else {"bytes_per_launch": t["bytes_per_launch"], "launches": t["launches"],
+                                       "source": "profiles/r1_pmc_hbm_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE)"}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(args, members_path):
     """The CPU oracle (restatement of the reference's diffusers path) timed on the host cores, on a
     bounded sample: 1 UNet forward at the full 96x96 latent, VAE encode/decode at 256x256 scaled by
@@ -244,6 +260,7 @@ def main():
                         "peak": opstats.HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(d["gbs"] / opstats.HBM_PEAK_GBS, 4), "traffic": None,
                         "launches_per_map": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
+            roof["traffic"] = pmc_traffic(dom)
             for d in kernels.values():
                 for k in ("ms", "tflops", "gbs"):
                     d[k] = round(d[k], 3)
