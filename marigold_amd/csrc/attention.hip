@@ -13,6 +13,8 @@
 //  * softmax_rows: fp32 -> bf16 row softmax for the VAE's single-head d=512 attention, whose
 //    scores are materialised by the GEMM kernel (288 GB HBM: 340 MB/member is cheap).
 //  * softmax_pairs: 2-key softmax of the collapsed cross-attention (see marigold_hip.h).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -286,19 +288,20 @@ __global__ __launch_bounds__(NW * 64) void flash_attn64_v2_kernel(const FaArgs a
   const int nkt = (a.Ntok + FA_KB - 1) / FA_KB;
   issue(0);
   if (nkt > 1) issue(1);
-  int st_c = 0, st_i = 2;
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) {
+  // One key tile.  st_c / st_i are literal constants in the steady-state loop (unrolled over the three
+  // ring stages) so every LDS address is base + immediate; ISSUE / MASK are compile-time tags so the
+  // steady state is branch-free (tile kt+2 always exists there, no ragged keys).
+  auto tile = [&](int kt, int st_c, int st_i, auto issue_tag, auto mask_tag) {
+    constexpr bool do_issue = decltype(issue_tag)::value;
+    constexpr bool MASK = decltype(mask_tag)::value;
+    if (do_issue || kt + 1 < nkt) {
       if constexpr (ITS == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    const bool do_issue = kt + 2 < nkt;
-    if constexpr (!SPLIT) {
-      if (do_issue) issue(st_i);
-    }
+    if constexpr (!SPLIT && do_issue) issue(st_i);
     const char* sK = smem + st_c * FA_STAGE;
     const char* sV = sK + FA_KB * 128;
 
@@ -316,16 +319,14 @@ __global__ __launch_bounds__(NW * 64) void flash_attn64_v2_kernel(const FaArgs a
             bf16x8, *(const uint4*)(sK + row * 128 + ((q ^ ((row >> 1) & 7)) << 4)));
         s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t2], 0, 0, 0);
       }
-      if constexpr (SPLIT) {
-        if (do_issue) {
-          if (t2 == 0) issue_k(st_i);
-          else issue_v(st_i);
-        }
+      if constexpr (SPLIT && do_issue) {
+        if (t2 == 0) issue_k(st_i);
+        else issue_v(st_i);
       }
     }
     // ---- online softmax; lane owns query l31, keys (r&3)+8(r>>2)+4*half of each sub-tile ----
     const int kbase = kt * FA_KB;
-    if (kbase + FA_KB > a.Ntok) {  // ragged last tile: mask keys beyond Ntok
+    if (MASK && kbase + FA_KB > a.Ntok) {  // ragged last tile: mask keys beyond Ntok
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -415,8 +416,25 @@ __global__ __launch_bounds__(NW * 64) void flash_attn64_v2_kernel(const FaArgs a
         }
       }
     }
-    st_c = (st_c + 1 == FA2_NSTAGE) ? 0 : st_c + 1;
-    st_i = (st_i + 1 == FA2_NSTAGE) ? 0 : st_i + 1;
+  };
+  {
+    int kt = 0;
+    for (; kt + 5 <= nkt; kt += 3) {  // tiles kt..kt+2 all have a tile two ahead and are not the last
+      tile(kt, 0, 2, std::true_type{}, std::false_type{});
+      tile(kt + 1, 1, 0, std::true_type{}, std::false_type{});
+      tile(kt + 2, 2, 1, std::true_type{}, std::false_type{});
+    }
+    int st_c = 0, st_i = 2;  // kt is a multiple of 3 here
+    for (; kt + 2 < nkt; ++kt) {
+      tile(kt, st_c, st_i, std::true_type{}, std::false_type{});
+      st_c = (st_c + 1 == FA2_NSTAGE) ? 0 : st_c + 1;
+      st_i = (st_i + 1 == FA2_NSTAGE) ? 0 : st_i + 1;
+    }
+    for (; kt < nkt; ++kt) {
+      tile(kt, st_c, st_i, std::false_type{}, std::true_type{});
+      st_c = (st_c + 1 == FA2_NSTAGE) ? 0 : st_c + 1;
+      st_i = (st_i + 1 == FA2_NSTAGE) ? 0 : st_i + 1;
+    }
   }
   // ---- finalize: O[q][d] = o^T / l; lane^32 exchange -> 8 consecutive d per lane, 16-byte stores ----
   float l0, l1;

@@ -16,6 +16,8 @@
 //     output channels of one pixel -> 16-byte NHWC stores / residual loads (32-byte for fp32),
 //     v_cvt_pk_bf16_f32 instead of integer rounding.  GEGLU pairs u/gate rows 16 apart (32-row
 //     interleave, weights.py::pack_geglu) so it keeps the 16-byte stores too.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -53,7 +55,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // fragment reads and their MFMAs instead of in one burst after the barrier, so the ~60-100 issue
 // cycles each piece costs overlap the wave's own MFMAs (all waves of a workgroup leave the barrier
 // together - a burst leaves every SIMD's matrix pipe idle at the same time).
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, bool PF>
+// ABL (tuning sweeps only; results are WRONG for ABL != 0): 1 = no LDS-DMA in the steady state,
+// 2 = fragment reads but no MFMAs, 3 = MFMAs on fixed registers (no fragment reads).
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, bool PF, int ABL = 0>
 __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args a) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   int i_tap = 0, i_c = 0;  // (tap, channel tile) of the NEXT tile to issue
   tap_setup(0);
   auto issue_piece = [&](int stage, int idx) {  // idx in [0, LOADS): A pieces first, then B pieces
+    if constexpr (ABL == 1) return;
     char* sbase = smem + stage * STAGE;
     if (idx < A_IT) {
       glds16(a_ptr[idx], sbase + (idx * NT + wave * 64) * 16);
@@ -171,81 +176,139 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
     if (d < KT) issue(d);
   int st_c = 0;                 // stage holding tile kt
   int st_i = D % NSTAGE;        // stage receiving tile kt + D
-  for (int kt = 0; kt < KT; ++kt) {
-    // tile kt has landed once at most min(D-1, KT-1-kt) younger tiles are still outstanding
-    const int younger = KT - 1 - kt;
-    if (D >= 3 && younger >= 2) wait_vmcnt<2 * LOADS>();
-    else if (D >= 2 && younger >= 1) wait_vmcnt<LOADS>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // everyone's part of tile kt landed; everyone left stage st_i
-    const bool do_issue = kt + D < KT;
-    if constexpr (!SPLIT) {
-      if (do_issue) issue(st_i);
+  // One K step.  ISSUE is a compile-time tag: the steady-state loop (a tile to prefetch every step) is
+  // straight-line code - no branch between the fragment reads and the MFMAs, so hipcc's waitcnt
+  // pass keeps the partial lgkmcnt waits - and the last D steps run the same body without the DMA.
+  auto load_frags = [&](const char* sA, int ks, bf16x8(&fa)[MI], bf16x8(&fb)[NI]) {
+    if constexpr (ABL == 3) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fa[mi] = __builtin_bit_cast(bf16x8, make_uint4(ks, lane, mi, 1));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fb[ni] = __builtin_bit_cast(bf16x8, make_uint4(ks, lane, ni, 2));
+      return;
     }
-    const char* sA = smem + st_c * STAGE;
     const char* sB = sA + BM * 128;
-    auto load_frags = [&](int ks, bf16x8(&fa)[MI], bf16x8(&fb)[NI]) {
-      const int q = ks * 2 + half;
+    const int q = ks * 2 + half;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int r = rowA[mi];
+      fa[mi] = __builtin_bit_cast(bf16x8, *(const uint4*)(sA + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)));
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int r = rowB[ni];
+      fb[ni] = __builtin_bit_cast(bf16x8, *(const uint4*)(sB + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)));
+    }
+  };
+  auto mfmas = [&](const bf16x8(&fa)[MI], const bf16x8(&fb)[NI]) {
+    if constexpr (ABL == 2) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(fa[mi]));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fb[ni]));
+      return;
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const int r = rowA[mi];
-        fa[mi] = __builtin_bit_cast(bf16x8, *(const uint4*)(sA + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)));
+        if constexpr (!TRANS)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        else
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[ni][mi], 0, 0, 0);
       }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int r = rowB[ni];
-        fb[ni] = __builtin_bit_cast(bf16x8, *(const uint4*)(sB + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)));
+  };
+
+  if constexpr (!PF) {
+    // One K step.  ISSUE is a compile-time tag: the steady-state loop (a tile to prefetch every step)
+    // is straight-line code and the last D steps run the same body without the DMA.
+    auto k_step = [&](int kt, auto issue_tag) {
+      constexpr bool ISSUE = decltype(issue_tag)::value;
+      if constexpr (ISSUE) {
+        wait_vmcnt<(D - 1) * LOADS>();  // tiles kt+1 .. kt+D-1 may stay in flight
+      } else {
+        const int younger = KT - 1 - kt;
+        if (D >= 3 && younger >= 2) wait_vmcnt<2 * LOADS>();
+        else if (D >= 2 && younger >= 1) wait_vmcnt<LOADS>();
+        else wait_vmcnt<0>();
       }
-    };
-    auto mfmas = [&](const bf16x8(&fa)[MI], const bf16x8(&fb)[NI]) {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          if constexpr (!TRANS)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
-          else
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[ni][mi], 0, 0, 0);
-        }
-    };
-    auto issue_part = [&](int ks) {
-      if constexpr (SPLIT) {
-        if (do_issue) {
-#pragma unroll
-          for (int idx = ks; idx < LOADS; idx += 4) issue_piece(st_i, idx);
-        }
-      }
-    };
-    if constexpr (PF) {
-      // fragment registers double-buffered: the reads of k-substep ks+1 are in flight while the
-      // MFMAs of ks run (two MFMA groups of cover instead of one)
-      bf16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
-      load_frags(0, fa0, fb0);
-      load_frags(1, fa1, fb1);
-      issue_part(0);
-      mfmas(fa0, fb0);
-      load_frags(2, fa0, fb0);
-      issue_part(1);
-      mfmas(fa1, fb1);
-      load_frags(3, fa1, fb1);
-      issue_part(2);
-      mfmas(fa0, fb0);
-      issue_part(3);
-      mfmas(fa1, fb1);
-    } else {
+      __builtin_amdgcn_s_barrier();  // everyone's part of tile kt landed; everyone left stage st_i
+      if constexpr (!SPLIT && ISSUE) issue(st_i);
+      const char* sA = smem + st_c * STAGE;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         bf16x8 fa[MI], fb[NI];
-        load_frags(ks, fa, fb);
-        issue_part(ks);
+        load_frags(sA, ks, fa, fb);
+        if constexpr (SPLIT && ISSUE) {
+#pragma unroll
+          for (int idx = ks; idx < LOADS; idx += 4) issue_piece(st_i, idx);
+        }
         mfmas(fa, fb);
       }
-    }
-    if constexpr (SPLIT) {
-      if (do_issue) advance();
-    }
-    st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
-    st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+      if constexpr (SPLIT && ISSUE) advance();
+      st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
+      st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+    };
+    int kt = 0;
+    for (; kt + D < KT; ++kt) k_step(kt, std::true_type{});
+    for (; kt < KT; ++kt) k_step(kt, std::false_type{});
+  } else {
+    // Software pipeline at half-K-step granularity (needs the 3-stage ring): the fragments of the
+    // NEXT eight MFMAs are always in flight while eight MFMAs run -
+    //   read F1 = (tile kt, k-substeps 2,3) | MFMA F0 + DMA pieces of tile kt+2 | wait + barrier (tile
+    //   kt+1 landed, every wave retired its reads of tile kt-1's stage) | read F0 = (tile kt+1, k-substeps
+    //   0,1) | MFMA F1.
+    // The profile that motivated it: MFMA, fragment reads and DMA issue of the plain loop add up
+    // (0.44 + 0.35 + 0.22 of the step time) instead of overlapping.
+    static_assert(NSTAGE == 3, "the pipelined loop is written for the 3-stage ring");
+    bf16x8 fa0[2][MI], fb0[2][NI], fa1[2][MI], fb1[2][NI];
+    if (KT > 1) wait_vmcnt<LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    load_frags(smem, 0, fa0[0], fb0[0]);
+    load_frags(smem, 1, fa0[1], fb0[1]);
+    int st_n = 1;  // stage of tile kt + 1
+    auto k_step = [&](auto issue_tag, auto next_tag) {
+      constexpr bool ISSUE = decltype(issue_tag)::value;  // tile kt+2 exists
+      constexpr bool NEXT = decltype(next_tag)::value;    // tile kt+1 exists
+      const char* sA = smem + st_c * STAGE;
+      load_frags(sA, 2, fa1[0], fb1[0]);
+      load_frags(sA, 3, fa1[1], fb1[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(fa0[0], fb0[0]);
+      if constexpr (ISSUE) {
+#pragma unroll
+        for (int idx = 0; idx < LOADS; idx += 2) issue_piece(st_i, idx);
+      }
+      mfmas(fa0[1], fb0[1]);
+      if constexpr (ISSUE) {
+#pragma unroll
+        for (int idx = 1; idx < LOADS; idx += 2) issue_piece(st_i, idx);
+        advance();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NEXT) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of stage st_c's first half and of
+                                                             // every older stage are retired before the barrier
+        if constexpr (ISSUE) wait_vmcnt<LOADS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const char* sN = smem + st_n * STAGE;
+        load_frags(sN, 0, fa0[0], fb0[0]);
+        load_frags(sN, 1, fa0[1], fb0[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(fa1[0], fb1[0]);
+      mfmas(fa1[1], fb1[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
+      st_n = (st_n + 1 == NSTAGE) ? 0 : st_n + 1;
+      st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+    };
+    int kt = 0;
+    for (; kt + 2 < KT; ++kt) k_step(std::true_type{}, std::true_type{});
+    for (; kt + 1 < KT; ++kt) k_step(std::false_type{}, std::true_type{});
+    for (; kt < KT; ++kt) k_step(std::false_type{}, std::false_type{});
   }
 
   // ---------------- epilogue ----------------
@@ -367,13 +430,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT = false, bool PF = false>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT = false, bool PF = false, int ABL = 0>
 int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int LDS = NSTAGE * (BM + BN) * 128;
   static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
   static bool attr_set = false;
-  auto kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS, SPLIT, PF>;
+  auto kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS, SPLIT, PF, ABL>;
   if (!attr_set && !g_dry_run) {
     MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -407,10 +470,16 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
     case 33: return launch2<256, 128, 4, 2, 3, TRANS, true>(a, batch_z, s);
     case 34: return launch2<256, 256, 2, 4, 2, TRANS, true>(a, batch_z, s);
     case 35: return launch2<128, 64, 2, 2, 3, TRANS, true>(a, batch_z, s);
-    case 36: return launch2<256, 128, 4, 2, 3, TRANS, true, true>(a, batch_z, s);
+    case 36: return launch2<256, 128, 4, 2, 3, TRANS, true, true>(a, batch_z, s);   // half-K-step pipelined loops
     case 37: return launch2<128, 64, 2, 2, 3, TRANS, true, true>(a, batch_z, s);
-    case 38: return launch2<256, 256, 2, 4, 2, TRANS, true, true>(a, batch_z, s);
-    case 39: return launch2<128, 128, 2, 2, 2, TRANS, true, true>(a, batch_z, s);
+    case 38: return launch2<128, 128, 2, 2, 3, TRANS, true, true>(a, batch_z, s);
+    case 39: return launch2<128, 128, 4, 2, 3, TRANS, true, true>(a, batch_z, s);
+    case 40: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 1>(a, batch_z, s);  // ablations (sweep only)
+    case 41: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 2>(a, batch_z, s);
+    case 42: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 3>(a, batch_z, s);
+    case 43: return launch2<128, 64, 2, 2, 3, TRANS, true, false, 1>(a, batch_z, s);
+    case 44: return launch2<128, 64, 2, 2, 3, TRANS, true, false, 2>(a, batch_z, s);
+    case 45: return launch2<128, 64, 2, 2, 3, TRANS, true, false, 3>(a, batch_z, s);
     default: MG_REQUIRE(false, "igemm: unknown v2 tile variant %d", variant);
   }
   return 0;

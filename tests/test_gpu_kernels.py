@@ -84,6 +84,10 @@ CONV_CASES = [
     ("g2_split_3stage", 2, 16, 24, 128, 128, 2, 1, None, 33),
     ("g2_split_256x256", 2, 16, 24, 192, 320, 1, 1, (32, 48), 34),
     ("g2_split_128x64", 1, 9, 7, 128, 64, 1, 1, None, 35),
+    ("g2_pipe_256x128", 2, 16, 24, 128, 192, 1, 1, None, 36),
+    ("g2_pipe_128x64_kt1", 2, 12, 12, 64, 320, 2, 1, None, 37),
+    ("g2_pipe_128x128", 1, 14, 14, 320, 128, 1, 1, None, 38),
+    ("g2_pipe_128x128w8_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 39),
     ("g2_auto_split_n320", 10, 72, 72, 64, 320, 1, 1, None, 0),   # 128k+64 columns: main + 64-wide tail launch
     ("g2_auto_small_m", 2, 12, 12, 128, 640, 1, 1, None, 0),
 ]
