@@ -203,11 +203,18 @@ class AutoencoderKLHIP(_EngineModule):
         seq.run()
         return out.clone()
 
+    decode_chunk = 0   # members per decode launch group; 0 = all at once (VAE batching)
+
     def decode(self, latent, post=L.POST_NONE):
         """latent [B,4,h,w] fp32 -> decoded map fp32 ([B,3,H,W], or [B,1,H,W] for POST_DEPTH)."""
         self._require_device()
         B, _, h, w = latent.shape
-        seq, inp, out = self._program("decode", B, h, w, post)
-        inp.copy_(latent)
-        seq.run()
-        return out.clone()
+        chunk = self.decode_chunk if 0 < self.decode_chunk < B else B
+        outs = []
+        for i in range(0, B, chunk):
+            part = latent[i:i + chunk]
+            seq, inp, out = self._program("decode", part.shape[0], h, w, post)
+            inp.copy_(part)
+            seq.run()
+            outs.append(out.clone())
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
