@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--denoise", type=int, default=10)
     ap.add_argument("--res", type=int, default=768)
     ap.add_argument("--kind", default="depth", choices=["depth", "normals"])
+    ap.add_argument("--scheduler", default="ddim", choices=["ddim", "lcm"], help="ddim = v1-1 (trailing, zero-SNR); lcm = depth-lcm-v1-0")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -161,7 +162,7 @@ def main():
     from marigold_amd import opstats, synthetic as syn
     from marigold_amd.arch import TINY_UNET, TINY_VAE, UNetConfig, VAEConfig
     from marigold_amd.modules import AutoencoderKLHIP, UNet2DConditionModelHIP
-    from marigold_amd.schedulers import DDIMScheduler
+    from marigold_amd.schedulers import DDIMScheduler, LCMScheduler
 
     ucfg, vcfg = (TINY_UNET, TINY_VAE) if args.tiny else (UNetConfig(), VAEConfig())
     t0 = time.perf_counter()
@@ -170,7 +171,8 @@ def main():
     ctx = syn.synthetic_text_embedding(ucfg.cross_attention_dim)
     cls = M.MarigoldDepthPipeline if args.kind == "depth" else M.MarigoldNormalsPipeline
     pipe = cls(unet=UNet2DConditionModelHIP(usd, ucfg), vae=AutoencoderKLHIP(vsd, vcfg),
-               scheduler=DDIMScheduler(), empty_text_embed=ctx, default_denoising_steps=args.denoise,
+               scheduler=DDIMScheduler() if args.scheduler == "ddim" else LCMScheduler(), empty_text_embed=ctx,
+               default_denoising_steps=args.denoise,
                default_processing_resolution=0).to(dev)
     if world > 1:
         pipe.enable_member_parallel(root=0)
@@ -294,13 +296,14 @@ def main():
     if rank == 0:
         value = args.steps / dt
         line = {
-            "metric": f"{args.kind} maps/sec @{args.res}x{args.res}, ens={args.ensemble}, {args.denoise} DDIM steps",
+            "metric": f"{args.kind} maps/sec @{args.res}x{args.res}, ens={args.ensemble}, {args.denoise} {args.scheduler.upper()} steps",
             "value": round(value, 4), "unit": f"{args.kind} maps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"marigold-{args.kind}-v1-1 architecture (SD-v2 UNet 865.9M + AutoencoderKL), "
-                                    f"{args.res}x{args.res}, ensemble_size={args.ensemble}, {args.denoise} DDIM steps "
-                                    f"(trailing, zero-SNR, v-prediction), seeded synthetic weights"
+                                    f"{args.res}x{args.res}, ensemble_size={args.ensemble}, {args.denoise} "
+                                    + ("DDIM steps (trailing, zero-SNR, v-prediction)" if args.scheduler == "ddim" else "LCM steps")
+                                    + ", seeded synthetic weights"
                                     + (" [TINY ARCH - plumbing only]" if args.tiny else "")),
                        "members_per_gpu": -(-args.ensemble // world), "parallelism": f"member-parallel x{world}",
                        "hipgraph": bool(args.graph)},

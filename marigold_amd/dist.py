@@ -41,6 +41,9 @@ def gather_members(local, E, chw, device, group=None, root=None, offset=0, dtype
     if G == 1:
         return local
     per = (E + G - 1) // G
+    out_device = device
+    if dist.get_backend(group) == "gloo":   # CPU tests / debugging: gloo collectives take host tensors
+        device = torch.device("cpu")
     buf = torch.zeros((per,) + tuple(chw), device=device, dtype=dtype)
     if local is not None and local.shape[0] > 0:
         buf[:local.shape[0]].copy_(local)
@@ -56,4 +59,4 @@ def gather_members(local, E, chw, device, group=None, root=None, offset=0, dtype
     for rr, idx in enumerate(members_per_rank(E, G, offset)):
         if idx:
             out[idx] = parts[rr][:len(idx)]
-    return out
+    return out.to(out_device)

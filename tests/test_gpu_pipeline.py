@@ -319,3 +319,59 @@ def test_graph_capture_matches_eager(tiny):
         prog.run()
     torch.cuda.synchronize()
     assert torch.equal(prog.x, ref)
+
+
+def _mp_worker(rank, world, port, q):
+    """One rank of the member-parallel pipeline; both ranks share cuda:0 and meet over gloo (RCCL cannot
+    put two ranks on one device - the collective is what differs from the 8-GPU run, the sharding,
+    noise slicing and gather ordering are the code under test)."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import marigold_amd as M
+    from marigold_amd import synthetic as syn
+    from marigold_amd.arch import TINY_UNET, TINY_VAE
+    pipe = M.build_synthetic_pipeline("depth", TINY_UNET, TINY_VAE, default_processing_resolution=0).to("cuda:0")
+    pipe.enable_member_parallel(root=0)
+    img = syn.synthetic_image(64, 128, seed=0)
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    out = pipe(img, denoising_steps=2, ensemble_size=3, processing_res=0, color_map=None, show_progress_bar=False,
+               generator=g)
+    if rank == 0:
+        q.put(out.depth_np)
+    else:
+        assert out.depth_np is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_member_parallel_two_ranks_share_one_gpu():
+    """E=3 members sharded over 2 processes (member e -> rank e % 2), ONE gather, aggregation on rank 0:
+    same map as the single-process run with the same generator seed."""
+    import socket
+    import torch.multiprocessing as mp
+    import marigold_amd as M
+    from marigold_amd import synthetic as syn
+    from marigold_amd.arch import TINY_UNET, TINY_VAE
+    from oracle import metrics as omet
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pipe = M.build_synthetic_pipeline("depth", TINY_UNET, TINY_VAE, default_processing_resolution=0).to("cuda:0")
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    ref = pipe(syn.synthetic_image(64, 128, seed=0), denoising_steps=2, ensemble_size=3, processing_res=0,
+               color_map=None, show_progress_bar=False, generator=g).depth_np
+    m = omet.affine_invariant_depth_errors(ref, got)
+    print(f"[parity] 2-rank member-parallel vs single process: max|diff| {np.abs(ref - got).max():.2e} {m}")
+    assert np.abs(ref - got).max() < 2e-2 and m["rmse"] < 5e-3
