@@ -74,6 +74,8 @@ extern void* g_zero_page;  // MG_ZERO_BYTES zero bytes in device memory (mg_init
 // Dry run (mg_program_validate): every launcher checks its op's shape / alignment contract and
 // returns before touching the device - the CPU test-suite validates full-size programs with it.
 extern thread_local bool g_dry_run;
+#define MG_SPLITK_WS_BYTES (64ll * 1024 * 1024)
+extern void* g_splitk_ws;  // fp32 partial sums of split-K GEMM launches (mg_init); stream-ordered reuse
 #define MG_LAUNCH(...)                                   \
   do {                                                   \
     if (!g_dry_run) hipLaunchKernelGGL(__VA_ARGS__);     \

@@ -33,6 +33,8 @@ struct Igemm2Args {
   int H, W, Cin, Ho, Wo, N, taps, stride, pad, Hu, Wu, epi, ldo, ldr, lda, ldt, ldw;
   int M, rows_per_img, tiles_m, tiles_n, cpt, KT, rv_stride, up2, ctr;
   int n_begin, n_end;  // output-column range of this launch (tiles start at n_begin, bound n_end <= N)
+  int splits, kps;     // split-K: `splits` workgroups per tile, each `kps` K steps; partials go to `ws`
+  float* ws;           // fp32 [splits][M][N] (scale / bias / residual are applied by the reduce kernel)
   long long sA, sW, sO, sR;
   float scale;
 };
@@ -76,9 +78,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   const int l31 = lane & 31, half = lane >> 5;
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int per_z = a.tiles_m * a.tiles_n;
+  const int tiles = a.tiles_m * a.tiles_n;
+  const int per_z = tiles * a.splits;
   const int z = bid / per_z;
-  const int t = bid - z * per_z;
+  const int rz = bid - z * per_z;
+  const int split = rz / tiles;
+  const int t = rz - split * tiles;
   const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
   const int m0 = tile_m * BM, n0 = a.n_begin + tile_n * BN;
 
@@ -112,6 +117,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
     const int n = n0 + r;
     b_ptr[it] = (n < a.n_end) ? (const char*)(Wb + (long long)n * a.ldw + (p ^ ((r >> 1) & 7)) * 8) : zero;
   }
+  const int kt0 = split * a.kps;                                   // this workgroup's K-step range
+  const int KT = min(a.KT, kt0 + a.kps) - kt0;
+  if (kt0) {
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      if (b_ptr[it] != zero) b_ptr[it] += (long long)kt0 * 128;
+  }
   const char* a_ptr[A_IT];
   const int hb = a.Hu ? a.Hu : a.H, wb = a.Hu ? a.Wu : a.W;  // bounds in (virtual) input space
   auto tap_setup = [&](int tap) {
@@ -129,8 +141,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
       a_ptr[it] = ok ? pv : zero;
     }
   };
-  int i_tap = 0, i_c = 0;  // (tap, channel tile) of the NEXT tile to issue
-  tap_setup(0);
+  int i_tap = kt0 / a.cpt, i_c = kt0 - i_tap * a.cpt;  // (tap, channel tile) of the NEXT tile to issue
+  tap_setup(i_tap);
+  if (i_c) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it)
+      if (a_ptr[it] != zero) a_ptr[it] += i_c * 128;
+  }
   auto issue_piece = [&](int stage, int idx) {  // idx in [0, LOADS): A pieces first, then B pieces
     if constexpr (ABL == 1) return;
     char* sbase = smem + stage * STAGE;
@@ -170,7 +187,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) rowB[ni] = wn * TN + ni * 32 + l31;
 
-  const int KT = a.KT;
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < KT) issue(d);
@@ -365,11 +381,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
         for (int j = 0; j < 4; ++j) {
           half_swap(acc[ni][mi][8 * gp + j], acc[ni][mi][8 * gp + 4 + j], v[j], v[4 + j]);
         }
+        if (a.splits <= 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= scale;
+          for (int j = 0; j < 8; ++j) v[j] *= scale;
+        }
         if constexpr (!TRANS) {
           const int m = mb + l31, n = nb + 16 * gp + 8 * half;
-          if (m < a.M && n < a.n_end) {
+          if (a.splits > 1) {  // split-K: raw partial sums, everything else happens in splitk_reduce_kernel
+            if (m < a.M && n < a.n_end) {
+              float* o = a.ws + ((long long)split * a.M + m) * a.N + n;
+              *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+              *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+          } else if (m < a.M && n < a.n_end) {
             if (a.bias) {
               const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
               v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
@@ -430,6 +454,48 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   }
 }
 
+// out[m][n] = bf16( scale * sum_s ws[s][m][n] + bias[n] + rowvec[img(m)][n] + residual[m][n] ): the
+// epilogue of a split-K launch (fixed summation order -> bit-reproducible), 8 channels per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const Igemm2Args a) {
+  const int nv = a.N >> 3;
+  const long long total = (long long)a.M * nv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / nv);
+    const int n = (int)(i - (long long)m * nv) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int sidx = 0; sidx < a.splits; ++sidx) {
+      const float* p = a.ws + ((long long)sidx * a.M + m) * a.N + n;
+      const float4 x0 = *(const float4*)p, x1 = *(const float4*)(p + 4);
+      v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w;
+      v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= a.scale;
+    if (a.bias) {
+      const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+      v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (a.rowvec) {
+      const float* rv = a.rowvec + (long long)(m / a.rows_per_img) * a.rv_stride + n;
+      const float4 r0 = *(const float4*)rv, r1 = *(const float4*)(rv + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+      v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    if (a.res) {
+      const uint4 r4 = *(const uint4*)(a.res + (long long)m * a.ldr + n);
+      v[0] += bflo(r4.x); v[1] += bfhi(r4.x); v[2] += bflo(r4.y); v[3] += bfhi(r4.y);
+      v[4] += bflo(r4.z); v[5] += bfhi(r4.z); v[6] += bflo(r4.w); v[7] += bfhi(r4.w);
+    }
+    uint4 pk;
+    pk.x = cvt_pk_bf16(v[0], v[1]); pk.y = cvt_pk_bf16(v[2], v[3]);
+    pk.z = cvt_pk_bf16(v[4], v[5]); pk.w = cvt_pk_bf16(v[6], v[7]);
+    *(uint4*)((bf16_t*)a.out + (long long)m * a.ldo + n) = pk;
+  }
+}
+
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT = false, bool PF = false, int ABL = 0>
 int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   constexpr int NT = WGM * WGN * 64;
@@ -444,9 +510,30 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   Igemm2Args b = a;
   b.tiles_m = (a.M + BM - 1) / BM;
   b.tiles_n = (a.n_end - a.n_begin + BN - 1) / BN;
-  const long long grid = (long long)b.tiles_m * b.tiles_n * batch_z;
+  // split-K for the deep UNet levels (a few hundred pixels x thousands of input channels): too few
+  // output tiles to fill 256 CUs, so the K loop is cut into `splits` workgroups per tile.
+  b.splits = 1;
+  b.kps = a.KT;
+  b.ws = nullptr;
+  const long long tiles = (long long)b.tiles_m * b.tiles_n;
+  if (!TRANS && a.splits == 0 && batch_z == 1 && a.epi == MG_EPI_BF16 && a.n_begin == 0 && a.n_end == a.N &&
+      tiles < 160 && a.KT >= 32 && g_splitk_ws) {
+    int sp = (int)min((long long)8, (320 + tiles - 1) / tiles);
+    sp = min(sp, a.KT / 12);
+    while (sp > 1 && (long long)sp * a.M * a.N * 4 > MG_SPLITK_WS_BYTES) --sp;
+    if (sp > 1) {
+      b.kps = (a.KT + sp - 1) / sp;
+      b.splits = (a.KT + b.kps - 1) / b.kps;
+      b.ws = (float*)g_splitk_ws;
+    }
+  }
+  const long long grid = tiles * b.splits * batch_z;
   MG_REQUIRE(grid > 0 && grid < (1ll << 31), "igemm: bad grid %lld", grid);
   MG_LAUNCH(kern, dim3((unsigned)grid), dim3(NT), LDS, s, b);
+  if (b.splits > 1) {
+    const long long nvec = (long long)a.M * (a.N / 8);
+    MG_LAUNCH(splitk_reduce_kernel, dim3((unsigned)min((nvec + 255) / 256, (long long)4096)), dim3(256), 0, s, b);
+  }
   if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -518,6 +605,9 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.cpt = a.Cin / 64;
   a.KT = a.taps * a.cpt;
   a.up2 = (a.Hu == 2 * a.H) && (a.Wu == 2 * a.W);
+  a.splits = variant ? -1 : 0;   // split-K only under the automatic tile choice
+  a.kps = 0;
+  a.ws = nullptr;
   a.ctr = 0;
   a.tiles_m = a.tiles_n = 0;
   MG_REQUIRE(g_zero_page || g_dry_run, "igemm: mg_init() not called");

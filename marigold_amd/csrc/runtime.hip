@@ -13,6 +13,7 @@
 #include "common.h"
 
 void* g_zero_page = nullptr;
+void* g_splitk_ws = nullptr;
 thread_local bool g_dry_run = false;
 int g_igemm_gen = 2;
 static thread_local char g_err[512] = "";
@@ -93,6 +94,7 @@ int mg_init(int device) {
              "mg_init: one process drives one GPU (already bound to device %d)", g_device);
   MG_CHECK_HIP(hipMalloc(&g_zero_page, MG_ZERO_BYTES));
   MG_CHECK_HIP(hipMemset(g_zero_page, 0, MG_ZERO_BYTES));
+  MG_CHECK_HIP(hipMalloc(&g_splitk_ws, MG_SPLITK_WS_BYTES));
   g_device = device;
   return 0;
 }

@@ -90,6 +90,9 @@ CONV_CASES = [
     ("g2_pipe_128x128w8_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 39),
     ("g2_auto_split_n320", 10, 72, 72, 64, 320, 1, 1, None, 0),   # 128k+64 columns: main + 64-wide tail launch
     ("g2_auto_small_m", 2, 12, 12, 128, 640, 1, 1, None, 0),
+    ("g2_auto_splitk", 1, 12, 12, 1280, 128, 1, 1, None, 0),        # 6 tiles x 8 K-splits + reduce kernel
+    ("g2_auto_splitk_n320", 1, 9, 7, 640, 320, 1, 1, None, 0),
+    ("g2_auto_splitk_up2", 1, 6, 6, 1280, 256, 1, 1, (12, 12), 0),
 ]
 
 
