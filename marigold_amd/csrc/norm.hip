@@ -148,6 +148,60 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   }
 }
 
+// One workgroup per (image, group): pass 1 accumulates sum / sum of squares of the group's HW x cpg
+// slice (bf16 pairs, strided rows - the slice is tens of KB and L2-resident), a fixed-order block
+// reduction gives mean / rstd, pass 2 re-reads the slice, applies scale / shift (+SiLU) and writes it.
+__global__ __launch_bounds__(256) void gn_fused_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                       int HW, int C, int groups, int silu, float eps) {
+  __shared__ double red[2][4];
+  __shared__ float stat[2];
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int cpg = C / groups, ppr = cpg >> 1;  // bf16 pairs per row of the slice
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bf16_t* xb = x + (long long)b * HW * C + g * cpg;
+  bf16_t* ob = out + (long long)b * HW * C + g * cpg;
+  const int total = HW * ppr;
+  float s = 0.f, q = 0.f;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int r = i / ppr, p = i - r * ppr;
+    const uint32_t w = *(const uint32_t*)(xb + (long long)r * C + 2 * p);
+    const float a = bflo(w), c = bfhi(w);
+    s += a + c;
+    q += a * a + c * c;
+  }
+  double sd = s, qd = q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sd += __shfl_xor(sd, o);
+    qd += __shfl_xor(qd, o);
+  }
+  if (lane == 0) { red[0][wave] = sd; red[1][wave] = qd; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double S = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double Q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double cnt = (double)HW * cpg;
+    const double mean = S / cnt;
+    double var = Q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[0] = (float)mean;
+    stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int r = i / ppr, p = i - r * ppr;
+    const int c = g * cpg + 2 * p;
+    const uint32_t w = *(const uint32_t*)(xb + (long long)r * C + 2 * p);
+    const float sc0 = rstd * gamma[c], sc1 = rstd * gamma[c + 1];
+    float v0 = bflo(w) * sc0 + (beta[c] - mean * sc0);
+    float v1 = bfhi(w) * sc1 + (beta[c + 1] - mean * sc1);
+    if (silu) { v0 = silu_f(v0); v1 = silu_f(v1); }
+    *(uint32_t*)(ob + (long long)r * C + 2 * p) = pack2bf(v0, v1);
+  }
+}
+
 // one wave per row, C <= 64*8*LN_NV
 constexpr int LN_NV = 4;
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x,
@@ -239,6 +293,14 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
       const int grid = (int)min((nvec + 255) / 256, (long long)256 * 16);
       MG_LAUNCH(gn_apply_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)op->p[0],
                          (const float*)op->p[1], (bf16_t*)op->p[2], nvec, HW, C, op->i[3]);
+      break;
+    }
+    case MG_OP_GN_FUSED: {
+      const int B = op->i[0], HW = op->i[1], C = op->i[2], groups = op->i[3];
+      MG_REQUIRE(B > 0 && HW > 0 && groups > 0 && C % groups == 0 && (C / groups) % 2 == 0,
+                 "gn_fused: C %d / groups %d must give an even channel count per group", C, groups);
+      MG_LAUNCH(gn_fused_kernel, dim3(groups, B), dim3(256), 0, s, (const bf16_t*)op->p[0], (const float*)op->p[1],
+                (const float*)op->p[2], (bf16_t*)op->p[3], HW, C, groups, op->i[4], op->f[0]);
       break;
     }
     case MG_OP_LAYERNORM: {
