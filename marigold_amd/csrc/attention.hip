@@ -571,8 +571,9 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
         case 6: MG_LAUNCH((flash_attn64_v2_kernel<true, 8, 2>), dim3((unsigned)g8), dim3(512), 0, s, a); break;
         case 7: MG_LAUNCH((flash_attn64_v2_kernel<true, 8, 1>), dim3((unsigned)g8), dim3(512), 0, s, a); break;
         case 8: MG_LAUNCH((flash_attn64_v2_kernel<true, 4, 0>), dim3((unsigned)g4), dim3(256), 0, s, a); break;
-        default:  // sweep (profiles/r1_sweep3_flash_variants.log): 8 waves pay off from a few thousand keys on
-          if (a.Ntok >= 2048) MG_LAUNCH((flash_attn64_v2_kernel<true, 8, 2>), dim3((unsigned)g8), dim3(512), 0, s, a);
+        default:  // sweep (profiles/r1_sweep3_flash_variants.log): 8 waves pay off from a few thousand keys on,
+                  // provided the grid still covers the 256 CUs twice (small ensembles: 4-wave blocks)
+          if (a.Ntok >= 2048 && g8 >= 512) MG_LAUNCH((flash_attn64_v2_kernel<true, 8, 2>), dim3((unsigned)g8), dim3(512), 0, s, a);
           else MG_LAUNCH((flash_attn64_v2_kernel<true, 4, 2>), dim3((unsigned)g4), dim3(256), 0, s, a);
           break;
       }

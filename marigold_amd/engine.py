@@ -176,6 +176,8 @@ class Builder:
     # ---- primitive layers ----------------------------------------------------------------
     # single-launch GroupNorm (MG_OP_GN_FUSED): measured SLOWER than the three-launch form down to the
     # smallest UNet tensors (strided 4-byte accesses; E=1: 20 -> 26 ms of GroupNorm per map), so it is off
+    # single-launch GroupNorm (MG_OP_GN_FUSED): measured SLOWER than the three-launch form even on the
+    # smallest UNet tensors (strided 4-byte accesses; E=1: 20 -> 26 ms of GroupNorm per map) -> off
     GN_FUSED_MAX_ELEMS = 0
 
     def group_norm(self, x, name, eps, silu):
