@@ -561,6 +561,9 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
     case 37: return launch2<128, 64, 2, 2, 3, TRANS, true, true>(a, batch_z, s);
     case 38: return launch2<128, 128, 2, 2, 3, TRANS, true, true>(a, batch_z, s);
     case 39: return launch2<128, 128, 4, 2, 3, TRANS, true, true>(a, batch_z, s);
+    case 46: return launch2<128, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);   // full-width tiles for N = 320
+    case 47: return launch2<256, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);
+    case 48: return launch2<128, 320, 4, 2, 2, TRANS, false>(a, batch_z, s);
     case 40: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 1>(a, batch_z, s);  // ablations (sweep only)
     case 41: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 2>(a, batch_z, s);
     case 42: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 3>(a, batch_z, s);
@@ -660,8 +663,9 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
 // Tile choice, from the round-1 sweeps on MI355X (profiles/r1_sweep*_*.log; TFLOP/s at E = 10):
 //   * 256x256 / 8 waves (wave tile 128x64) when N is a multiple of 256 and there are >= 512 tiles:
 //     VAE 512/256-channel layers 890-1080, GEGLU projections 440-750;
-//   * 128x64 / 4 waves / 3 stages for N = 128k+64 (the 320-channel UNet level: no ragged-tile waste,
-//     750-830) and for the deep levels where M is a few thousand pixels;
+//   * 128x320 / 8 waves (wave tile 32x160) for the 320-channel UNet level at large M (730-920);
+//   * 128x64 / 4 waves / 3 stages for other N = 128k+64 and for the deep levels where M is a few
+//     thousand pixels;
 //   * 256x128 / 8 waves / 3 stages for the long-K layers (870-1000), 128x128 / 4 waves / 2 stages
 //     (two workgroups per CU) when K <= 1536;
 //   all with the next tile's LDS-DMA pieces issued between the k-substeps' MFMA groups.
@@ -670,6 +674,9 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
   if (N <= 32) return 29;
   const long long tm256 = (M + 255) / 256;
   if (N % 256 == 0 && tm256 * (N / 256) * batch_z >= 512) return 34;
+  // N = 320 (UNet level 0): a full-width 128x320 tile reads the activation tile once for all output
+  // channels (2.1x fewer LDS-DMA bytes per MFMA than 128x64): 900 vs 740 TFLOP/s on the 640->320 convs
+  if (N == 320 && ((M + 127) / 128) * batch_z >= 400) return 46;
   const long long t256 = tm256 * ((N + 127) / 128) * batch_z;
   const long long t128x64 = ((M + 127) / 128) * ((N + 63) / 64) * batch_z;
   if (t256 >= 200) {

@@ -202,65 +202,73 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const bf16_t* __restrict_
   }
 }
 
-// one wave per row, C <= 64*8*LN_NV
-constexpr int LN_NV = 4;
+// LayerNorm over the last dim: one wave per R rows, all R rows' 16-byte loads issued before any
+// reduction (with a single row in flight per wave the kernel sits at ~2.7 TB/s: bytes in flight =
+// waves x 640 B, Little's law).  C <= 64 * 8 * NV.
+template <int NV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         bf16_t* __restrict__ out, int M, int C,
                                                         float eps) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
   const int lane = threadIdx.x & 63;
-  if (row >= M) return;
+  if (row0 >= M) return;
   const int cv = C >> 3;
-  float v[LN_NV][8];
-  float s = 0.f;
-  const bf16_t* xr = x + (long long)row * C;
+  uint4 u[R][NV];
 #pragma unroll
-  for (int k = 0; k < LN_NV; ++k) {
-    const int vc = lane + k * 64;
-    if (vc < cv) {
-      const uint4 u = *(const uint4*)(xr + vc * 8);
-      v[k][0] = bflo(u.x); v[k][1] = bfhi(u.x); v[k][2] = bflo(u.y); v[k][3] = bfhi(u.y);
-      v[k][4] = bflo(u.z); v[k][5] = bfhi(u.z); v[k][6] = bflo(u.w); v[k][7] = bfhi(u.w);
+  for (int r = 0; r < R; ++r) {
+    const int row = min(row0 + r, M - 1);
+    const bf16_t* xr = x + (long long)row * C;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[k][j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[k][j] = 0.f;
+    for (int k = 0; k < NV; ++k) {
+      const int vc = lane + k * 64;
+      u[r][k] = vc < cv ? *(const uint4*)(xr + vc * 8) : make_uint4(0, 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s / (float)C;
-  float q = 0.f;
+  for (int r = 0; r < R; ++r) {
+    if (row0 + r >= M) break;
+    float v[NV][8];
+    float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_NV; ++k) {
-    const int vc = lane + k * 64;
-    if (vc < cv) {
+    for (int k = 0; k < NV; ++k) {
+      v[k][0] = bflo(u[r][k].x); v[k][1] = bfhi(u[r][k].x); v[k][2] = bflo(u[r][k].y); v[k][3] = bfhi(u[r][k].y);
+      v[k][4] = bflo(u[r][k].z); v[k][5] = bfhi(u[r][k].z); v[k][6] = bflo(u[r][k].w); v[k][7] = bfhi(u[r][k].w);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; q += d * d; }
+      for (int j = 0; j < 8; ++j) s += v[k][j];   // padding vectors are zero
     }
-  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rstd = rsqrtf(q / (float)C + eps);
-  bf16_t* orow = out + (long long)row * C;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_NV; ++k) {
-    const int vc = lane + k * 64;
-    if (vc < cv) {
-      const float4 g0 = *(const float4*)(gamma + vc * 8), g1 = *(const float4*)(gamma + vc * 8 + 4);
-      const float4 b0 = *(const float4*)(beta + vc * 8), b1 = *(const float4*)(beta + vc * 8 + 4);
-      const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-      const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      float r[8];
+    for (int k = 0; k < NV; ++k) {
+      if (lane + k * 64 < cv) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = (v[k][j] - mean) * rstd * gs[j] + bs[j];
-      uint4 o;
-      o.x = pack2bf(r[0], r[1]); o.y = pack2bf(r[2], r[3]);
-      o.z = pack2bf(r[4], r[5]); o.w = pack2bf(r[6], r[7]);
-      *(uint4*)(orow + vc * 8) = o;
+        for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; q += d * d; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    bf16_t* orow = out + (long long)(row0 + r) * C;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int vc = lane + k * 64;
+      if (vc < cv) {
+        const float4 g0 = *(const float4*)(gamma + vc * 8), g1 = *(const float4*)(gamma + vc * 8 + 4);
+        const float4 b0 = *(const float4*)(beta + vc * 8), b1 = *(const float4*)(beta + vc * 8 + 4);
+        const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float rr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rr[j] = (v[k][j] - mean) * rstd * gs[j] + bs[j];
+        uint4 o;
+        o.x = pack2bf(rr[0], rr[1]); o.y = pack2bf(rr[2], rr[3]);
+        o.z = pack2bf(rr[4], rr[5]); o.w = pack2bf(rr[6], rr[7]);
+        *(uint4*)(orow + vc * 8) = o;
+      }
     }
   }
 }
@@ -305,10 +313,16 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
     }
     case MG_OP_LAYERNORM: {
       const int M = op->i[0], C = op->i[1];
-      MG_REQUIRE(C % 8 == 0 && C <= 64 * 8 * LN_NV, "layernorm: unsupported C %d", C);
-      MG_LAUNCH(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s,
-                         (const bf16_t*)op->p[0], (const float*)op->p[1], (const float*)op->p[2],
-                         (bf16_t*)op->p[3], M, C, op->f[0]);
+      const int cv = C / 8;
+      MG_REQUIRE(C % 8 == 0 && cv <= 256, "layernorm: unsupported C %d (multiple of 8, <= 2048)", C);
+#define LN_LAUNCH(NV, R)                                                                                   \
+  MG_LAUNCH((layernorm_kernel<NV, R>), dim3((M + 4 * R - 1) / (4 * R)), dim3(256), 0, s, (const bf16_t*)op->p[0], \
+            (const float*)op->p[1], (const float*)op->p[2], (bf16_t*)op->p[3], M, C, op->f[0])
+      if (cv <= 64) LN_LAUNCH(1, 4);
+      else if (cv <= 128) LN_LAUNCH(2, 4);
+      else if (cv <= 192) LN_LAUNCH(3, 2);
+      else LN_LAUNCH(4, 2);
+#undef LN_LAUNCH
       break;
     }
     default: MG_REQUIRE(false, "norm: bad op kind %d", op->kind);

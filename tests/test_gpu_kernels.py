@@ -90,6 +90,9 @@ CONV_CASES = [
     ("g2_pipe_128x128w8_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 39),
     ("g2_auto_split_n320", 10, 72, 72, 64, 320, 1, 1, None, 0),   # 128k+64 columns: main + 64-wide tail launch
     ("g2_auto_small_m", 2, 12, 12, 128, 640, 1, 1, None, 0),
+    ("g2_128x320", 2, 12, 20, 128, 320, 1, 1, None, 46),
+    ("g2_256x320", 2, 12, 20, 64, 640, 1, 1, None, 47),
+    ("g2_128x320_burst", 1, 12, 12, 320, 320, 1, 1, None, 48),
     ("g2_auto_splitk", 1, 12, 12, 1280, 128, 1, 1, None, 0),        # 6 tiles x 8 K-splits + reduce kernel
     ("g2_auto_splitk_n320", 1, 9, 7, 640, 320, 1, 1, None, 0),
     ("g2_auto_splitk_up2", 1, 6, 6, 1280, 256, 1, 1, (12, 12), 0),
@@ -225,7 +228,7 @@ def test_groupnorm(dev, B, H, W, C, silu, eps):
     _close(f"groupnorm_fused/C{C}", out2.float().permute(0, 3, 1, 2), ref)
 
 
-@pytest.mark.parametrize("M,C", [(37, 64), (200, 320), (50, 1280)])
+@pytest.mark.parametrize("M,C", [(37, 64), (200, 320), (50, 1280), (131, 640), (9, 2048), (1, 1024)])
 def test_layernorm(dev, M, C):
     from marigold_amd import ops
     g = torch.Generator().manual_seed(M)
