@@ -114,11 +114,6 @@ enum mg_op_kind {
    *  p[0] src0 f32 [B|1][C0][H][W]  p[1] src1 f32 [B][C1][H][W] | NULL  p[2] out bf16 [B*H*W][Kp];
    *  i: B,H,W,C0,C1,Kp, src0_broadcast */
   MG_OP_IM2COL_SMALL = 16,
-  /* GroupNorm in ONE launch for small tensors (deep UNet levels, small batches - where the three-
-   * launch form is launch-latency bound): one workgroup per (image, group) computes the statistics
-   * and applies them (+SiLU).  p[0] x bf16 [B][HW][C]  p[1] gamma f32  p[2] beta f32  p[3] out bf16;
-   *  i: B,HW,C,groups,silu ; f[0] eps */
-  MG_OP_GN_FUSED = 17,
   /* Test-time ensembling (marigold/util/ensemble.py).
    * DEPTH_STATS : one pass over [E][HW]: per-member min,max,mean and the centred E x E
    *               second-moment matrix (closed form of the pairwise-RMSE cost, :138-145).

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 #include "../../include/marigold_hip.h"
 
 typedef uint16_t bf16_t;  // raw bf16 bits
@@ -51,6 +53,33 @@ __device__ __forceinline__ void half_swap(float g0, float g1, float& first, floa
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(g0), __float_as_uint(g1), false, false);
   first = __uint_as_float(r[0]);
   second = __uint_as_float(r[1]);
+}
+
+// v_cvt_pk_bf16_f32: two fp32 -> packed bf16 (round to nearest even) in one instruction
+typedef __attribute__((ext_vector_type(2))) __bf16 mg_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float mg_f32x2_t;
+__device__ __forceinline__ uint32_t cvt_pk_bf16_f32(float lo, float hi) {
+  mg_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mg_bf16x2_t));
+}
+__device__ __forceinline__ float silu_fast_f(float x) {  // x * sigmoid(x): one v_exp, one v_rcp
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
+// Sum over the 64 lanes of a wave with DPP moves (VALU speed; __shfl_xor goes through the LDS crossbar
+// - six dependent ds_bpermute round trips per reduction).  Result is wave-uniform.
+__device__ __forceinline__ float wave_sum_f(float v) {
+  auto dpp = [](float x, auto ctrl_tag, auto row_mask_tag) {
+    constexpr int ctrl = decltype(ctrl_tag)::value, rm = decltype(row_mask_tag)::value;
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), ctrl, rm, 0xF, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});   // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});  // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});  // row_mirror: 16-lane row sums
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});  // row_bcast15 -> rows 1, 3
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});  // row_bcast31 -> rows 2, 3
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
 }
 
 // 16-byte async global -> LDS copy.  LDS destination = wave-uniform base + lane*16.

@@ -174,19 +174,8 @@ class Builder:
         self.seq.add(op, label)
 
     # ---- primitive layers ----------------------------------------------------------------
-    # single-launch GroupNorm (MG_OP_GN_FUSED): measured SLOWER than the three-launch form down to the
-    # smallest UNet tensors (strided 4-byte accesses; E=1: 20 -> 26 ms of GroupNorm per map), so it is off
-    # single-launch GroupNorm (MG_OP_GN_FUSED): measured SLOWER than the three-launch form even on the
-    # smallest UNet tensors (strided 4-byte accesses; E=1: 20 -> 26 ms of GroupNorm per map) -> off
-    GN_FUSED_MAX_ELEMS = 0
-
     def group_norm(self, x, name, eps, silu):
         C, B, HW = x.C, x.B, x.HW
-        if B * HW * C <= self.GN_FUSED_MAX_ELEMS and (C // self.groups) % 2 == 0:
-            out = self.new(x.B, x.H, x.W, C)
-            self.add(O.gn_fused(x.t, self.ws.vec(f"{name}.weight"), self.ws.vec(f"{name}.bias"), out.t, B=B, HW=HW,
-                                C=C, groups=self.groups, silu=silu, eps=eps), f"{name}.fused")
-            return out
         # ~768 (chunk, image) blocks: covers the 256 CUs three times over while keeping the
         # second-level reduction (gn_finalize) short; >= 32 rows per chunk
         chunks = max(1, min(HW // 32, max(16, 768 // B)))

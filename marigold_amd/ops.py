@@ -70,10 +70,6 @@ def gn_apply(x, ss, out, *, B, HW, C, silu):
     return make_op(L.OP_GN_APPLY, i=[B, HW, C, int(silu)], p=[x, ss, out])
 
 
-def gn_fused(x, gamma, beta, out, *, B, HW, C, groups, silu, eps):
-    return make_op(L.OP_GN_FUSED, i=[B, HW, C, groups, int(silu)], f=[eps], p=[x, gamma, beta, out])
-
-
 def layernorm(x, gamma, beta, out, *, M, C, eps=1e-5):
     return make_op(L.OP_LAYERNORM, i=[M, C], f=[eps], p=[x, gamma, beta, out])
 

@@ -10,7 +10,7 @@ HBM_PEAK_GBS = 8000.0       # HBM3E spec (6.29 TB/s measured streaming)
 
 CLASS = {
     L.OP_IGEMM: "igemm_mfma", L.OP_FLASH_ATTN64: "flash_attn64", L.OP_GN_STATS: "groupnorm",
-    L.OP_GN_FINALIZE: "groupnorm", L.OP_GN_APPLY: "groupnorm", L.OP_GN_FUSED: "groupnorm", L.OP_LAYERNORM: "layernorm",
+    L.OP_GN_FINALIZE: "groupnorm", L.OP_GN_APPLY: "groupnorm", L.OP_LAYERNORM: "layernorm",
     L.OP_SOFTMAX_ROWS: "softmax", L.OP_SOFTMAX_PAIRS: "softmax",
     L.OP_CONV_CIN_SMALL: "boundary_conv", L.OP_CONV_COUT_SMALL: "boundary_conv",
     L.OP_CONCAT_C: "concat", L.OP_SCHED_STEP: "scheduler_step", L.OP_LINEAR_SMALL_M: "time_embedding",
@@ -41,8 +41,6 @@ def op_cost(op):
         byts = 4 * B * heads * T * 64 * 2
     elif k == L.OP_GN_STATS:
         byts = i[0] * i[1] * i[2] * 2
-    elif k == L.OP_GN_FUSED:
-        byts = 3 * i[0] * i[1] * i[2] * 2
     elif k == L.OP_GN_APPLY:
         byts = 2 * i[0] * i[1] * i[2] * 2
     elif k == L.OP_LAYERNORM:

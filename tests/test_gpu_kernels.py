@@ -222,10 +222,6 @@ def test_groupnorm(dev, B, H, W, C, silu, eps):
                ops.gn_apply(xd, ss, out, B=B, HW=HW, C=C, silu=silu)):
         _run(op)
     _close(f"groupnorm/C{C}", out.float().permute(0, 3, 1, 2), ref)
-    # the single-launch form used for small tensors
-    out2 = torch.full_like(xd, float("nan"))
-    _run(ops.gn_fused(xd, gamma.to(dev), beta.to(dev), out2, B=B, HW=HW, C=C, groups=32, silu=silu, eps=eps))
-    _close(f"groupnorm_fused/C{C}", out2.float().permute(0, 3, 1, 2), ref)
 
 
 @pytest.mark.parametrize("M,C", [(37, 64), (200, 320), (50, 1280), (131, 640), (9, 2048), (1, 1024)])
