@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
       if (vc >= cv) break;
       const bf16_t* col = xb + vc * 8;
       int r = r0 + ty;
-      for (; r + 3 * tyn < r1; r += 4 * tyn) {  // 4 independent 16-byte loads in flight
+      for (; r + 3 * tyn < r1; r += 4 * tyn) {  // 4 independent 16-byte loads in flight (8 measured slower)
         const uint4 u0 = *(const uint4*)(col + (long long)r * C);
         const uint4 u1 = *(const uint4*)(col + (long long)(r + tyn) * C);
         const uint4 u2 = *(const uint4*)(col + (long long)(r + 2 * tyn) * C);
@@ -176,59 +176,72 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ beta,
                                                         bf16_t* __restrict__ out, int M, int C,
                                                         float eps) {
-  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  constexpr int G = 4;  // row groups per wave: gamma / beta are loaded once per G*R rows
   const int lane = threadIdx.x & 63;
-  if (row0 >= M) return;
   const int cv = C >> 3;
-  uint4 u[R][NV];
+  float gs[NV][8], bs[NV][8];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int row = min(row0 + r, M - 1);
-    const bf16_t* xr = x + (long long)row * C;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int vc = lane + k * 64;
-      u[r][k] = vc < cv ? *(const uint4*)(xr + vc * 8) : make_uint4(0, 0, 0, 0);
+  for (int k = 0; k < NV; ++k) {
+    const int vc = lane + k * 64;
+    if (vc < cv) {
+      const float4 g0 = *(const float4*)(gamma + vc * 8), g1 = *(const float4*)(gamma + vc * 8 + 4);
+      const float4 b0 = *(const float4*)(beta + vc * 8), b1 = *(const float4*)(beta + vc * 8 + 4);
+      gs[k][0] = g0.x; gs[k][1] = g0.y; gs[k][2] = g0.z; gs[k][3] = g0.w;
+      gs[k][4] = g1.x; gs[k][5] = g1.y; gs[k][6] = g1.z; gs[k][7] = g1.w;
+      bs[k][0] = b0.x; bs[k][1] = b0.y; bs[k][2] = b0.z; bs[k][3] = b0.w;
+      bs[k][4] = b1.x; bs[k][5] = b1.y; bs[k][6] = b1.z; bs[k][7] = b1.w;
     }
   }
+  const int wrow0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (G * R);
+  for (int grp = 0; grp < G; ++grp) {
+    const int row0 = wrow0 + grp * R;
+    if (row0 >= M) return;
+    uint4 u[R][NV];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if (row0 + r >= M) break;
-    float v[NV][8];
-    float s = 0.f;
+    for (int r = 0; r < R; ++r) {
+      const int row = min(row0 + r, M - 1);
+      const bf16_t* xr = x + (long long)row * C;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      v[k][0] = bflo(u[r][k].x); v[k][1] = bfhi(u[r][k].x); v[k][2] = bflo(u[r][k].y); v[k][3] = bfhi(u[r][k].y);
-      v[k][4] = bflo(u[r][k].z); v[k][5] = bfhi(u[r][k].z); v[k][6] = bflo(u[r][k].w); v[k][7] = bfhi(u[r][k].w);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[k][j];   // padding vectors are zero
-    }
-    const float mean = wave_sum_f(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      if (lane + k * 64 < cv) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; q += d * d; }
+      for (int k = 0; k < NV; ++k) {
+        const int vc = lane + k * 64;
+        u[r][k] = vc < cv ? *(const uint4*)(xr + vc * 8) : make_uint4(0, 0, 0, 0);
       }
     }
-    const float rstd = rsqrtf(wave_sum_f(q) / (float)C + eps);
-    bf16_t* orow = out + (long long)(row0 + r) * C;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int vc = lane + k * 64;
-      if (vc < cv) {
-        const float4 g0 = *(const float4*)(gamma + vc * 8), g1 = *(const float4*)(gamma + vc * 8 + 4);
-        const float4 b0 = *(const float4*)(beta + vc * 8), b1 = *(const float4*)(beta + vc * 8 + 4);
-        const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        float rr[8];
+    for (int r = 0; r < R; ++r) {
+      if (row0 + r >= M) break;
+      float v[NV][8];
+      float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rr[j] = (v[k][j] - mean) * rstd * gs[j] + bs[j];
-        uint4 o;
-        o.x = cvt_pk_bf16_f32(rr[0], rr[1]); o.y = cvt_pk_bf16_f32(rr[2], rr[3]);
-        o.z = cvt_pk_bf16_f32(rr[4], rr[5]); o.w = cvt_pk_bf16_f32(rr[6], rr[7]);
-        *(uint4*)(orow + vc * 8) = o;
+      for (int k = 0; k < NV; ++k) {
+        v[k][0] = bflo(u[r][k].x); v[k][1] = bfhi(u[r][k].x); v[k][2] = bflo(u[r][k].y); v[k][3] = bfhi(u[r][k].y);
+        v[k][4] = bflo(u[r][k].z); v[k][5] = bfhi(u[r][k].z); v[k][6] = bflo(u[r][k].w); v[k][7] = bfhi(u[r][k].w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[k][j];   // padding vectors are zero
+      }
+      const float mean = wave_sum_f(s) / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        if (lane + k * 64 < cv) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; q += d * d; }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum_f(q) / (float)C + eps);
+      bf16_t* orow = out + (long long)(row0 + r) * C;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int vc = lane + k * 64;
+        if (vc < cv) {
+          float rr[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rr[j] = (v[k][j] - mean) * rstd * gs[k][j] + bs[k][j];
+          uint4 o;
+          o.x = cvt_pk_bf16_f32(rr[0], rr[1]); o.y = cvt_pk_bf16_f32(rr[2], rr[3]);
+          o.z = cvt_pk_bf16_f32(rr[4], rr[5]); o.w = cvt_pk_bf16_f32(rr[6], rr[7]);
+          *(uint4*)(orow + vc * 8) = o;
+        }
       }
     }
   }
@@ -271,7 +284,7 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
       const int cv = C / 8;
       MG_REQUIRE(C % 8 == 0 && cv <= 256, "layernorm: unsupported C %d (multiple of 8, <= 2048)", C);
 #define LN_LAUNCH(NV, R)                                                                                   \
-  MG_LAUNCH((layernorm_kernel<NV, R>), dim3((M + 4 * R - 1) / (4 * R)), dim3(256), 0, s, (const bf16_t*)op->p[0], \
+  MG_LAUNCH((layernorm_kernel<NV, R>), dim3((M + 16 * R - 1) / (16 * R)), dim3(256), 0, s, (const bf16_t*)op->p[0], \
             (const float*)op->p[1], (const float*)op->p[2], (bf16_t*)op->p[3], M, C, op->f[0])
       if (cv <= 64) LN_LAUNCH(1, 4);
       else if (cv <= 128) LN_LAUNCH(2, 4);

@@ -39,15 +39,15 @@ for (M, C) in ((92160, 320), (23040, 640), (5760, 1280), (92160, 640)):
     t = timeit(lambda: O.launch(op))
     print(f"layernorm {2 * nbytes / t / 1e9:7.0f} GB/s ({t * 1e6:.1f} us)", end="  ")
     B, HW = 10, M // 10
-    chunks = max(1, min(HW // 32, max(16, 768 // B)))
-    part = torch.empty(B, chunks, C, 2, device=dev)
     ss = torch.empty(B, 2, C, device=dev)
-    op = O.gn_stats(x, part, B=B, HW=HW, C=C, chunks=chunks)
-    t = timeit(lambda: O.launch(op))
-    print(f"gn_stats {nbytes / t / 1e9:7.0f} GB/s ({t * 1e6:.1f} us)", end="  ")
-    op = O.gn_finalize(part, g, b, ss, B=B, C=C, groups=32, chunks=chunks, HW=HW, eps=1e-5)
-    t = timeit(lambda: O.launch(op))
-    print(f"gn_finalize {t * 1e6:.1f} us", end="  ")
+    for target in (256, 384, 512, 768):
+        chunks = max(1, min(HW // 32, max(16, target // B)))
+        part = torch.empty(B, chunks, C, 2, device=dev)
+        op = O.gn_stats(x, part, B=B, HW=HW, C=C, chunks=chunks)
+        t = timeit(lambda: O.launch(op))
+        op2 = O.gn_finalize(part, g, b, ss, B=B, C=C, groups=32, chunks=chunks, HW=HW, eps=1e-5)
+        t2 = timeit(lambda: O.launch(op2))
+        print(f"gn_stats[{target}] {nbytes / t / 1e9:5.0f} GB/s ({t * 1e6:.1f}+{t2 * 1e6:.1f} us)", end="  ")
     op = O.gn_apply(x, ss, y, B=B, HW=HW, C=C, silu=True)
     t = timeit(lambda: O.launch(op))
     print(f"gn_apply {2 * nbytes / t / 1e9:7.0f} GB/s ({t * 1e6:.1f} us)")
