@@ -517,7 +517,7 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   b.ws = nullptr;
   const long long tiles = (long long)b.tiles_m * b.tiles_n;
   if (!TRANS && a.splits == 0 && batch_z == 1 && a.epi == MG_EPI_BF16 && a.n_begin == 0 && a.n_end == a.N &&
-      tiles < 160 && a.KT >= 32 && g_splitk_ws) {
+      tiles < 160 && a.KT >= 32 && g_splitk_ws) {   // (a wider window, < 256 tiles, measured no gain)
     int sp = (int)min((long long)8, (320 + tiles - 1) / tiles);
     sp = min(sp, a.KT / 12);
     while (sp > 1 && (long long)sp * a.M * a.N * 4 > MG_SPLITK_WS_BYTES) --sp;
