@@ -158,6 +158,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    from marigold_amd.util.host import usable_cores
+    torch.set_num_threads(max(1, min(32, usable_cores() // max(1, world))))   # weight synthesis is the only host-heavy part
     import marigold_amd as M
     from marigold_amd import opstats, synthetic as syn
     from marigold_amd.arch import TINY_UNET, TINY_VAE, UNetConfig, VAEConfig
