@@ -132,6 +132,12 @@ enum mg_op_kind {
   MG_OP_ENS_DEPTH_MEDIAN = 21,
   MG_OP_ENS_DEPTH_NORM = 22,
   MG_OP_ENS_NORMALS = 23,
+  /* Image resampling either side of the path (marigold/util/image_util.py:90-120, marigold_depth_
+   * pipeline.py:306-312, ensemble.py:158-161): torchvision resize(..., antialias=True) semantics.
+   *  p[0] src  p[1] dst  p[2] f32 temporary [planes][Hin][Wout] (needed when both sizes change) ;
+   *  i: planes (= B*C), Hin, Win, Hout, Wout, mode (0 bilinear, 1 bicubic, 2 nearest-exact),
+   *  dtype (1: uint8 in/out - computed in float, rounded half-to-even; 0: fp32) */
+  MG_OP_RESIZE = 24,
   MG_OP_MEMSET = 30, /* p[0] dst ; i[0] byte value ; l[0] bytes */
   MG_OP_COPY = 31    /* p[0] src p[1] dst ; l[0] bytes (device to device) */
 };

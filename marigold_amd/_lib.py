@@ -17,6 +17,7 @@ OP_FLASH_ATTN64, OP_SOFTMAX_ROWS, OP_SOFTMAX_PAIRS = 6, 7, 8
 OP_CONV_CIN_SMALL, OP_CONV_COUT_SMALL, OP_CONCAT_C, OP_SCHED_STEP = 9, 10, 11, 12
 OP_LINEAR_SMALL_M, OP_LATENT_1X1, OP_POST_NCHW, OP_IM2COL_SMALL = 13, 14, 15, 16
 OP_ENS_DEPTH_STATS, OP_ENS_DEPTH_MEDIAN, OP_ENS_DEPTH_NORM, OP_ENS_NORMALS = 20, 21, 22, 23
+OP_RESIZE = 24
 OP_MEMSET, OP_COPY = 30, 31
 EPI_BF16, EPI_GEGLU, EPI_F32 = 0, 1, 2
 POST_NONE, POST_DEPTH, POST_NORMALS = 0, 1, 2

@@ -57,6 +57,7 @@ static int dispatch(const mg_op* op, hipStream_t s) {
     case MG_OP_ENS_DEPTH_MEDIAN:
     case MG_OP_ENS_DEPTH_NORM:
     case MG_OP_ENS_NORMALS: return mg_launch_ensemble(op, s);
+    case MG_OP_RESIZE: return mg_launch_resize(op, s);
     default: mg_set_error("mg_launch: unknown op kind %d", op->kind); return 2;
   }
 }

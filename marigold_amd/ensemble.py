@@ -184,7 +184,8 @@ def ensemble_depth(depth, scale_invariant=True, shift_invariant=True, output_unc
         d_align = d
         if max_res is not None and max(H, W) > max_res:
             f = min(max_res / W, max_res / H)
-            d_align = torch.nn.functional.interpolate(d, (int(H * f), int(W * f)), mode="nearest-exact")
+            from .util.image_util import InterpolationMode, resize
+            d_align = resize(d, (int(H * f), int(W * f)), InterpolationMode.NEAREST_EXACT)
         al = DepthAligner(d_align, scale_invariant, shift_invariant, reduction, regularizer_strength)
         p0 = al.init_param()
         res = scipy.optimize.minimize(al.reference_fd_objective, p0, jac=True, method="BFGS", tol=tol,

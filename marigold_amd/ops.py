@@ -137,6 +137,10 @@ def ens_normals(n, out, unc, *, E, HW, reduction=0):
     return make_op(L.OP_ENS_NORMALS, i=[E, reduction], p=[n, out, unc], l=[HW])
 
 
+def resize(src, dst, tmp, *, planes, Hin, Win, Hout, Wout, mode, u8):
+    return make_op(L.OP_RESIZE, i=[planes, Hin, Win, Hout, Wout, mode, int(u8)], p=[src, dst, tmp])
+
+
 def memset(dst, nbytes, value=0):
     return make_op(L.OP_MEMSET, i=[value], p=[dst], l=[nbytes])
 

@@ -15,7 +15,7 @@ CLASS = {
     L.OP_CONV_CIN_SMALL: "boundary_conv", L.OP_CONV_COUT_SMALL: "boundary_conv",
     L.OP_CONCAT_C: "concat", L.OP_SCHED_STEP: "scheduler_step", L.OP_LINEAR_SMALL_M: "time_embedding",
     L.OP_LATENT_1X1: "boundary_conv", L.OP_POST_NCHW: "boundary_conv", L.OP_IM2COL_SMALL: "boundary_conv", L.OP_ENS_DEPTH_STATS: "ensemble", L.OP_ENS_DEPTH_MEDIAN: "ensemble",
-    L.OP_ENS_DEPTH_NORM: "ensemble", L.OP_ENS_NORMALS: "ensemble", L.OP_MEMSET: "memops", L.OP_COPY: "memops",
+    L.OP_ENS_DEPTH_NORM: "ensemble", L.OP_ENS_NORMALS: "ensemble", L.OP_RESIZE: "resize", L.OP_MEMSET: "memops", L.OP_COPY: "memops",
 }
 BOUND = {"igemm_mfma": "mfma", "flash_attn64": "mfma"}   # everything else is HBM-bound streaming
 

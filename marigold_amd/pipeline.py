@@ -214,6 +214,8 @@ class _MarigoldPipelineBase:
         input_size = rgb.shape
         assert 4 == rgb.dim() and 3 == input_size[-3], f"Wrong input shape {input_size}, expected [1, rgb, H, W]"
         if processing_res > 0:
+            if max(input_size[-2:]) != processing_res and self.device.type == "cuda":
+                rgb = rgb.to(self.device)   # resample on the device (csrc/resize.hip)
             rgb = resize_max_res(rgb, max_edge_resolution=processing_res, resample_method=resample_method)
         rgb_norm = rgb / 255.0 * 2.0 - 1.0
         rgb_norm = rgb_norm.to(self.dtype)

@@ -4,7 +4,9 @@ torch.nn.functional because torchvision is not a dependency here.
 ``resize`` reproduces torchvision.transforms.functional.resize(img, size, mode, antialias=True)
 (SURVEY.md App. C.8): == F.interpolate(..., align_corners=False, antialias=True); uint8 inputs are
 computed in float, rounded and cast back; the input is returned unchanged when the size already
-matches; NEAREST_EXACT == mode "nearest-exact".
+matches; NEAREST_EXACT == mode "nearest-exact".  CUDA tensors (uint8 / fp32) go through the HIP
+resampling kernels (csrc/resize.hip, MG_OP_RESIZE); host tensors use torch's CPU implementation,
+which is also the parity reference of the kernels.
 """
 import enum
 
@@ -18,11 +20,31 @@ class InterpolationMode(enum.Enum):
     NEAREST_EXACT = "nearest-exact"
 
 
+_HIP_MODES = {"bilinear": 0, "bicubic": 1, "nearest-exact": 2}
+
+
+def _resize_hip(img, h, w, mode):
+    """Device path (csrc/resize.hip): uint8 or fp32 CUDA tensors [..., H, W]."""
+    from .. import ops as O
+    src = img.contiguous()
+    planes = src.numel() // (src.shape[-2] * src.shape[-1])
+    Hin, Win = src.shape[-2:]
+    dst = torch.empty(src.shape[:-2] + (h, w), dtype=src.dtype, device=src.device)
+    tmp = None
+    if mode != "nearest-exact" and Hin != h and Win != w:
+        tmp = torch.empty(planes * Hin * w, dtype=torch.float32, device=src.device)
+    O.launch(O.resize(src, dst, tmp, planes=planes, Hin=Hin, Win=Win, Hout=h, Wout=w, mode=_HIP_MODES[mode],
+                      u8=src.dtype == torch.uint8))
+    return dst
+
+
 def resize(img: torch.Tensor, size, interpolation=InterpolationMode.BILINEAR, antialias=True):
     h, w = int(size[0]), int(size[1])
     if tuple(img.shape[-2:]) == (h, w):
         return img
     mode = interpolation.value
+    if img.is_cuda and antialias and img.dtype in (torch.uint8, torch.float32):
+        return _resize_hip(img, h, w, mode)
     if mode == "nearest-exact":
         return torch.nn.functional.interpolate(img, size=(h, w), mode=mode)
     x = img

@@ -523,3 +523,28 @@ def test_small_cin_conv_on_mfma_path(dev):
                               bcast0=bcast))
         _run(ops.linear(col, wp.to(dev, torch.bfloat16), out, M=B * H * W, K=kp, N=Cout, bias=bias.to(dev)))
         _close(f"small_cin_mfma/{C0}+{C1}->{Cout}", out.float().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic", "nearest-exact"])
+def test_resize_vs_torch_cpu(dev, mode):
+    """MG_OP_RESIZE vs torch's CPU F.interpolate(antialias=True) (what torchvision's resize runs): down-
+    and up-sampling, one axis only, uint8 round trip (reference: image_util.py:90-120, :306-312)."""
+    from marigold_amd.util.image_util import InterpolationMode, resize
+    g = torch.Generator().manual_seed(4)
+    im = {m.value: m for m in InterpolationMode}[mode]
+    cases = [((1, 3, 96, 128), (72, 96)), ((1, 3, 50, 70), (100, 140)), ((1, 1, 64, 48), (64, 31)),
+             ((2, 3, 33, 40), (77, 40)), ((1, 3, 480, 640), (576, 768)), ((1, 1, 768, 576), (480, 360))]
+    for shape, size in cases:
+        xf = torch.rand(shape, generator=g) * 2 - 1
+        xu = (torch.rand(shape, generator=g) * 255).round().to(torch.uint8)
+        for x in (xf, xu):
+            ref = resize(x, size, im)            # host path = torch CPU
+            got = resize(x.to(dev), size, im).cpu()
+            assert got.shape == ref.shape and got.dtype == ref.dtype
+            if mode == "nearest-exact":
+                assert torch.equal(got, ref)
+            elif x.dtype == torch.uint8:
+                d = (got.int() - ref.int()).abs()
+                assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-3, (shape, size, int(d.max()))
+            else:
+                assert float((got - ref).abs().max()) < 2e-5, (shape, size, float((got - ref).abs().max()))
