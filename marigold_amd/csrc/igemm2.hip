@@ -59,13 +59,22 @@ __device__ __forceinline__ void wait_vmcnt() {
 // together - a burst leaves every SIMD's matrix pipe idle at the same time).
 // ABL (tuning sweeps only; results are WRONG for ABL != 0): 1 = no LDS-DMA in the steady state,
 // 2 = fragment reads but no MFMAs, 3 = MFMAs on fixed registers (no fragment reads).
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, bool PF, int ABL = 0>
+// BK: K-tile depth (64: 128-byte LDS rows; 32: 64-byte rows, half the LDS per stage - lets two 4-wave
+// workgroups with 128x64 wave tiles share a CU).
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, bool PF, int ABL = 0, int BK = 64>
 __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args a) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
-  constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
+  constexpr int ROWB = BK * 2;        // bytes per LDS row (one pixel's / one weight row's K tile)
+  constexpr int CPR = BK / 8;         // 16-byte chunks per row
+  constexpr int KS = BK / 16;         // MFMA k-substeps per K tile
+  constexpr int A_IT = BM * CPR / NT, B_IT = BN * CPR / NT;
   constexpr int LOADS = A_IT + B_IT;  // LDS-DMA instructions per wave per K tile
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  static_assert(BK == 64 || BK == 32, "BK is 64 or 32");
+  // XOR swizzle of the 16-byte chunk index (applied on the DMA source address and on the fragment
+  // read): conflict-free ds_read_b128 for 128-byte rows (r>>1)&7 and for 64-byte rows (r>>2)&3
+  auto swz = [](int chunk, int r) { return BK == 64 ? (chunk ^ ((r >> 1) & 7)) : (chunk ^ ((r >> 2) & 3)); };
   constexpr int D = NSTAGE - 1;       // prefetch distance (tiles in flight)
   static_assert(A_IT >= 1 && B_IT >= 1 && MI >= 1 && NI >= 1, "tile too small for the block");
   static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
@@ -97,8 +106,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int ci = it * NT + tid;
-    const int r = ci >> 3, p = ci & 7;
-    a_qoff[it] = (p ^ ((r >> 1) & 7)) * 8;
+    const int r = ci / CPR, p = ci % CPR;
+    a_qoff[it] = swz(p, r) * 8;
     const int m = m0 + r;
     const bool ok = m < a.M;
     const int mm = ok ? m : 0;
@@ -113,16 +122,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
     const int ci = it * NT + tid;
-    const int r = ci >> 3, p = ci & 7;
+    const int r = ci / CPR, p = ci % CPR;
     const int n = n0 + r;
-    b_ptr[it] = (n < a.n_end) ? (const char*)(Wb + (long long)n * a.ldw + (p ^ ((r >> 1) & 7)) * 8) : zero;
+    b_ptr[it] = (n < a.n_end) ? (const char*)(Wb + (long long)n * a.ldw + swz(p, r) * 8) : zero;
   }
   const int kt0 = split * a.kps;                                   // this workgroup's K-step range
   const int KT = min(a.KT, kt0 + a.kps) - kt0;
   if (kt0) {
 #pragma unroll
     for (int it = 0; it < B_IT; ++it)
-      if (b_ptr[it] != zero) b_ptr[it] += (long long)kt0 * 128;
+      if (b_ptr[it] != zero) b_ptr[it] += (long long)kt0 * ROWB;
   }
   const char* a_ptr[A_IT];
   const int hb = a.Hu ? a.Hu : a.H, wb = a.Hu ? a.Wu : a.W;  // bounds in (virtual) input space
@@ -146,18 +155,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   if (i_c) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it)
-      if (a_ptr[it] != zero) a_ptr[it] += i_c * 128;
+      if (a_ptr[it] != zero) a_ptr[it] += i_c * ROWB;
   }
   auto issue_piece = [&](int stage, int idx) {  // idx in [0, LOADS): A pieces first, then B pieces
     if constexpr (ABL == 1) return;
     char* sbase = smem + stage * STAGE;
     if (idx < A_IT) {
       glds16(a_ptr[idx], sbase + (idx * NT + wave * 64) * 16);
-      a_ptr[idx] += 128;
+      a_ptr[idx] += ROWB;
     } else {
       const int it = idx - A_IT;
-      glds16(b_ptr[it], sbase + BM * 128 + (it * NT + wave * 64) * 16);
-      b_ptr[it] += 128;
+      glds16(b_ptr[it], sbase + BM * ROWB + (it * NT + wave * 64) * 16);
+      b_ptr[it] += ROWB;
     }
   };
   auto advance = [&]() {
@@ -203,17 +212,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
       for (int ni = 0; ni < NI; ++ni) fb[ni] = __builtin_bit_cast(bf16x8, make_uint4(ks, lane, ni, 2));
       return;
     }
-    const char* sB = sA + BM * 128;
+    const char* sB = sA + BM * ROWB;
     const int q = ks * 2 + half;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int r = rowA[mi];
-      fa[mi] = __builtin_bit_cast(bf16x8, *(const uint4*)(sA + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)));
+      fa[mi] = __builtin_bit_cast(bf16x8, *(const uint4*)(sA + r * ROWB + (swz(q, r) << 4)));
     }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int r = rowB[ni];
-      fb[ni] = __builtin_bit_cast(bf16x8, *(const uint4*)(sB + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)));
+      fb[ni] = __builtin_bit_cast(bf16x8, *(const uint4*)(sB + r * ROWB + (swz(q, r) << 4)));
     }
   };
   auto mfmas = [&](const bf16x8(&fa)[MI], const bf16x8(&fb)[NI]) {
@@ -252,12 +261,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
       if constexpr (!SPLIT && ISSUE) issue(st_i);
       const char* sA = smem + st_c * STAGE;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         bf16x8 fa[MI], fb[NI];
         load_frags(sA, ks, fa, fb);
         if constexpr (SPLIT && ISSUE) {
 #pragma unroll
-          for (int idx = ks; idx < LOADS; idx += 4) issue_piece(st_i, idx);
+          for (int idx = ks; idx < LOADS; idx += KS) issue_piece(st_i, idx);
         }
         mfmas(fa, fb);
       }
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
     //   0,1) | MFMA F1.
     // The profile that motivated it: MFMA, fragment reads and DMA issue of the plain loop add up
     // (0.44 + 0.35 + 0.22 of the step time) instead of overlapping.
-    static_assert(NSTAGE == 3, "the pipelined loop is written for the 3-stage ring");
+    static_assert(NSTAGE == 3 && BK == 64, "the pipelined loop is written for the 3-stage ring, BK = 64");
     bf16x8 fa0[2][MI], fb0[2][NI], fa1[2][MI], fb1[2][NI];
     if (KT > 1) wait_vmcnt<LOADS>();
     else wait_vmcnt<0>();
@@ -496,34 +505,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Igemm2Args a) 
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT = false, bool PF = false, int ABL = 0>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT = false, bool PF = false, int ABL = 0,
+          int BK = 64>
 int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   constexpr int NT = WGM * WGN * 64;
-  constexpr int LDS = NSTAGE * (BM + BN) * 128;
+  constexpr int LDS = NSTAGE * (BM + BN) * BK * 2;
   static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
   static bool attr_set = false;
-  auto kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS, SPLIT, PF, ABL>;
+  auto kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS, SPLIT, PF, ABL, BK>;
   if (!attr_set && !g_dry_run) {
     MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   Igemm2Args b = a;
+  b.cpt = a.Cin / BK;
+  b.KT = a.taps * b.cpt;
   b.tiles_m = (a.M + BM - 1) / BM;
   b.tiles_n = (a.n_end - a.n_begin + BN - 1) / BN;
   // split-K for the deep UNet levels (a few hundred pixels x thousands of input channels): too few
   // output tiles to fill 256 CUs, so the K loop is cut into `splits` workgroups per tile.
   b.splits = 1;
-  b.kps = a.KT;
+  b.kps = b.KT;
   b.ws = nullptr;
   const long long tiles = (long long)b.tiles_m * b.tiles_n;
   if (!TRANS && a.splits == 0 && batch_z == 1 && a.epi == MG_EPI_BF16 && a.n_begin == 0 && a.n_end == a.N &&
-      tiles < 160 && a.KT >= 32 && g_splitk_ws) {   // (a wider window, < 256 tiles, measured no gain)
+      tiles < 160 && b.KT >= 32 && g_splitk_ws) {   // (a wider window, < 256 tiles, measured no gain)
     int sp = (int)min((long long)8, (320 + tiles - 1) / tiles);
-    sp = min(sp, a.KT / 12);
+    sp = min(sp, b.KT / 12);
     while (sp > 1 && (long long)sp * a.M * a.N * 4 > MG_SPLITK_WS_BYTES) --sp;
     if (sp > 1) {
-      b.kps = (a.KT + sp - 1) / sp;
-      b.splits = (a.KT + b.kps - 1) / b.kps;
+      b.kps = (b.KT + sp - 1) / sp;
+      b.splits = (b.KT + b.kps - 1) / b.kps;
       b.ws = (float*)g_splitk_ws;
     }
   }
@@ -561,6 +573,10 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
     case 37: return launch2<128, 64, 2, 2, 3, TRANS, true, true>(a, batch_z, s);
     case 38: return launch2<128, 128, 2, 2, 3, TRANS, true, true>(a, batch_z, s);
     case 39: return launch2<128, 128, 4, 2, 3, TRANS, true, true>(a, batch_z, s);
+    case 50: return launch2<256, 128, 2, 2, 2, TRANS, true, false, 0, 32>(a, batch_z, s);  // BK = 32: 4 waves, wave tile 128x64
+    case 51: return launch2<256, 128, 2, 2, 3, TRANS, true, false, 0, 32>(a, batch_z, s);
+    case 52: return launch2<128, 128, 1, 2, 3, TRANS, true, false, 0, 32>(a, batch_z, s);  // 2 waves, wave tile 128x64
+    case 53: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 0, 32>(a, batch_z, s);  // 8 waves, wave tile 64x64
     case 46: return launch2<128, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);   // full-width tiles for N = 320
     case 47: return launch2<256, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);
     case 48: return launch2<128, 320, 4, 2, 2, TRANS, false>(a, batch_z, s);
@@ -670,9 +686,11 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
 //     (two workgroups per CU) when K <= 1536;
 //   all with the next tile's LDS-DMA pieces issued between the k-substeps' MFMA groups.
 int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
-  (void)geglu;
   if (N <= 32) return 29;
   const long long tm256 = (M + 255) / 256;
+  // short K (GEGLU projections, K = C linears): 256x128 with 32-deep K tiles - half the LDS per stage,
+  // two 8-wave workgroups per CU (GEGLU 525-780 vs 485-770 for 256x256 and 400-700 for the 64-deep tile)
+  if (N % 128 == 0 && tm256 * (N / 128) * batch_z >= 400 && (geglu || K <= 768)) return 53;
   if (N % 256 == 0 && tm256 * (N / 256) * batch_z >= 512) return 34;
   // N = 320 (UNet level 0): a full-width 128x320 tile reads the activation tile once for all output
   // channels (2.1x fewer LDS-DMA bytes per MFMA than 128x64): 900 vs 740 TFLOP/s on the 640->320 convs

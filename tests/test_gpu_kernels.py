@@ -90,6 +90,10 @@ CONV_CASES = [
     ("g2_pipe_128x128w8_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 39),
     ("g2_auto_split_n320", 10, 72, 72, 64, 320, 1, 1, None, 0),   # 128k+64 columns: main + 64-wide tail launch
     ("g2_auto_small_m", 2, 12, 12, 128, 640, 1, 1, None, 0),
+    ("g2_bk32_256x128_w4", 2, 16, 24, 128, 192, 1, 1, None, 50),
+    ("g2_bk32_3stage_stride2", 2, 16, 16, 64, 128, 2, 1, None, 51),
+    ("g2_bk32_128x128_w2", 1, 14, 14, 320, 128, 1, 1, None, 52),
+    ("g2_bk32_w8_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 53),
     ("g2_128x320", 2, 12, 20, 128, 320, 1, 1, None, 46),
     ("g2_256x320", 2, 12, 20, 64, 640, 1, 1, None, 47),
     ("g2_128x320_burst", 1, 12, 12, 320, 320, 1, 1, None, 48),
@@ -138,7 +142,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = torch.randn(N, generator=g) * 0.1
     ref = x @ w.t() + b
-    for variant in (0, 1, 2, 3, 4, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39):
+    for variant in (0, 1, 2, 3, 4, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 46, 50, 51, 52, 53):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N,
                         bias=b.to(dev), variant=variant))
@@ -150,7 +154,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     xg = _bf(torch.randn(200, C, generator=g))
     u, gt = (xg @ wg.t() + bg).chunk(2, dim=-1)
     ref = u * F.gelu(gt)
-    for group, variants in ((16, (1, 3)), (32, (20, 23, 24, 27))):
+    for group, variants in ((16, (1, 3)), (32, (20, 23, 24, 27, 34, 53, 0))):
         wp, bp = Wm.pack_geglu(wg, bg, group)
         for variant in variants:
             out = torch.full((200, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
