@@ -72,6 +72,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   constexpr int LOADS = A_IT + B_IT;  // LDS-DMA instructions per wave per K tile
   constexpr int STAGE = (BM + BN) * ROWB;
   static_assert(BK == 64 || BK == 32, "BK is 64 or 32");
+  static_assert((BM * CPR) % NT == 0 && (BN * CPR) % NT == 0, "every thread stages a whole number of 16-byte chunks");
   // XOR swizzle of the 16-byte chunk index (applied on the DMA source address and on the fragment
   // read): conflict-free ds_read_b128 for 128-byte rows (r>>1)&7 and for 64-byte rows (r>>2)&3
   auto swz = [](int chunk, int r) { return BK == 64 ? (chunk ^ ((r >> 1) & 7)) : (chunk ^ ((r >> 2) & 3)); };
