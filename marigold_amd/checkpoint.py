@@ -45,7 +45,22 @@ def _rename_legacy_vae_keys(sd):
     return out
 
 
+def _resolve(path):
+    """A local checkpoint folder, or a hub id already present in the local Hugging Face cache (the
+    reference passes ids like ``prs-eth/marigold-depth-v1-1``; nothing is downloaded here)."""
+    if os.path.isdir(path):
+        return path
+    try:
+        from huggingface_hub import snapshot_download
+        return snapshot_download(path, local_files_only=True)
+    except Exception as e:  # noqa: BLE001
+        raise FileNotFoundError(
+            f"checkpoint '{path}' is neither a local folder nor in the local Hugging Face cache ({type(e).__name__}); "
+            f"download it first (script/download_weights.sh in the reference) and pass the folder") from e
+
+
 def load_pipeline(cls, path, variant=None, torch_dtype=None, **kw):
+    path = _resolve(path)
     index = _json(os.path.join(path, "model_index.json"))
     ucfg = _json(os.path.join(path, "unet", "config.json"))
     unet_cfg = UNetConfig(in_channels=ucfg.get("in_channels", 8), out_channels=ucfg.get("out_channels", 4),

@@ -373,3 +373,9 @@ def test_cli_flags_and_output_formats(tmp_path):
     assert (out / "normals_vis" / "a_normals.png").exists()
     assert cli.main("depth", ["--input_rgb_dir", str(tmp_path / "out"), "--output_dir", str(out)],
                     pipeline=FakeDepth()) == 1   # no images -> exit code 1 like the reference
+
+
+def test_from_pretrained_without_checkpoint_fails_clearly():
+    import marigold_amd as M
+    with pytest.raises(FileNotFoundError, match="neither a local folder nor in the local Hugging Face cache"):
+        M.MarigoldDepthPipeline.from_pretrained("prs-eth/marigold-depth-v1-1")
