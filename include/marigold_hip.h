@@ -143,7 +143,7 @@ enum mg_op_kind {
 };
 
 enum { MG_EPI_BF16 = 0, MG_EPI_GEGLU = 1, MG_EPI_F32 = 2 };
-enum { MG_POST_NONE = 0, MG_POST_DEPTH = 1, MG_POST_NORMALS = 2 };
+enum { MG_POST_NONE = 0, MG_POST_DEPTH = 1, MG_POST_NORMALS = 2, MG_POST_UNIT = 3 /* IID: clip, (x+1)/2 */ };
 
 typedef struct mg_op {
   int32_t kind;

@@ -1,7 +1,7 @@
 """marigold_amd - MI355X-native engine for the Marigold inference hot path, behind the
 reference's pipeline API (exports mirror /root/reference/marigold/__init__.py:31-41)."""
-from .pipeline import (MarigoldDepthOutput, MarigoldDepthPipeline,  # noqa: F401
-                       MarigoldNormalsOutput, MarigoldNormalsPipeline)
+from .pipeline import (IIDEntry, MarigoldDepthOutput, MarigoldDepthPipeline,  # noqa: F401
+                       MarigoldIIDOutput, MarigoldIIDPipeline, MarigoldNormalsOutput, MarigoldNormalsPipeline)
 
 MarigoldPipeline = MarigoldDepthPipeline  # for backward compatibility
 

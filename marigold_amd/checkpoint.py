@@ -91,10 +91,12 @@ def load_pipeline(cls, path, variant=None, torch_dtype=None, **kw):
         text_encoder = CLIPTextModel.from_pretrained(os.path.join(path, "text_encoder"))
         tokenizer = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
     extra = {k: index[k] for k in ("scale_invariant", "shift_invariant", "default_denoising_steps",
-                                   "default_processing_resolution") if k in index}
-    if cls.__name__ == "MarigoldNormalsPipeline":
+                                   "default_processing_resolution", "target_properties") if k in index}
+    if cls.__name__ != "MarigoldDepthPipeline":
         extra.pop("scale_invariant", None)
         extra.pop("shift_invariant", None)
+    if cls.__name__ != "MarigoldIIDPipeline":
+        extra.pop("target_properties", None)
     return cls(unet=unet, vae=vae, scheduler=scheduler, text_encoder=text_encoder, tokenizer=tokenizer,
                empty_text_embed=empty, **extra)
 

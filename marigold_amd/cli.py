@@ -7,6 +7,9 @@ the same minus ``--color_map``):
             <out>/depth_colored/<name>_depth_colored.png
   normals : <out>/normals_npy/<name>_normals.npy  float32 [3,H,W] in [-1,1]
             <out>/normals_vis/<name>_normals.png   (n + 1) * 127.5
+  iid     : <out>/iid_{appearance|lighting}_npy/<name>_<target>.npy  float32 [H,W,3] in [0,1]
+            <out>/iid_{appearance|lighting}_vis/<name>_<target>.png  (script/iid/run.py:160-166, :260-270;
+            the folder flavour is picked from the checkpoint name like the reference does)
 
 Differences: the engine only runs on an MI355X (there is no CPU / MPS path: ``--apple_silicon`` is
 accepted and refused), and ``--half_precision`` selects the ``fp16`` weight variant of the checkpoint
@@ -21,9 +24,11 @@ import numpy as np
 from PIL import Image
 
 EXTENSION_LIST = (".jpg", ".jpeg", ".png")
-_DEFAULT_CKPT = {"depth": "prs-eth/marigold-depth-v1-1", "normals": "prs-eth/marigold-normals-v1-1"}
+_DEFAULT_CKPT = {"depth": "prs-eth/marigold-depth-v1-1", "normals": "prs-eth/marigold-normals-v1-1",
+                 "iid": "prs-eth/marigold-iid-appearance-v1-1"}
 _TITLE = {"depth": "Marigold : Monocular Depth Estimation : Multi-image Inference",
-          "normals": "Marigold : Surface Normals Estimation : Multi-image Inference"}
+          "normals": "Marigold : Surface Normals Estimation : Multi-image Inference",
+          "iid": "Marigold : Intrinsic Image Decomposition : Multi-image Inference"}
 
 
 def build_parser(kind: str) -> argparse.ArgumentParser:
@@ -54,9 +59,14 @@ def list_images(folder):
     return files
 
 
-def output_dirs(kind, output_dir):
-    sub = ("depth_colored", "depth_bw", "depth_npy") if kind == "depth" else ("normals_vis", "normals_npy")
-    dirs = {s: os.path.join(output_dir, s) for s in sub}
+def output_dirs(kind, output_dir, checkpoint=""):
+    if kind == "iid":
+        flavour = "appearance" if "appearance" in checkpoint else "lighting"
+        dirs = {"iid_vis": os.path.join(output_dir, f"iid_{flavour}_vis"),
+                "iid_npy": os.path.join(output_dir, f"iid_{flavour}_npy")}
+    else:
+        sub = ("depth_colored", "depth_bw", "depth_npy") if kind == "depth" else ("normals_vis", "normals_npy")
+        dirs = {s: os.path.join(output_dir, s) for s in sub}
     for d in (output_dir, *dirs.values()):
         os.makedirs(d, exist_ok=True)
     return dirs
@@ -85,6 +95,15 @@ def save_prediction(kind, dirs, rgb_path, out):
             p = os.path.join(dirs["depth_colored"], f"{name}_colored.png")
             _save(p, out.depth_colored.save)
             written.append(p)
+    elif kind == "iid":
+        for entry in out:
+            arr = np.moveaxis(entry.array, 0, -1)   # chw2hwc
+            p = os.path.join(dirs["iid_npy"], f"{base}_{entry.name}.npy")
+            _save(p, lambda q: np.save(q, arr))
+            written.append(p)
+            p = os.path.join(dirs["iid_vis"], f"{base}_{entry.name}.png")
+            _save(p, entry.image.save)
+            written.append(p)
     else:
         name = base + "_normals"
         p = os.path.join(dirs["normals_npy"], f"{name}.npy")
@@ -109,7 +128,7 @@ def main(kind: str, argv=None, pipeline=None) -> int:
                         "same resolution, due to the padding and pooling properties of conv layers.")
     if args.apple_silicon:
         raise RuntimeError("--apple_silicon: this engine runs on an AMD MI355X only")
-    dirs = output_dirs(kind, args.output_dir)
+    dirs = output_dirs(kind, args.output_dir, args.checkpoint)
     logging.info(f"output dir = {args.output_dir}")
     files = list_images(args.input_rgb_dir)
     if not files:
@@ -120,7 +139,8 @@ def main(kind: str, argv=None, pipeline=None) -> int:
         if not torch.cuda.is_available():
             raise RuntimeError("no MI355X visible: the Marigold HIP engine has no CPU fallback")
         import marigold_amd as M
-        cls = M.MarigoldDepthPipeline if kind == "depth" else M.MarigoldNormalsPipeline
+        cls = {"depth": M.MarigoldDepthPipeline, "normals": M.MarigoldNormalsPipeline,
+               "iid": M.MarigoldIIDPipeline}[kind]
         pipeline = cls.from_pretrained(args.checkpoint, variant="fp16" if args.half_precision else None,
                                        torch_dtype=torch.float16 if args.half_precision else torch.float32)
         pipeline.enable_xformers_memory_efficient_attention()   # no-op: attention is always the fused kernel
@@ -128,6 +148,8 @@ def main(kind: str, argv=None, pipeline=None) -> int:
     if kind == "depth":
         logging.info(f"Loaded depth pipeline: scale_invariant={pipeline.scale_invariant}, "
                      f"shift_invariant={pipeline.shift_invariant}")
+    elif kind == "iid":
+        logging.info(f"Loaded IID pipeline with predicted target names: {pipeline.target_names}")
     else:
         logging.info("Loaded normals pipeline")
     logging.info(f"Inference settings: checkpoint = `{args.checkpoint}`, with denoise_steps = "

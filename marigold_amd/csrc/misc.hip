@@ -229,11 +229,14 @@ __global__ __launch_bounds__(256) void post_nchw_kernel(const float* __restrict_
        pix += (long long)gridDim.x * 256) {
     const long long b = pix / HW, p = pix - b * HW;
     float acc[COUT];
-    const float4 v0 = *(const float4*)(in + pix * ldi);
-    acc[0] = v0.x * scale;
-    if (COUT > 1) acc[1] = v0.y * scale;
-    if (COUT > 2) acc[2] = v0.z * scale;
-    if (COUT > 3) acc[3] = v0.w * scale;
+#pragma unroll
+    for (int c4 = 0; c4 < COUT; c4 += 4) {
+      const float4 v = *(const float4*)(in + pix * ldi + c4);
+      acc[c4] = v.x * scale;
+      if (c4 + 1 < COUT) acc[c4 + 1] = v.y * scale;
+      if (c4 + 2 < COUT) acc[c4 + 2] = v.z * scale;
+      if (c4 + 3 < COUT) acc[c4 + 3] = v.w * scale;
+    }
     if (post == MG_POST_DEPTH) {
       float m = 0.f;
 #pragma unroll
@@ -251,6 +254,10 @@ __global__ __launch_bounds__(256) void post_nchw_kernel(const float* __restrict_
       const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-6f);
 #pragma unroll
       for (int co = 0; co < COUT; ++co) out[(b * COUT + co) * HW + p] = acc[co] * inv;
+    } else if (post == MG_POST_UNIT) {   // IID: clip to [-1,1], shift to [0,1] (marigold_iid_pipeline.py:523-526)
+#pragma unroll
+      for (int co = 0; co < COUT; ++co)
+        out[(b * COUT + co) * HW + p] = (fminf(fmaxf(acc[co], -1.f), 1.f) + 1.0f) * 0.5f;
     } else {
 #pragma unroll
       for (int co = 0; co < COUT; ++co) out[(b * COUT + co) * HW + p] = acc[co];
@@ -349,9 +356,9 @@ int mg_launch_misc(const mg_op* op, hipStream_t s) {
               (const float*)op->p[1], (bf16_t*)op->p[2], B, H, W, C0, op->i[6]);                   \
     break;                                                                                         \
   }
-      I2C_CASE(3, 64) I2C_CASE(4, 64) I2C_CASE(8, 128)
+      I2C_CASE(3, 64) I2C_CASE(4, 64) I2C_CASE(8, 128) I2C_CASE(12, 128) I2C_CASE(16, 192)
 #undef I2C_CASE
-      MG_REQUIRE(false, "im2col_small: unsupported (Cin %d, Kp %d): (3,64), (4,64) or (8,128)", cin, Kp);
+      MG_REQUIRE(false, "im2col_small: unsupported (Cin %d, Kp %d): (3,64), (4,64), (8,128), (12,128), (16,192)", cin, Kp);
       break;
     }
     case MG_OP_POST_NCHW: {
@@ -365,7 +372,9 @@ int mg_launch_misc(const mg_op* op, hipStream_t s) {
         case 1: MG_LAUNCH(post_nchw_kernel<1>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
         case 3: MG_LAUNCH(post_nchw_kernel<3>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
         case 4: MG_LAUNCH(post_nchw_kernel<4>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
-        default: MG_REQUIRE(false, "post_nchw: unsupported Cout %d (1, 3 or 4)", Cout);
+        case 8: MG_LAUNCH(post_nchw_kernel<8>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
+        case 12: MG_LAUNCH(post_nchw_kernel<12>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
+        default: MG_REQUIRE(false, "post_nchw: unsupported Cout %d (1, 3, 4, 8 or 12)", Cout);
       }
       break;
     }

@@ -96,13 +96,14 @@ class WeightStore:
         return self._memo(("sc", name), lambda: Wm.f32(Wm.pack_small_conv(self.sd[f"{name}.weight"]), self.device))
 
     def small_conv_mfma(self, key, w4, bias):
-        """Cout <= 8 conv3x3 as an MFMA GEMM: weights [Cout,Cin,3,3] -> bf16 [8][9*Cin] (rows >= Cout
-        zero), bias fp32 [8]."""
+        """Cout <= 16 conv3x3 as an MFMA GEMM: weights [Cout,Cin,3,3] -> bf16 [8|16][9*Cin] (rows >= Cout
+        zero), bias fp32 [8|16]."""
         def f():
             co = w4.shape[0]
-            w = torch.zeros(8, 9 * w4.shape[1])
+            npad = 8 if co <= 8 else 16
+            w = torch.zeros(npad, 9 * w4.shape[1])
             w[:co] = Wm.pack_conv3x3(w4.float())
-            b = torch.zeros(8)
+            b = torch.zeros(npad)
             b[:co] = bias.float()
             return Wm.bf16(w, self.device), Wm.f32(b, self.device)
         return self._memo(("scm", key), f)
@@ -113,7 +114,7 @@ class WeightStore:
         def f():
             w = self.sd[f"{name}.weight"].float()
             k = 9 * w.shape[1]
-            kp = 64 if k <= 64 else 128
+            kp = (k + 63) // 64 * 64
             wp = torch.zeros(w.shape[0], kp)
             wp[:, :k] = Wm.pack_conv3x3(w)
             return Wm.bf16(wp, self.device), kp
@@ -221,10 +222,11 @@ class Builder:
         """conv3x3 (pad 1) bf16 NHWC -> <= 4 fp32 NCHW channels on the MFMA path: GEMM into a padded
         fp32 [M][8] buffer, then the pointwise tail (MG_OP_POST_NCHW)."""
         w8, b8 = self.ws.small_conv_mfma(key, w4, bias)
-        tmp = self.raw(x.M * 8 * 4)
-        self.add(O.igemm(x.t, w8, tmp, B=x.B, H=x.H, W=x.W, Cin=x.C, Ho=x.H, Wo=x.W, N=8, taps=9, stride=1,
-                         pad=1, bias=b8, epi=L.EPI_F32, ldo=8, n_alg=cout), f"{key}")
-        self.add(O.post_nchw(tmp, out, B=x.B, HW=x.HW, Cout=cout, ldi=8, post=post, scale=scale), f"{key}.post")
+        npad = w8.shape[0]
+        tmp = self.raw(x.M * npad * 4)
+        self.add(O.igemm(x.t, w8, tmp, B=x.B, H=x.H, W=x.W, Cin=x.C, Ho=x.H, Wo=x.W, N=npad, taps=9, stride=1,
+                         pad=1, bias=b8, epi=L.EPI_F32, ldo=npad, n_alg=cout), f"{key}")
+        self.add(O.post_nchw(tmp, out, B=x.B, HW=x.HW, Cout=cout, ldi=npad, post=post, scale=scale), f"{key}.post")
         self.free(tmp)
 
     def dense(self, x, wt, bias, N, *, residual=None, out=None, epi=L.EPI_BF16, label="", K=None, out_dtype_bytes=2):
@@ -404,7 +406,8 @@ def emit_unet_forward(bld, cfg, ctx, rgb_latent, x_latent, eps_out, temb_table, 
 
     c0 = boc[0]
     cin = ws.sd["conv_in.weight"].shape[1]
-    x = bld.conv_from_nchw(rgb_latent, x_latent, "conv_in", B, h, w, cin - 4, 4, c0,
+    c_rgb = rgb_latent.shape[1]   # 4 image-latent channels + 4 per predicted modality (IID: 8 / 12)
+    x = bld.conv_from_nchw(rgb_latent, x_latent, "conv_in", B, h, w, c_rgb, cin - c_rgb, c0,
                            bcast0=rgb_latent.shape[0] == 1)
     skips = [x]
     force_size = any(d % (2 ** (n - 1)) != 0 for d in (h, w))

@@ -228,3 +228,23 @@ def ensemble_normals(normals, output_uncertainty=False, reduction="closest"):
     O.launch(O.ens_normals(n, out, unc, E=E, HW=H * W, reduction=0 if reduction == "closest" else 1))
     return (out.reshape(1, 3, H, W).to(normals.dtype),
             None if unc is None else unc.reshape(1, 1, H, W).to(normals.dtype))
+
+
+def ensemble_iid(targets, output_uncertainty=False, reduction="median"):
+    """targets: CUDA tensor [E,C,H,W] -> ([1,C,H,W], [1,C,H,W] | None): per-element median (+ median
+    absolute deviation) or mean (+ unbiased std) over the members (reference ensemble.py:252-270), as one
+    pass of the fused median kernel without alignment."""
+    if reduction not in ("median", "mean"):
+        raise ValueError(f"Unrecognized reduction method: {reduction}.")
+    E = targets.shape[0]
+    n = targets[0].numel()
+    t = targets.to(torch.float32).contiguous()
+    dev = t.device
+    pred = torch.empty(n, dtype=torch.float32, device=dev)
+    unc = torch.empty(n, dtype=torch.float32, device=dev) if output_uncertainty else None
+    mm = torch.empty(2 + 2 * E, dtype=torch.float32, device=dev)
+    scratch = torch.empty(_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+    O.launch(O.ens_depth_median(t.reshape(E, n), None, pred, unc, mm, scratch, E=E, HW=n,
+                                reduction=0 if reduction == "median" else 1, has_shift=False))
+    shape = (1,) + tuple(targets.shape[1:])
+    return pred.reshape(shape).to(targets.dtype), None if unc is None else unc.reshape(shape).to(targets.dtype)

@@ -120,7 +120,7 @@ class UNet2DConditionModelHIP(_EngineModule):
         seq = O.OpSeq(f"denoise[B={B},{h}x{w},T={len(timesteps)}]")
         bld = E.Builder(seq, self.pool, self.ws, self.config.norm_groups)
         rgb_latent = torch.zeros(1 if rgb_broadcast else B, 4, h, w, device=dev)
-        x = torch.zeros(B, 4, h, w, device=dev)
+        x = torch.zeros(B, self.config.out_channels, h, w, device=dev)
         eps = torch.zeros(B, self.config.out_channels, h, w, device=dev)
         seq.hold(rgb_latent, x, eps)
         table = E.emit_time_embeddings(bld, self.config, timesteps)
@@ -135,7 +135,7 @@ class UNet2DConditionModelHIP(_EngineModule):
                 cx, cm, cn = scheduler.step_coefficients(i)
                 nz = None
                 if scheduler.needs_noise(i):
-                    nz = seq.hold(torch.zeros(B, 4, h, w, device=dev))
+                    nz = seq.hold(torch.zeros(B, self.config.out_channels, h, w, device=dev))
                     noises.append(nz)
                 seq.add(O.sched_step(x, eps, nz, x, n=x.numel(), cx=cx, cm=cm, cn=cn), f"scheduler.step[{i}]")
         seq.keep.extend(bld.persist.values())
@@ -152,7 +152,7 @@ class UNet2DConditionModelHIP(_EngineModule):
                                     timesteps=[int(timestep)])
         s = sample.to(self.device, torch.float32)
         prog.rgb_latent.copy_(s[:, :4])
-        prog.x.copy_(s[:, 4:])
+        prog.x.copy_(s[:, 4:])   # 4 channels per predicted modality
         prog.run()
         return SimpleNamespace(sample=prog.eps.clone())
 

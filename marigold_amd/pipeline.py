@@ -13,7 +13,7 @@ ensembling).  Differences that are deliberate and documented in DESIGN.md:
 """
 import logging
 from dataclasses import dataclass
-from typing import Dict, Optional, Union
+from typing import Any, Dict, List, Optional, Union
 
 import numpy as np
 import torch
@@ -21,7 +21,7 @@ from PIL import Image
 
 from . import _lib as L
 from . import dist as mdist
-from .ensemble import ensemble_depth, ensemble_normals
+from .ensemble import ensemble_depth, ensemble_iid, ensemble_normals
 from .modules import AutoencoderKLHIP, UNet2DConditionModelHIP
 from .schedulers import DDIMScheduler, LCMScheduler
 from .util.batchsize import find_batch_size
@@ -51,6 +51,8 @@ class _MarigoldPipelineBase:
     latent_scale_factor = 0.18215
     _kind = "depth"
     _ckpt_hint = "prs-eth/marigold-depth-v1-1"
+    _target_latent_channels = 4    # latent channels the UNet predicts (4 per modality)
+    _pred_channels = 1             # channels of one decoded prediction
 
     def __init__(self, unet: UNet2DConditionModelHIP, vae: AutoencoderKLHIP,
                  scheduler: Union[DDIMScheduler, LCMScheduler], text_encoder=None, tokenizer=None,
@@ -152,7 +154,8 @@ class _MarigoldPipelineBase:
         rgb_latent = self.encode_rgb(rgb_in)                       # [1|B,4,h,w] fp32
         h, w = rgb_latent.shape[-2:]
         if init_latents is None:
-            target_latent = torch.randn((B, 4, h, w), device=device, dtype=self.dtype, generator=generator)
+            target_latent = torch.randn((B, self._target_latent_channels, h, w), device=device, dtype=self.dtype,
+                                        generator=generator)
         else:
             target_latent = init_latents.to(device)
         if self.empty_text_embed is None:
@@ -179,7 +182,7 @@ class _MarigoldPipelineBase:
             # so results do not depend on the number of GPUs
             if init_latents is None:
                 hh, ww = self._latent_hw(rgb_norm.shape[-2:])
-                init_latents = torch.randn((E, 4, hh, ww), device=self.device, dtype=self.dtype,
+                init_latents = torch.randn((E, self._target_latent_channels, hh, ww), device=self.device, dtype=self.dtype,
                                            generator=generator)
             members = mdist.shard_members(E, mdist.world_size(self._member_group),
                                           mdist.rank(self._member_group))
@@ -191,7 +194,7 @@ class _MarigoldPipelineBase:
             preds.append(self.single_infer(rgb, denoising_steps, generator, False, lat))
         local = torch.cat(preds, dim=0) if preds else None
         if self._member_parallel and mdist.world_size(self._member_group) > 1:
-            C = 1 if self._kind == "depth" else 3
+            C = self._pred_channels
             hh, ww = rgb_norm.shape[-2:]
             return mdist.gather_members(local, E, (C, hh, ww), self.device, self._member_group,
                                         getattr(self, "_member_root", None))
@@ -289,6 +292,7 @@ class MarigoldNormalsPipeline(_MarigoldPipelineBase):
     """Surface normals (reference marigold/marigold_normals_pipeline.py:77-479)."""
     _kind = "normals"
     _ckpt_hint = "prs-eth/marigold-normals-v1-1"
+    _pred_channels = 3
 
     def __init__(self, unet, vae, scheduler, text_encoder=None, tokenizer=None,
                  default_denoising_steps: Optional[int] = None,
@@ -344,3 +348,133 @@ class MarigoldNormalsPipeline(_MarigoldPipelineBase):
         normals_img = ((final_pred + 1) * 127.5).astype(np.uint8)
         normals_img = Image.fromarray(chw2hwc(normals_img))
         return MarigoldNormalsOutput(normals_np=final_pred, normals_img=normals_img, uncertainty=pred_uncert)
+
+
+# ------------------------------------------------------------------------------------------ IID
+
+@dataclass
+class IIDEntry:
+    """One decomposed component (reference marigold/marigold_iid_pipeline.py:59-77): ``array`` [3,H,W] in
+    [0,1], ``image`` PIL RGB, ``uncertainty`` [3,H,W] | None."""
+    name: str
+    array: Optional[np.ndarray] = None
+    image: Optional[Image.Image] = None
+    uncertainty: Optional[np.ndarray] = None
+
+
+class MarigoldIIDOutput:
+    """Named container of the predicted modalities (reference :80-161)."""
+
+    def __init__(self, target_names: List[str]):
+        self.n_targets = len(target_names)
+        self.target_names = target_names
+        self.entries: List[IIDEntry] = [IIDEntry(name=n) for n in target_names]
+        self._by_name = {e.name: e for e in self.entries}
+        self._filled = set()
+
+    def fill_entry(self, name: str, prediction: torch.Tensor, uncertainty: Optional[torch.Tensor] = None,
+                   target_properties: Optional[Dict[str, Any]] = None) -> None:
+        if name not in self._by_name:
+            raise KeyError(f"Unknown entry name: {name}")
+        if name in self._filled:
+            raise RuntimeError(f"Entry {name} already filled")
+        array = prediction.squeeze().cpu().numpy()
+        vis = array
+        space = target_properties[name].get("prediction_space", "srgb")
+        if space == "linear":   # linear radiometric space -> display gamma, optionally normalised to its maximum
+            if target_properties[name].get("up_to_scale", False):
+                vis = vis / max(vis.max(), 1e-6)
+            vis = vis ** (1 / 2.2)
+        entry = self._by_name[name]
+        entry.array = array
+        entry.image = Image.fromarray(chw2hwc((vis * 255).astype(np.uint8)))
+        entry.uncertainty = None if uncertainty is None else uncertainty.squeeze().cpu().numpy()
+        self._filled.add(name)
+
+    @property
+    def is_complete(self) -> bool:
+        return len(self._filled) == self.n_targets
+
+    def __getitem__(self, key: str) -> IIDEntry:
+        return self._by_name[key]
+
+    def __iter__(self):
+        return iter(self.entries)
+
+
+class MarigoldIIDPipeline(_MarigoldPipelineBase):
+    """Intrinsic image decomposition (reference marigold/marigold_iid_pipeline.py:164-585): the UNet
+    predicts 4 latent channels per modality in ``target_properties["target_names"]``
+    (8 + ... input channels = image latent + all modality latents), every modality is decoded by the
+    VAE separately (here: as extra batch entries of ONE decode program) and mapped to [0,1]."""
+    _kind = "iid"
+    _ckpt_hint = "prs-eth/marigold-iid-appearance-v1-1` or `prs-eth/marigold-iid-lighting-v1-1"
+
+    def __init__(self, unet, vae, scheduler, text_encoder=None, tokenizer=None,
+                 target_properties: Optional[Dict[str, Any]] = None, default_denoising_steps: Optional[int] = None,
+                 default_processing_resolution: Optional[int] = None, empty_text_embed=None):
+        super().__init__(unet, vae, scheduler, text_encoder, tokenizer, None, None, default_denoising_steps,
+                         default_processing_resolution, empty_text_embed)
+        self.target_properties = target_properties
+        self.target_names = target_properties["target_names"]
+        self.n_targets = len(self.target_names)
+        self._target_latent_channels = 4 * self.n_targets
+        self._pred_channels = 3 * self.n_targets
+        if unet.config.out_channels != self._target_latent_channels or \
+                unet.config.in_channels != 4 + self._target_latent_channels:
+            raise ValueError(f"UNet with {unet.config.in_channels}->{unet.config.out_channels} channels does not "
+                             f"match {self.n_targets} target(s) {self.target_names}")
+        self.config = dict(target_properties=target_properties, default_denoising_steps=default_denoising_steps,
+                           default_processing_resolution=default_processing_resolution)
+
+    def _lcm_policy(self, n_step):
+        raise RuntimeError("This pipeline implementation does not support the LCMScheduler. Please refer to the "
+                           "project README.md for instructions about using LCM.")
+
+    def _decode(self, latent):
+        return self.decode_targets(latent)
+
+    def decode_targets(self, target_latent: torch.Tensor) -> torch.Tensor:
+        """[B,4n,h,w] -> [B,3n,H,W] in [0,1]: every modality through post_quant_conv + decoder
+        (reference :556-585) with the clip / shift of :523-526 fused; modalities ride in the batch."""
+        B, _, h, w = target_latent.shape
+        dec = self.vae.decode(target_latent.reshape(B * self.n_targets, 4, h, w), post=L.POST_UNIT)
+        return dec.reshape(B, 3 * self.n_targets, dec.shape[-2], dec.shape[-1])
+
+    def fill_outputs(self, output: MarigoldIIDOutput, final_pred: torch.Tensor,
+                     pred_uncert: Optional[torch.Tensor] = None):
+        for i, name in enumerate(self.target_names):
+            output.fill_entry(name=name, prediction=final_pred[:, 3 * i:3 * i + 3],
+                              uncertainty=None if pred_uncert is None else pred_uncert[:, 3 * i:3 * i + 3],
+                              target_properties=self.target_properties)
+
+    @torch.no_grad()
+    def __call__(self, input_image: Union[Image.Image, torch.Tensor], denoising_steps: Optional[int] = None,
+                 ensemble_size: int = 1, processing_res: Optional[int] = None, match_input_res: bool = True,
+                 resample_method: str = "bilinear", batch_size: int = 0,
+                 generator: Union[torch.Generator, None] = None, show_progress_bar: bool = True,
+                 ensemble_kwargs: Dict = None, init_latents: Optional[torch.Tensor] = None) -> MarigoldIIDOutput:
+        if denoising_steps is None:
+            denoising_steps = self.default_denoising_steps
+        if processing_res is None:
+            processing_res = self.default_processing_resolution
+        assert processing_res >= 0
+        assert ensemble_size >= 1
+        self._check_inference_step(denoising_steps)
+        resample = get_tv_resample_method(resample_method)
+        rgb_norm, input_size = self._preprocess(input_image, processing_res, resample)
+        target_preds = self._predict_members(rgb_norm, ensemble_size, denoising_steps, batch_size, generator,
+                                             init_latents)
+        output = MarigoldIIDOutput(target_names=self.target_names)
+        if target_preds is None:   # member-parallel non-root rank with a rooted gather
+            return output
+        assert target_preds.dim() == 4 and target_preds.shape[1] == 3 * self.n_targets
+        if ensemble_size > 1:
+            final_pred, pred_uncert = ensemble_iid(target_preds, **(ensemble_kwargs or {}))
+        else:
+            final_pred, pred_uncert = target_preds, None
+        if match_input_res:
+            final_pred = resize(final_pred, input_size[-2:], interpolation=resample, antialias=True)
+        self.fill_outputs(output, final_pred, pred_uncert)
+        assert output.is_complete
+        return output

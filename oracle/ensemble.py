@@ -10,6 +10,7 @@ Follows /root/reference/marigold/util/ensemble.py:
                              ensemble :120-136, cost_fn :138-152, compute_param :154-173,
                              final normalisation :184-194)
   ensemble_normals :199-249
+  ensemble_iid     :252-270
 Semantics kept on purpose: ``torch.median`` picks the LOWER middle element for even E;
 the optimiser runs on an fp32 copy while the final affine is applied in the input dtype;
 BFGS has no analytic gradient (scipy finite differences), tol=1e-6, maxiter=50.
@@ -135,3 +136,19 @@ def ensemble_normals(normals, output_uncertainty=False, reduction="closest"):
         return mean, unc
     idx = cos.argmax(dim=0, keepdim=True).repeat(1, 3, 1, 1)
     return torch.gather(normals, 0, idx), unc
+
+
+def ensemble_iid(targets, output_uncertainty=False, reduction="median"):
+    """Per-element median (+MAD) or mean (+std) over the members of [E,C,H,W]."""
+    unc = None
+    if reduction == "mean":
+        pred = targets.mean(dim=0, keepdim=True)
+        if output_uncertainty:
+            unc = targets.std(dim=0, keepdim=True)
+    elif reduction == "median":
+        pred = torch.median(targets, dim=0, keepdim=True).values
+        if output_uncertainty:
+            unc = torch.median((targets - pred).abs(), dim=0, keepdim=True).values
+    else:
+        raise ValueError(f"Unrecognized reduction method: {reduction}.")
+    return pred, unc

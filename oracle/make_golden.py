@@ -125,6 +125,12 @@ def make_ensemble_golden():
         m, _ = ref.ensemble_normals(x.clone(), reduction="mean")
         out[f"{name}_in"], out[f"{name}_closest"], out[f"{name}_unc"], out[f"{name}_mean"] = \
             x.numpy(), n.numpy(), u.numpy(), m.numpy()
+    g = torch.Generator("cpu").manual_seed(41)
+    x = torch.rand(5, 6, 20, 24, generator=g)       # E=5 members, 2 modalities x 3 channels
+    for red in ("median", "mean"):
+        p, u = ref.ensemble_iid(x.clone(), output_uncertainty=True, reduction=red)
+        out[f"iid_{red}_pred"], out[f"iid_{red}_unc"] = p.numpy(), u.numpy()
+    out["iid_in"] = x.numpy()
     np.savez_compressed(os.path.join(GOLD, "ensemble_ref.npz"), **out)
     print("ensemble_ref.npz:", sorted(out))
 

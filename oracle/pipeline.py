@@ -43,10 +43,15 @@ def denoise(unet, scheduler, rgb_latent, target_latent, text_embed, n_steps, gen
 @torch.no_grad()
 def single_infer(kind, unet, vae, scheduler, rgb_norm, init_latent, text_embed, n_steps,
                  generator=None, trace=None):
-    """rgb_norm [B,3,H,W] in [-1,1]; init_latent [B,4,H/8,W/8].  kind: 'depth' | 'normals'."""
+    """rgb_norm [B,3,H,W] in [-1,1]; init_latent [B,4,H/8,W/8] ([B,4n,...] for 'iid').
+    kind: 'depth' | 'normals' | 'iid'."""
     rgb_latent = encode_rgb(vae, rgb_norm)
     lat = denoise(unet, scheduler, rgb_latent, init_latent.to(rgb_latent.dtype), text_embed,
                   n_steps, generator, trace)
+    if kind == "iid":   # marigold_iid_pipeline.py:556-585, 523-526: every modality decoded separately
+        n = lat.shape[1] // 4
+        dec = torch.cat([decode_latent(vae, lat[:, 4 * i:4 * i + 4]) for i in range(n)], dim=1)
+        return (torch.clip(dec, -1.0, 1.0) + 1.0) / 2.0
     dec = decode_latent(vae, lat)
     if kind == "depth":
         d = dec.mean(dim=1, keepdim=True)
@@ -70,6 +75,8 @@ def predict(kind, unet, vae, scheduler, image_u8, init_latents, text_embed, n_st
     kw = ensemble_kwargs or {}
     if kind == "depth":
         out, unc = ens.ensemble_depth(preds, True, True, **kw)
+    elif kind == "iid":
+        out, unc = ens.ensemble_iid(preds, **kw)
     else:
         out, unc = ens.ensemble_normals(preds, **kw)
     return out, unc, preds

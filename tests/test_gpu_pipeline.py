@@ -375,3 +375,57 @@ def test_member_parallel_two_ranks_share_one_gpu():
     m = omet.affine_invariant_depth_errors(ref, got)
     print(f"[parity] 2-rank member-parallel vs single process: max|diff| {np.abs(ref - got).max():.2e} {m}")
     assert np.abs(ref - got).max() < 2e-2 and m["rmse"] < 5e-3
+
+
+def test_iid_pipeline_vs_oracle(tiny, tmp_path):
+    """Third model family (marigold_iid_pipeline.py): 2 modalities -> UNet 12 -> 8 latent channels,
+    per-modality VAE decode, ensemble_iid; engine vs the CPU oracle on the tiny architecture."""
+    import marigold_amd as M
+    from marigold_amd import ensemble as ens, synthetic as syn
+    from marigold_amd.arch import UNetConfig
+    from marigold_amd.modules import UNet2DConditionModelHIP
+    from marigold_amd.schedulers import DDIMScheduler
+    from oracle import pipeline as opipe
+    from oracle.schedulers import DDIMScheduler as ODDIM
+    from oracle.sd2_unet import UNet2DConditionModel
+    ucfg = UNetConfig(in_channels=12, out_channels=8, block_out_channels=(64, 128, 128, 128), heads=(1, 2, 2, 2),
+                      cross_attention_dim=64)
+    usd = syn.synthetic_unet_state_dict(ucfg)
+    props = {"target_names": ["albedo", "material"], "albedo": {"prediction_space": "srgb"},
+             "material": {"prediction_space": "stack"}}
+    pipe = M.MarigoldIIDPipeline(UNet2DConditionModelHIP(usd, ucfg).to("cuda:0"), tiny["evae"], DDIMScheduler(),
+                                 target_properties=props, default_denoising_steps=2, default_processing_resolution=0,
+                                 empty_text_embed=tiny["ctx"])
+    img = syn.synthetic_image(64, 128, seed=0)
+    g = torch.Generator().manual_seed(77)
+    lat0 = torch.randn(3, 8, 8, 16, generator=g)
+    out = pipe(img, ensemble_size=3, show_progress_bar=False, init_latents=lat0,
+               ensemble_kwargs=dict(output_uncertainty=True))
+    assert out.is_complete and out["albedo"].array.shape == (3, 64, 128) and out["material"].image.size == (128, 64)
+    ounet = UNet2DConditionModel(in_channels=12, out_channels=8, block_out_channels=ucfg.block_out_channels,
+                                 attention_head_dim=ucfg.heads, cross_attention_dim=64).eval()
+    ounet.load_state_dict(usd)
+    ref, unc, members = opipe.predict("iid", ounet, tiny["ovae"], ODDIM(), img, lat0, tiny["ctx"], 2,
+                                      ensemble_kwargs=dict(output_uncertainty=True))
+    got = np.concatenate([out["albedo"].array, out["material"].array], axis=0)
+    err = np.abs(got - ref[0].numpy())
+    print(f"[parity] IID E=3 T=2 vs oracle: |err| mean {err.mean():.2e} p99 {np.percentile(err, 99):.2e} max {err.max():.2e}")
+    # per-element median over 3 members of bf16-engine predictions: a near-tie can pick another member
+    assert err.mean() < 3e-3 and np.percentile(err, 99) < 2e-2
+    assert got.min() >= 0 and got.max() <= 1
+    # ensemble_iid kernel path vs the reference-pinned oracle on the oracle's own members (exact ops)
+    for red in ("median", "mean"):
+        p, u = ens.ensemble_iid(members.cuda(), output_uncertainty=True, reduction=red)
+        from oracle import ensemble as oens
+        rp, ru = oens.ensemble_iid(members, output_uncertainty=True, reduction=red)
+        assert float((p.cpu() - rp).abs().max()) < (0 if red == "median" else 1e-6) + 1e-7
+        assert float((u.cpu() - ru).abs().max()) < 1e-6
+    # checkpoint folder (model_index.json with target_properties) -> from_pretrained -> same bits
+    from marigold_amd.checkpoint import save_synthetic_checkpoint
+    save_synthetic_checkpoint(str(tmp_path / "iid"), "MarigoldIIDPipeline", usd, tiny["vsd"], ucfg, tiny["vcfg"],
+                              DDIMScheduler(), tiny["ctx"], target_properties=props, default_denoising_steps=2,
+                              default_processing_resolution=0)
+    pipe2 = M.MarigoldIIDPipeline.from_pretrained(str(tmp_path / "iid")).to("cuda")
+    assert pipe2.target_names == props["target_names"]
+    out2 = pipe2(img, ensemble_size=3, show_progress_bar=False, init_latents=lat0)
+    assert np.array_equal(out2["material"].array, out["material"].array)

@@ -371,6 +371,30 @@ def test_cli_flags_and_output_formats(tmp_path):
     assert cli.main("normals", ["--input_rgb_dir", str(inp), "--output_dir", str(out)], pipeline=FakeNormals()) == 0
     assert np.load(out / "normals_npy" / "b_normals.npy").shape == (3, 6, 8)
     assert (out / "normals_vis" / "a_normals.png").exists()
+
+    from marigold_amd.pipeline import MarigoldIIDOutput
+    props = {"target_names": ["albedo", "shading", "residual"], "albedo": {"prediction_space": "srgb"},
+             "shading": {"prediction_space": "linear", "up_to_scale": True},
+             "residual": {"prediction_space": "linear", "up_to_scale": True}}
+
+    class FakeIID:
+        default_denoising_steps, default_processing_resolution = 4, 768
+        target_names = props["target_names"]
+
+        def __call__(self, image, **kw):
+            o = MarigoldIIDOutput(self.target_names)
+            for n in self.target_names:
+                o.fill_entry(n, torch.rand(1, 3, 6, 8), None, props)
+            return o
+
+    assert cli.build_parser("iid").parse_args(["--input_rgb_dir", "i", "--output_dir", "o"]).checkpoint == \
+        "prs-eth/marigold-iid-appearance-v1-1"
+    assert cli.main("iid", ["--input_rgb_dir", str(inp), "--output_dir", str(out), "--checkpoint",
+                            "prs-eth/marigold-iid-lighting-v1-1"], pipeline=FakeIID()) == 0
+    assert np.load(out / "iid_lighting_npy" / "a_shading.npy").shape == (6, 8, 3)   # chw2hwc like script/iid/run.py:263
+    assert Image.open(out / "iid_lighting_vis" / "b_residual.png").size == (8, 6)
+    assert cli.main("iid", ["--input_rgb_dir", str(inp), "--output_dir", str(out)], pipeline=FakeIID()) == 0
+    assert (out / "iid_appearance_npy" / "b_albedo.npy").exists()
     assert cli.main("depth", ["--input_rgb_dir", str(tmp_path / "out"), "--output_dir", str(out)],
                     pipeline=FakeDepth()) == 1   # no images -> exit code 1 like the reference
 
@@ -379,3 +403,48 @@ def test_from_pretrained_without_checkpoint_fails_clearly():
     import marigold_amd as M
     with pytest.raises(FileNotFoundError, match="neither a local folder nor in the local Hugging Face cache"):
         M.MarigoldDepthPipeline.from_pretrained("prs-eth/marigold-depth-v1-1")
+
+
+def test_iid_output_container_and_pipeline_contract():
+    """MarigoldIIDOutput / IIDEntry semantics (marigold_iid_pipeline.py:59-161) and the channel contract
+    of MarigoldIIDPipeline, without a GPU."""
+    import marigold_amd as M
+    from marigold_amd import synthetic as syn
+    from marigold_amd.arch import UNetConfig, TINY_VAE
+    from marigold_amd.modules import AutoencoderKLHIP, UNet2DConditionModelHIP
+    from marigold_amd.schedulers import DDIMScheduler, LCMScheduler
+    props = {"target_names": ["albedo", "shading"], "albedo": {"prediction_space": "srgb"},
+             "shading": {"prediction_space": "linear", "up_to_scale": True}}
+    out = M.MarigoldIIDOutput(props["target_names"])
+    a = torch.rand(1, 3, 5, 7)
+    out.fill_entry("albedo", a, None, props)
+    with pytest.raises(RuntimeError):
+        out.fill_entry("albedo", a, None, props)
+    with pytest.raises(KeyError):
+        out.fill_entry("nope", a, None, props)
+    assert not out.is_complete
+    sh = torch.rand(1, 3, 5, 7) * 0.5
+    out.fill_entry("shading", sh, torch.rand(1, 3, 5, 7), props)
+    assert out.is_complete and out["shading"].uncertainty.shape == (3, 5, 7)
+    want = (((sh[0] / sh.max()) ** (1 / 2.2)).numpy() * 255).astype(np.uint8)
+    assert np.array_equal(np.asarray(out["shading"].image), np.moveaxis(want, 0, -1))
+    assert [e.name for e in out] == props["target_names"] and out["albedo"].array.shape == (3, 5, 7)
+    ucfg = UNetConfig(in_channels=12, out_channels=8, block_out_channels=(64, 128, 128, 128), heads=(1, 2, 2, 2),
+                      cross_attention_dim=64)
+    unet = UNet2DConditionModelHIP(syn.synthetic_unet_state_dict(ucfg), ucfg)
+    vae = AutoencoderKLHIP(syn.synthetic_vae_state_dict(TINY_VAE), TINY_VAE)
+    pipe = M.MarigoldIIDPipeline(unet, vae, DDIMScheduler(), target_properties=props, default_denoising_steps=4,
+                                 default_processing_resolution=768,
+                                 empty_text_embed=syn.synthetic_text_embedding(64))
+    assert pipe.n_targets == 2 and pipe._target_latent_channels == 8 and pipe._pred_channels == 6
+    with pytest.raises(ValueError, match="does not match"):
+        M.MarigoldIIDPipeline(unet, vae, DDIMScheduler(), target_properties={"target_names": ["a"], "a": {}})
+    pipe.scheduler = LCMScheduler()
+    with pytest.raises(RuntimeError, match="does not support the LCMScheduler"):
+        pipe._check_inference_step(4)
+    # the 12 -> 64 conv_in / 64 -> 8 conv_out programs validate through the C ABI without a device
+    unet.dry()
+    unet.set_context(torch.zeros(1, 2, 64))
+    prog = unet.denoise_program(2, 8, 16, DDIMScheduler(), 2)
+    prog.seq.validate()
+    assert tuple(prog.x.shape) == (2, 8, 8, 16) and tuple(prog.eps.shape) == (2, 8, 8, 16)

@@ -61,3 +61,13 @@ def test_median_is_lower_middle():
     a = torch.tensor([[1.0], [4.0], [2.0], [3.0]]).view(4, 1, 1, 1)
     p, _ = oens.depth_reduce(a, "median", False)
     assert p.item() == 2.0
+
+
+@pytest.mark.parametrize("red", ["median", "mean"])
+def test_iid(gold, red):
+    x = torch.from_numpy(gold["iid_in"])
+    p, u = oens.ensemble_iid(x.clone(), output_uncertainty=True, reduction=red)
+    np.testing.assert_array_equal(p.numpy(), gold[f"iid_{red}_pred"])
+    np.testing.assert_allclose(u.numpy(), gold[f"iid_{red}_unc"], atol=1e-7)
+    with pytest.raises(ValueError):
+        oens.ensemble_iid(x, reduction="max")
