@@ -430,3 +430,37 @@ def test_iid_pipeline_vs_oracle(tiny, tmp_path):
     assert pipe2.target_names == props["target_names"]
     out2 = pipe2(img, ensemble_size=3, show_progress_bar=False, init_latents=lat0)
     assert np.array_equal(out2["material"].array, out["material"].array)
+
+
+def test_dataset_inference_and_evaluation_on_device(tiny, tmp_path):
+    """N3 end to end on the GPU: script/depth/infer.py's program over a synthetic NYU-layout tar split with the
+    tiny engine pipeline, then script/depth/eval.py's program with least-squares alignment.  The prediction
+    files must equal a direct pipeline call with the same seed, and the protocol files must come out."""
+    import yaml
+    import marigold_amd as M
+    from PIL import Image
+    from marigold_amd.evaluation import DatasetMode, get_dataset, harness
+    from marigold_amd.schedulers import DDIMScheduler
+    from oracle.make_eval_golden import write_synthetic_datasets
+    cfgs = write_synthetic_datasets(str(tmp_path), as_tar=("nyu",))
+    cfg_path = tmp_path / "nyu.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfgs["nyu"]))
+    pipe = M.MarigoldDepthPipeline(tiny["eunet"], tiny["evae"], DDIMScheduler(), scale_invariant=True,
+                                   shift_invariant=True, default_denoising_steps=2,
+                                   default_processing_resolution=128, empty_text_embed=tiny["ctx"])
+    out, ev = tmp_path / "pred", tmp_path / "eval"
+    base = ["--dataset_config", str(cfg_path), "--base_data_dir", str(tmp_path)]
+    assert harness.infer_main("depth", base + ["--output_dir", str(out), "--denoise_steps", "2", "--processing_res",
+                                               "128", "--ensemble_size", "2", "--seed", "11"], pipeline=pipe) == 0
+    sample = get_dataset(cfgs["nyu"], str(tmp_path), DatasetMode.RGB_ONLY)[1]
+    g = torch.Generator(device=pipe.device).manual_seed(11)
+    direct = pipe(Image.fromarray(np.moveaxis(sample["rgb_int"].astype(np.uint8), 0, -1)), denoising_steps=2,
+                  ensemble_size=2, processing_res=128, batch_size=0, color_map=None, show_progress_bar=False,
+                  generator=g).depth_np
+    saved = np.load(out / "test" / "kitchen" / "pred_0012.npy")
+    assert saved.shape == (480, 640) and saved.dtype == np.float32 and np.array_equal(saved, direct)
+    assert harness.eval_main("depth", base + ["--prediction_dir", str(out), "--output_dir", str(ev),
+                                              "--alignment", "least_square"]) == 0
+    rows = (ev / "per_sample_metrics.csv").read_text().strip().split("\n")
+    assert len(rows) == 3 and all(np.isfinite([float(v) for v in r.split(",")[1:]]).all() for r in rows[1:])
+    assert (ev / "eval_metrics-least_square.txt").exists()
