@@ -61,8 +61,20 @@ __device__ __forceinline__ void wait_vmcnt() {
 // 2 = fragment reads but no MFMAs, 3 = MFMAs on fixed registers (no fragment reads).
 // BK: K-tile depth (64: 128-byte LDS rows; 32: 64-byte rows, half the LDS per stage - lets two 4-wave
 // workgroups with 128x64 wave tiles share a CU).
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, bool PF, int ABL = 0, int BK = 64>
-__global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args a) {
+// LOOP: K-loop schedule - 0 = one barrier per K tile (the default family), 1 = half-K-step software pipeline,
+// 2 = "ping-pong": 256x256 tile, 8 waves in two groups of four (rows 0-127 / 128-255) that run ONE BARRIER
+// APART, four phases per K tile, each phase {fragment reads + LDS-DMA issue | barrier | 8 MFMAs | barrier} -
+// while one group's waves are in the MFMA segment, their SIMD partners (the other group) are in the
+// load segment, so the matrix pipe always has a wave to run (cdna_hip_programming.md "256^2 8-phase").
+// PPOPT (ping-pong only): bit 0 = no s_setprio around the MFMA segments; bit 2 = in phases 1-3 the second
+// LDS-DMA piece of the half tile is issued in the middle of the MFMA segment instead of the load segment
+// (a piece costs its wave 60-185 issue cycles - two of them make the load segment longer than the partner's
+// eight MFMAs).
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, int LOOP, int ABL, int BK, int PPOPT = 0>
+__device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
+  constexpr bool PF = LOOP == 1, PP = LOOP == 2;
+  static_assert(!PP || (BM == 256 && BN == 256 && WGM == 2 && WGN == 4 && NSTAGE == 2 && BK == 64 && ABL == 0),
+                "the ping-pong schedule is written for the 256x256 / 8-wave / 2-stage tile");
   constexpr int NT = WGM * WGN * 64;
   constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
   constexpr int ROWB = BK * 2;        // bytes per LDS row (one pixel's / one weight row's K tile)
@@ -101,6 +113,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   const bf16_t* __restrict__ Wb = a.Wt + (long long)z * a.sW;
   const char* zero = (const char*)a.zero;
 
+  // LDS row slot -> tile row.  Identity except for the ping-pong schedule, whose K tile is staged as four
+  // half tiles in the order the phases consume them: A slots [0,128) = the first 64 rows of both wave groups,
+  // [128,256) their second 64 rows; B slots [0,128) = the first 32 columns of the four wave columns, ...
+  auto a_row_of = [](int slot) { return PP ? ((slot >> 6) & 1) * 128 + (slot >> 7) * 64 + (slot & 63) : slot; };
+  auto b_row_of = [](int slot) { return PP ? ((slot >> 5) & 3) * 64 + (slot >> 7) * 32 + (slot & 31) : slot; };
   // ---- staging rows owned by this thread (fixed over the K loop) ----
   int a_by[A_IT], a_bx[A_IT], a_qoff[A_IT];
   long long a_img[A_IT];
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
     const int ci = it * NT + tid;
     const int r = ci / CPR, p = ci % CPR;
     a_qoff[it] = swz(p, r) * 8;
-    const int m = m0 + r;
+    const int m = m0 + a_row_of(r);
     const bool ok = m < a.M;
     const int mm = ok ? m : 0;
     const int img = mm / a.rows_per_img;
@@ -124,7 +141,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   for (int it = 0; it < B_IT; ++it) {
     const int ci = it * NT + tid;
     const int r = ci / CPR, p = ci % CPR;
-    const int n = n0 + r;
+    const int n = n0 + b_row_of(r);
     b_ptr[it] = (n < a.n_end) ? (const char*)(Wb + (long long)n * a.ldw + swz(p, r) * 8) : zero;
   }
   const int kt0 = split * a.kps;                                   // this workgroup's K-step range
@@ -158,15 +175,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
     for (int it = 0; it < A_IT; ++it)
       if (a_ptr[it] != zero) a_ptr[it] += i_c * ROWB;
   }
+  // LDS map: [stage][A rows | B rows]; the ping-pong schedule keeps [A stage 0 | A stage 1 | B stage 0 | B stage 1]
+  // so that both stages of an operand are within the 16-bit immediate offset of one base address.
+  auto a_stage = [&](int stage) { return smem + stage * (PP ? BM * ROWB : STAGE); };
+  auto b_stage = [&](int stage) { return smem + (PP ? NSTAGE * BM * ROWB + stage * (BN * ROWB) : stage * STAGE + BM * ROWB); };
   auto issue_piece = [&](int stage, int idx) {  // idx in [0, LOADS): A pieces first, then B pieces
     if constexpr (ABL == 1) return;
-    char* sbase = smem + stage * STAGE;
     if (idx < A_IT) {
-      glds16(a_ptr[idx], sbase + (idx * NT + wave * 64) * 16);
+      glds16(a_ptr[idx], a_stage(stage) + (idx * NT + wave * 64) * 16);
       a_ptr[idx] += ROWB;
     } else {
       const int it = idx - A_IT;
-      glds16(b_ptr[it], sbase + BM * ROWB + (it * NT + wave * 64) * 16);
+      glds16(b_ptr[it], b_stage(stage) + (it * NT + wave * 64) * 16);
       b_ptr[it] += ROWB;
     }
   };
@@ -193,13 +213,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
 
   int rowA[MI], rowB[NI];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) rowA[mi] = wm * TM + mi * 32 + l31;
+  for (int mi = 0; mi < MI; ++mi)
+    rowA[mi] = PP ? (mi >> 1) * 128 + wm * 64 + (mi & 1) * 32 + l31 : wm * TM + mi * 32 + l31;
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) rowB[ni] = wn * TN + ni * 32 + l31;
+  for (int ni = 0; ni < NI; ++ni) rowB[ni] = PP ? ni * 128 + wn * 32 + l31 : wn * TN + ni * 32 + l31;
 
+  if constexpr (!PP) {
 #pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (d < KT) issue(d);
+    for (int d = 0; d < D; ++d)
+      if (d < KT) issue(d);
+  }
   int st_c = 0;                 // stage holding tile kt
   int st_i = D % NSTAGE;        // stage receiving tile kt + D
   // One K step.  ISSUE is a compile-time tag: the steady-state loop (a tile to prefetch every step) is
@@ -245,7 +268,130 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
       }
   };
 
-  if constexpr (!PF) {
+  if constexpr (PP) {
+    // Half tiles of K tile t (each 128 LDS rows = two DMA pieces per wave), in consumption order:
+    //   H0 = A rows {mi 0,1}  H1 = B rows {ni 0}  H2 = B rows {ni 1}  H3 = A rows {mi 2,3}
+    // Phase p of tile t:  P1 reads H0+H1 -> acc(mi 0,1 x ni 0)   P2 reads H2 -> acc(mi 0,1 x ni 1)
+    //                     P3 reads H3 -> acc(mi 2,3 x ni 1)      P4 reads -  -> acc(mi 2,3 x ni 0)
+    // and issues half tile H(p-1) of tile t+1 into the other stage.  A half tile is read one phase AFTER the
+    // counted vmcnt that retires it (wait in the load segment of phase p-1, barrier, read in phase p): with the
+    // two groups one barrier apart that is the earliest point at which every wave's part has landed.  Stage
+    // reuse is 4-5 phases behind the last read of the slot.  Waits in a tile that still issues: P1/P2/P4
+    // leave the two youngest half tiles (4 loads) in flight; the last tile drains 2 -> 0.
+    static_assert(A_IT == 4 && B_IT == 4 && MI == 4 && NI == 2 && KS == 4, "ping-pong geometry");
+    auto issue_half = [&](int stage, int h) {
+      if (h == 0) { issue_piece(stage, 0); issue_piece(stage, 1); }
+      else if (h == 1) { issue_piece(stage, A_IT + 0); issue_piece(stage, A_IT + 1); }
+      else if (h == 2) { issue_piece(stage, A_IT + 2); issue_piece(stage, A_IT + 3); }
+      else { issue_piece(stage, 2); issue_piece(stage, 3); }
+    };
+    bf16x8 fa[2][KS], fb[NI][KS];
+    auto read_a = [&](int st, int pair) {
+      const char* sA = a_stage(st);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int r = rowA[pair * 2 + m];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          fa[m][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(sA + r * ROWB + (swz(ks * 2 + half, r) << 4)));
+      }
+    };
+    auto read_b = [&](int st, int ni) {
+      const char* sB = b_stage(st);
+      const int r = rowB[ni];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        fb[ni][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(sB + r * ROWB + (swz(ks * 2 + half, r) << 4)));
+    };
+    auto quadrant = [&](int pair, int ni, int mid_stage, int mid_piece) {   // 8 MFMAs, two accumulators alternating
+      if constexpr (!(PPOPT & 1)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks == 2 && mid_piece >= 0) issue_piece(mid_stage, mid_piece);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          if constexpr (!TRANS)
+            acc[ni][pair * 2 + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni][ks], fa[m][ks], acc[ni][pair * 2 + m], 0, 0, 0);
+          else
+            acc[ni][pair * 2 + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][ks], fb[ni][ks], acc[ni][pair * 2 + m], 0, 0, 0);
+        }
+      }
+      if constexpr (!(PPOPT & 1)) __builtin_amdgcn_s_setprio(0);
+    };
+    auto fence = [&]() {   // nothing moves across: neither the compiler's memory ops nor the machine scheduler
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto rendezvous = [&]() {
+      fence();
+      __builtin_amdgcn_s_barrier();
+      fence();
+    };
+    auto compute = [&](int pair, int ni, int mid_stage = 0, int mid_piece = -1) {   // barrier | MFMA segment | barrier
+      rendezvous();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      quadrant(pair, ni, mid_stage, mid_piece);
+      rendezvous();
+    };
+    // prologue: the whole first tile, H0 and H1 landed for everyone before the first phase
+    issue_half(0, 0); issue_half(0, 1); issue_half(0, 2); issue_half(0, 3);
+    advance();
+    wait_vmcnt<4>();
+    rendezvous();
+    if (wm == 1) rendezvous();   // the second wave group runs one barrier behind the first
+    // DMA pieces of the half tiles: H0 = A pieces 0,1; H1 = B pieces 0,1; H2 = B pieces 2,3; H3 = A pieces 2,3
+    constexpr int HP[4][2] = {{0, 1}, {A_IT + 0, A_IT + 1}, {A_IT + 2, A_IT + 3}, {2, 3}};
+    constexpr bool MID = (PPOPT & 4) != 0;
+    // counted waits in a tile that stages its successor: loads that may stay in flight after the wait of P1 / P2
+    // (the half tile read next phase is older than these); P4 always leaves H2', H3' = 4 pieces
+    constexpr int W12 = MID ? 3 : 4;
+    auto tile = [&](int st, auto issue_tag) {
+      constexpr bool ISSUE = decltype(issue_tag)::value;   // a next tile exists: stage it into the other stage
+      const int sn = st ^ 1;
+      // P1
+      read_a(st, 0); read_b(st, 0);
+      if constexpr (ISSUE) {
+        issue_piece(sn, HP[0][0]);
+        if constexpr (!MID) issue_piece(sn, HP[0][1]);
+        wait_vmcnt<W12>();
+      } else {
+        wait_vmcnt<2>();
+      }
+      compute(0, 0, sn, (ISSUE && MID) ? HP[0][1] : -1);
+      // P2
+      read_b(st, 1);
+      if constexpr (ISSUE) {
+        issue_piece(sn, HP[1][0]);
+        if constexpr (!MID) issue_piece(sn, HP[1][1]);
+        wait_vmcnt<W12>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      compute(0, 1, sn, (ISSUE && MID) ? HP[1][1] : -1);
+      // P3
+      read_a(st, 1);
+      if constexpr (ISSUE) {
+        issue_piece(sn, HP[2][0]);
+        if constexpr (!MID) issue_piece(sn, HP[2][1]);
+      }
+      compute(1, 1, sn, (ISSUE && MID) ? HP[2][1] : -1);
+      // P4 (no fragment reads: both pieces of H3' and the tap bookkeeping go here)
+      if constexpr (ISSUE) {
+        issue_piece(sn, HP[3][0]);
+        issue_piece(sn, HP[3][1]);
+        advance();
+        wait_vmcnt<4>();
+      }
+      compute(1, 0);
+    };
+    {
+      int kt = 0, st = 0;
+      for (; kt + 1 < KT; ++kt, st ^= 1) tile(st, std::true_type{});
+      tile(st, std::false_type{});
+    }
+    if (wm == 0) rendezvous();   // pair the second group's last barrier
+  } else if constexpr (!PF) {
     // One K step.  ISSUE is a compile-time tag: the steady-state loop (a tile to prefetch every step)
     // is straight-line code and the last D steps run the same body without the DMA.
     auto k_step = [&](int kt, auto issue_tag) {
@@ -464,6 +610,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args 
   }
 }
 
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, bool PF, int ABL = 0, int BK = 64>
+__global__ __launch_bounds__(WGM* WGN * 64) void igemm2_kernel(const Igemm2Args a) {
+  igemm2_body<BM, BN, WGM, WGN, NSTAGE, TRANS, SPLIT, PF ? 1 : 0, ABL, BK>(a);
+}
+
+// The ping-pong schedule on the 256x256 / 8-wave / 2-stage tile (LOOP = 2 above).
+template <bool TRANS, int PPOPT>
+__global__ __launch_bounds__(512) void igemm2_pingpong_kernel(const Igemm2Args a) {
+  igemm2_body<256, 256, 2, 4, 2, TRANS, false, 2, 0, 64, PPOPT>(a);
+}
+
 // out[m][n] = bf16( scale * sum_s ws[s][m][n] + bias[n] + rowvec[img(m)][n] + residual[m][n] ): the
 // epilogue of a split-K launch (fixed summation order -> bit-reproducible), 8 channels per thread.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Igemm2Args a) {
@@ -507,13 +664,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Igemm2Args a) 
 }
 
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT = false, bool PF = false, int ABL = 0,
-          int BK = 64>
+          int BK = 64, int PPOPT = -1>
 int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int LDS = NSTAGE * (BM + BN) * BK * 2;
   static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
   static bool attr_set = false;
-  auto kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS, SPLIT, PF, ABL, BK>;
+  void (*kern)(const Igemm2Args);
+  if constexpr (PPOPT >= 0) kern = igemm2_pingpong_kernel<TRANS, PPOPT>;
+  else kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS, SPLIT, PF, ABL, BK>;
   if (!attr_set && !g_dry_run) {
     MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -578,6 +737,10 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
     case 51: return launch2<256, 128, 2, 2, 3, TRANS, true, false, 0, 32>(a, batch_z, s);
     case 52: return launch2<128, 128, 1, 2, 3, TRANS, true, false, 0, 32>(a, batch_z, s);  // 2 waves, wave tile 128x64
     case 53: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 0, 32>(a, batch_z, s);  // 8 waves, wave tile 64x64
+    case 60: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 0>(a, batch_z, s);   // ping-pong schedule
+    case 61: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 1>(a, batch_z, s);   //   without s_setprio
+    case 62: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 4>(a, batch_z, s);   //   2nd DMA piece among the MFMAs
+    case 63: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 5>(a, batch_z, s);   //   both
     case 46: return launch2<128, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);   // full-width tiles for N = 320
     case 47: return launch2<256, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);
     case 48: return launch2<128, 320, 4, 2, 2, TRANS, false>(a, batch_z, s);
@@ -679,7 +842,8 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
 
 // Tile choice, from the round-1 sweeps on MI355X (profiles/r1_sweep*_*.log; TFLOP/s at E = 10):
 //   * 256x256 / 8 waves (wave tile 128x64) when N is a multiple of 256 and there are >= 512 tiles:
-//     VAE 512/256-channel layers 890-1080, GEGLU projections 440-750;
+//     VAE 512/256-channel layers 890-1080, GEGLU projections 440-750 - since sweep 10 with the ping-pong
+//     K loop (variant 62; variant 34 is the same tile with one barrier per K tile);
 //   * 128x320 / 8 waves (wave tile 32x160) for the 320-channel UNet level at large M (730-920);
 //   * 128x64 / 4 waves / 3 stages for other N = 128k+64 and for the deep levels where M is a few
 //     thousand pixels;
@@ -691,8 +855,12 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
   const long long tm256 = (M + 255) / 256;
   // short K (GEGLU projections, K = C linears): 256x128 with 32-deep K tiles - half the LDS per stage,
   // two 8-wave workgroups per CU (GEGLU 525-780 vs 485-770 for 256x256 and 400-700 for the 64-deep tile)
+  const bool many256 = N % 256 == 0 && tm256 * (N / 256) * batch_z >= 512;
+  if (geglu && K >= 1280 && many256) return 62;   // 1280 -> 10240: 831 vs 760-790
   if (N % 128 == 0 && tm256 * (N / 128) * batch_z >= 400 && (geglu || K <= 768)) return 53;
-  if (N % 256 == 0 && tm256 * (N / 256) * batch_z >= 512) return 34;
+  // 256x256 with the ping-pong schedule (two wave groups one barrier apart, 2nd DMA piece among the MFMAs):
+  // +3...10 % over the one-barrier 256x256 tile in interleaved rounds (VAE 512-channel convs 1068 vs 996)
+  if (many256) return 62;
   // N = 320 (UNet level 0): a full-width 128x320 tile reads the activation tile once for all output
   // channels (2.1x fewer LDS-DMA bytes per MFMA than 128x64): 900 vs 740 TFLOP/s on the 640->320 convs
   if (N == 320 && ((M + 127) / 128) * batch_z >= 400) return 46;

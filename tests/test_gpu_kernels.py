@@ -94,6 +94,11 @@ CONV_CASES = [
     ("g2_bk32_3stage_stride2", 2, 16, 16, 64, 128, 2, 1, None, 51),
     ("g2_bk32_128x128_w2", 1, 14, 14, 320, 128, 1, 1, None, 52),
     ("g2_bk32_w8_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 53),
+    ("g2_pingpong_up_nedge", 2, 16, 24, 192, 320, 1, 1, (32, 48), 60),   # 27 K tiles over 9 taps, N edge, 12 M tiles
+    ("g2_pingpong_kt9_stride2", 2, 16, 16, 64, 64, 2, 1, None, 60),
+    ("g2_pingpong_big_k_medge", 1, 13, 12, 1280, 256, 1, 1, None, 60),   # 180 K tiles, M = 156 (one partial tile)
+    ("g2_pingpong_mid_up_nedge", 2, 16, 24, 192, 320, 1, 1, (32, 48), 62),   # 2nd DMA piece issued among the MFMAs
+    ("g2_pingpong_mid_kt9_stride2", 2, 16, 16, 64, 64, 2, 1, None, 63),
     ("g2_128x320", 2, 12, 20, 128, 320, 1, 1, None, 46),
     ("g2_256x320", 2, 12, 20, 64, 640, 1, 1, None, 47),
     ("g2_128x320_burst", 1, 12, 12, 320, 320, 1, 1, None, 48),
@@ -142,7 +147,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = torch.randn(N, generator=g) * 0.1
     ref = x @ w.t() + b
-    for variant in (0, 1, 2, 3, 4, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 46, 50, 51, 52, 53):
+    for variant in (0, 1, 2, 3, 4, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 46, 50, 51, 52, 53, 60, 61, 62, 63):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N,
                         bias=b.to(dev), variant=variant))
@@ -154,7 +159,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     xg = _bf(torch.randn(200, C, generator=g))
     u, gt = (xg @ wg.t() + bg).chunk(2, dim=-1)
     ref = u * F.gelu(gt)
-    for group, variants in ((16, (1, 3)), (32, (20, 23, 24, 27, 34, 53, 0))):
+    for group, variants in ((16, (1, 3)), (32, (20, 23, 24, 27, 34, 53, 60, 62, 0))):
         wp, bp = Wm.pack_geglu(wg, bg, group)
         for variant in variants:
             out = torch.full((200, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
@@ -171,7 +176,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     qk = torch.full((B * T, 3 * C), float("nan"), device=dev, dtype=torch.bfloat16)
     vt = torch.zeros((B, C, ldt), device=dev, dtype=torch.bfloat16)
     refv = refq[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1)
-    for variant in (1, 0, 20, 23, 27):
+    for variant in (1, 0, 20, 23, 27, 60, 62):
         qk.fill_(float("nan"))
         vt.zero_()
         _run(ops.igemm(xq.to(dev, torch.bfloat16), wqkv.to(dev, torch.bfloat16), qk, B=B, H=T, W=1, Cin=C,
@@ -193,12 +198,47 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     refS = torch.einsum("ztd,zsd->zts", qkv[..., :D], qkv[..., D:2 * D]) * 0.25
     qd = qkv.to(dev, torch.bfloat16)
     S = torch.full((Z, T, T), float("nan"), device=dev, dtype=torch.float32)
-    for variant in (1, 0, 20, 27):
+    for variant in (1, 0, 20, 27, 60):
         S.fill_(float("nan"))
         _run(ops.igemm(qd, qd[:, :, D:], S, B=1, H=T, W=1, Cin=D, Ho=T, Wo=1, N=T, epi=L.EPI_F32, ldo=T,
                        lda=3 * D, ldw=3 * D, batch_z=Z, zstrides=(T * 3 * D, T * 3 * D, T * T, 0),
                        scale=0.25, variant=variant))
         _close(f"scores_f32/v{variant}", S, refS, tol=2e-3)
+
+
+def test_igemm_pingpong_short_k_and_repeatability(dev):
+    """Tile variant 60 (two wave groups one barrier apart, four phases per K tile): the one- and two-tile K loops
+    (prologue / drain only), and a many-tile problem launched repeatedly - every launch must give the same bits
+    (a staged half tile read before its DMA landed would show up as run-to-run differences)."""
+    from marigold_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for M, K, N in ((300, 64, 320), (700, 128, 256), (513, 192, 512)):
+        x = _bf(torch.randn(M, K, generator=g))
+        w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+        b = torch.randn(N, generator=g) * 0.1
+        out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N, bias=b.to(dev),
+                        variant=60))
+        _close(f"pingpong/linear K={K}", out, x @ w.t() + b)
+        for v in (62, 63):
+            out.fill_(float("nan"))
+            _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N, bias=b.to(dev),
+                            variant=v))
+            _close(f"pingpong/linear K={K} v{v}", out, x @ w.t() + b)
+    M, K, N = 8192, 2304, 768
+    x = _bf(torch.randn(M, K, generator=g))
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    xd, wd = x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16)
+    ref = x @ w.t()
+    out34 = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    _run(ops.linear(xd, wd, out34, M=M, K=K, N=N, variant=34))
+    _close("linear 8192x2304x768 v34", out34, ref)
+    for v in (60, 61, 62, 63):
+        for rep in range(4):
+            out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+            _run(ops.linear(xd, wd, out, M=M, K=K, N=N, variant=v))
+            # same MFMA sequence per accumulator as the one-barrier 256x256 tile -> identical bits, every launch
+            assert torch.equal(out, out34), f"v{v} launch {rep} differs from the one-barrier tile"
 
 
 # --------------------------------------------------------------------------- norms
