@@ -311,9 +311,10 @@ def main():
                        "hipgraph": bool(args.graph)},
             "roofline": roof,
             "cpu_baseline": cpu,
-            "algorithmic_tflop_per_map": round(flops_per_map / 1e12, 2),
-            "pipeline_tflops": round(flops_per_map * value / 1e12, 1),
-            "pipeline_mfma_frac": round(flops_per_map * value / 1e12 / opstats.MFMA_PEAK_TFLOPS, 4),
+            # whole-map figures only where rank 0 ran the whole map (its programs cover its own members only)
+            "algorithmic_tflop_per_map": round(flops_per_map / 1e12, 2) if world == 1 else None,
+            "pipeline_tflops": round(flops_per_map * value / 1e12, 1) if world == 1 else None,
+            "pipeline_mfma_frac": round(flops_per_map * value / 1e12 / opstats.MFMA_PEAK_TFLOPS, 4) if world == 1 else None,
             "stages": stages,
             "kernels": kernels,
         }
