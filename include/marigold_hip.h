@@ -39,9 +39,10 @@ enum mg_op_kind {
    *  upsampled input size, 0 = none)  i[12] epilogue (MG_EPI_*)  i[13] ldo  i[14] trans_from
    *  (columns >= this go to out2 as [img][n-trans_from][ldt] transposed; -1 = none)
    *  i[15] batch_z  i[16] ldr  i[17] lda  i[18] ldt  i[19] tile variant (0 = auto; 1..13 force a
- *  generation-1 tile, 20..28 a generation-2 tile - used by the tuning sweep)  i[20] ldw
+   *  generation-1 tile, 20..53 a generation-2 tile, 60..63 the 256x256 ping-pong schedule - used by the
+   *  tuning sweep and the parity tests, see igemm2.hip::dispatch_tile)  i[20] ldw
    *  i[21] rowvec broadcast (1 = a single [N] row shared by every image)
- *  i[22], i[23] un-padded N, K for FLOP accounting (0 = as launched; ignored by the kernel)
+   *  i[22], i[23] un-padded N, K for FLOP accounting (0 = as launched; ignored by the kernel)
    *  l[0..3] z-strides (elements) of A, Wt, out, residual      f[0] scale on the accumulator */
   MG_OP_IGEMM = 1,
   /* GroupNorm, 3 launches (stats partials -> per-(b,c) scale/shift -> apply [+SiLU]).
