@@ -18,7 +18,7 @@ g = torch.Generator(device="cpu").manual_seed(1)
 REPS = int(os.environ.get("REPS", "3"))
 
 
-def conv(B, HW, Cin, N, taps, geglu=False):
+def conv(B, HW, Cin, N, taps, geglu=False, variant=0):
     M = B * HW * HW
     K = taps * Cin
     x = (torch.randn(M, Cin, generator=g) * 0.5).to(dev, torch.bfloat16)
@@ -26,7 +26,7 @@ def conv(B, HW, Cin, N, taps, geglu=False):
     bias = torch.randn(N, generator=g).to(dev)
     out = torch.empty(M, N // 2 if geglu else N, device=dev, dtype=torch.bfloat16)
     op = O.igemm(x, w, out, B=B, H=HW, W=HW, Cin=Cin, Ho=HW, Wo=HW, N=N, taps=taps, stride=1,
-                 pad=1 if taps == 9 else 0, bias=bias, epi=L.EPI_GEGLU if geglu else L.EPI_BF16)
+                 pad=1 if taps == 9 else 0, bias=bias, epi=L.EPI_GEGLU if geglu else L.EPI_BF16, variant=variant)
     for _ in range(REPS):
         O.launch(op)
     torch.cuda.synchronize()
@@ -48,6 +48,7 @@ def flash(B, heads, T):
 flash(10, 5, 9216)
 conv(10, 96, 320, 320, 9)      # 128x64 tile
 conv(10, 48, 640, 640, 9)      # 256x128 tile, 3 stages
-conv(10, 96, 512, 512, 9)      # 256x256 tile (VAE)
+conv(10, 96, 512, 512, 9)      # 256x256 tile, ping-pong K loop (VAE; the automatic choice)
+conv(10, 96, 512, 512, 9, variant=34)   # same tile, one barrier per K tile
 conv(10, 96, 320, 2560, 1, geglu=True)
 print("microbench done")
