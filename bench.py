@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--ensemble", type=int, default=10)
     ap.add_argument("--denoise", type=int, default=10)
     ap.add_argument("--res", type=int, default=768)
-    ap.add_argument("--kind", default="depth", choices=["depth", "normals"])
+    ap.add_argument("--kind", default="depth", choices=["depth", "normals", "iid"],
+                    help="iid = the appearance model (albedo + material: UNet 12 -> 8 latent channels)")
     ap.add_argument("--scheduler", default="ddim", choices=["ddim", "lcm"], help="ddim = v1-1 (trailing, zero-SNR); lcm = depth-lcm-v1-0")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,6 +81,10 @@ def cpu_baseline(args, members_path):
     from oracle.sd2_unet import UNet2DConditionModel
     from oracle.sd2_vae import AutoencoderKL
     ucfg, vcfg = (TINY_UNET, TINY_VAE) if args.tiny else (UNetConfig(), VAEConfig())
+    n_dec = 1
+    if args.kind == "iid":
+        import dataclasses
+        ucfg, n_dec = dataclasses.replace(ucfg, in_channels=12, out_channels=8), 2   # one VAE decode per modality
     usd, vsd = syn.synthetic_unet_state_dict(ucfg), syn.synthetic_vae_state_dict(vcfg)
     ctx = syn.synthetic_text_embedding(ucfg.cross_attention_dim)
     members = torch.from_numpy(np.load(members_path)) if members_path and os.path.exists(members_path) else None
@@ -89,10 +94,11 @@ def cpu_baseline(args, members_path):
     lat = res // 8
     t = {}
     with torch.no_grad():
-        unet = UNet2DConditionModel(block_out_channels=ucfg.block_out_channels, attention_head_dim=ucfg.heads,
+        unet = UNet2DConditionModel(in_channels=ucfg.in_channels, out_channels=ucfg.out_channels,
+                                    block_out_channels=ucfg.block_out_channels, attention_head_dim=ucfg.heads,
                                     cross_attention_dim=ucfg.cross_attention_dim).eval()
         unet.load_state_dict(usd)
-        x = torch.randn(1, 8, lat, lat)
+        x = torch.randn(1, ucfg.in_channels, lat, lat)
         t0 = time.perf_counter()
         unet(x, torch.tensor(999), ctx)
         t["unet_fwd"] = time.perf_counter() - t0
@@ -131,7 +137,7 @@ def cpu_baseline(args, members_path):
             for _ in range(5):
                 orig(p, m, True, True, "median", 0.02)
             t["ensemble"] = (time.perf_counter() - t0) / 5 * n_eval
-    per_map = E * (t["vae_encode"] + T * t["unet_fwd"] + t["vae_decode"]) + t["ensemble"]
+    per_map = E * (t["vae_encode"] + T * t["unet_fwd"] + n_dec * t["vae_decode"]) + t["ensemble"]
     return {"value": 1.0 / per_map, "unit": f"{args.kind} maps/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
             "sample": (f"CPU oracle fp32: 1 UNet fwd @{lat}x{lat} latent ({t['unet_fwd']:.2f}s) + VAE enc/dec "
                        f"@{min(res, 256)}^2 scaled x{scale:.0f} by pixels ({t['vae_encode']:.1f}s/{t['vae_decode']:.1f}s) "
@@ -167,15 +173,22 @@ def main():
     from marigold_amd.schedulers import DDIMScheduler, LCMScheduler
 
     ucfg, vcfg = (TINY_UNET, TINY_VAE) if args.tiny else (UNetConfig(), VAEConfig())
+    if args.kind == "iid":
+        import dataclasses
+        ucfg = dataclasses.replace(ucfg, in_channels=12, out_channels=8)
     t0 = time.perf_counter()
     usd = syn.synthetic_unet_state_dict(ucfg)
     vsd = syn.synthetic_vae_state_dict(vcfg)
     ctx = syn.synthetic_text_embedding(ucfg.cross_attention_dim)
-    cls = M.MarigoldDepthPipeline if args.kind == "depth" else M.MarigoldNormalsPipeline
+    cls = {"depth": M.MarigoldDepthPipeline, "normals": M.MarigoldNormalsPipeline, "iid": M.MarigoldIIDPipeline}[args.kind]
+    extra = {}
+    if args.kind == "iid":
+        extra["target_properties"] = {"target_names": ["albedo", "material"], "albedo": {"prediction_space": "srgb"},
+                                      "material": {"prediction_space": "stack"}}
     pipe = cls(unet=UNet2DConditionModelHIP(usd, ucfg), vae=AutoencoderKLHIP(vsd, vcfg),
                scheduler=DDIMScheduler() if args.scheduler == "ddim" else LCMScheduler(), empty_text_embed=ctx,
                default_denoising_steps=args.denoise,
-               default_processing_resolution=0).to(dev)
+               default_processing_resolution=0, **extra).to(dev)
     if world > 1:
         pipe.enable_member_parallel(root=0)
     if rank == 0:
@@ -219,7 +232,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     if rank == 0:
-        res = out.depth_np if args.kind == "depth" else out.normals_np
+        res = {"depth": lambda: out.depth_np, "normals": lambda: out.normals_np,
+               "iid": lambda: out["albedo"].array}[args.kind]()
         assert res is not None and res.shape[-2:] == (args.res, args.res)
         import numpy as np
         assert np.isfinite(res).all()

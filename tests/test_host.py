@@ -249,6 +249,17 @@ def test_full_size_programs_validate_without_gpu():
     seq, _, _ = vae._program("decode", 2, 96, 96, 1)
     seq.validate()
     assert abs(opstats.program_flops(seq.ops) / 2 / 1e9 - 5754.3) < 5
+    # the IID family at full size (appearance: 2 modalities -> 12 in / 8 out latent channels; lighting: 3 -> 16 / 12):
+    # conv_in / conv_out widths differ, the modalities ride in the batch of ONE decode program
+    for n_targets in (2, 3):
+        icfg = UNetConfig(in_channels=4 + 4 * n_targets, out_channels=4 * n_targets)
+        iunet = UNet2DConditionModelHIP({k: torch.zeros(sh) for k, sh in unet_param_shapes(icfg).items()}, icfg).dry()
+        iunet.set_context(torch.zeros(1, 2, 1024))
+        iprog = iunet.denoise_program(2, 96, 96, DDIMScheduler(), 1)
+        iprog.seq.validate()
+        assert tuple(iprog.x.shape) == (2, 4 * n_targets, 96, 96)
+        seq, _, _ = vae._program("decode", 2 * n_targets, 96, 96, 3)   # post = MG_POST_UNIT
+        seq.validate()
     # odd sizes (C1: 384x512 input up-scaled to 576x768 -> 72x96 latent) and a contract violation
     unet.denoise_program(1, 72, 96, DDIMScheduler(timestep_spacing="leading", rescale_betas_zero_snr=False), 1).seq.validate()
     from marigold_amd import _lib as L, ops as O
