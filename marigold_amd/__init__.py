@@ -13,13 +13,19 @@ def build_synthetic_pipeline(kind="depth", unet_cfg=None, vae_cfg=None, schedule
     from .arch import UNetConfig, VAEConfig
     from .modules import AutoencoderKLHIP, UNet2DConditionModelHIP
     from .schedulers import DDIMScheduler
+    if kind == "iid":   # appearance model: albedo + material
+        kw.setdefault("target_properties", {"target_names": ["albedo", "material"],
+                                            "albedo": {"prediction_space": "srgb"},
+                                            "material": {"prediction_space": "stack"}})
+        n = len(kw["target_properties"]["target_names"])
+        unet_cfg = unet_cfg or UNetConfig(in_channels=4 + 4 * n, out_channels=4 * n)
     unet_cfg = unet_cfg or UNetConfig()
     vae_cfg = vae_cfg or VAEConfig()
     unet = UNet2DConditionModelHIP(syn.synthetic_unet_state_dict(unet_cfg, seed), unet_cfg)
     vae = AutoencoderKLHIP(syn.synthetic_vae_state_dict(vae_cfg, seed), vae_cfg)
     emb = syn.synthetic_text_embedding(unet_cfg.cross_attention_dim)
     scheduler = scheduler or DDIMScheduler()
-    cls = MarigoldDepthPipeline if kind == "depth" else MarigoldNormalsPipeline
+    cls = {"depth": MarigoldDepthPipeline, "normals": MarigoldNormalsPipeline, "iid": MarigoldIIDPipeline}[kind]
     kw.setdefault("default_denoising_steps", 4)
     kw.setdefault("default_processing_resolution", 768)
     return cls(unet=unet, vae=vae, scheduler=scheduler, empty_text_embed=emb, **kw)

@@ -123,3 +123,19 @@ def pil_to_tensor(img):
     if arr.ndim == 2:
         arr = arr[:, :, None]
     return torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+
+
+def float2int(img):
+    """[0,1] float -> uint8 by truncation (reference image_util.py:137-141)."""
+    if isinstance(img, np.ndarray):
+        return (img * 255.0).astype(np.uint8)
+    return (img * 255.0).to(torch.uint8)
+
+
+def srgb2linear(img):
+    """gamma-2.2 decode (reference image_util.py:144-145)."""
+    return img ** 2.2
+
+
+def linear2srgb(img):
+    return img ** (1.0 / 2.2)
