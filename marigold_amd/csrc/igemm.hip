@@ -333,6 +333,7 @@ int launch_variant(const IgemmArgs& a, int batch_z, hipStream_t s) {
 int mg_launch_igemm(const mg_op* op, hipStream_t s) {
   {
     const int v = op->i[19];
+    if (v >= 70 && v < 80) return mg_launch_igemm3(op, s, v);
     if ((v == 0 && mg_igemm_generation() == 2) || v >= 20) {
       const int rc = mg_launch_igemm2(op, s, v);
       if (rc >= 0) return rc;

@@ -459,3 +459,33 @@ def test_iid_output_container_and_pipeline_contract():
     prog = unet.denoise_program(2, 8, 16, DDIMScheduler(), 2)
     prog.seq.validate()
     assert tuple(prog.x.shape) == (2, 8, 8, 16) and tuple(prog.eps.shape) == (2, 8, 8, 16)
+
+
+def test_halo_conv_index_model():
+    """Index model of the experimental halo-shared 3x3 tile (csrc/igemm3.hip): one staged activation tile of
+    256 + 2 pixels per (ky, channel tile) serves the three kx taps - LDS row `slot` holds input pixel
+    m0 - 1 + slot + (ky - 1) * W (zero when that pixel's own image row is not the row this ky reads for it), the
+    fragment of output pixel r for tap kx is row r + kx, or the zero row when x + kx - 1 leaves the image row.
+    Checked against a plain zero-padded im2col for several image shapes, including W = 1 and tiles that span
+    images."""
+    rng = np.random.default_rng(5)
+    BM, ROWS = 256, 264
+    for B, H, W in ((2, 5, 7), (3, 9, 31), (1, 20, 13), (2, 3, 1), (1, 1, 300)):
+        HW, M = H * W, B * H * W
+        img = rng.integers(1, 1000, size=(B, H, W)).astype(np.int64)   # one "channel" is enough for the index logic
+        flat = img.reshape(-1)
+        pad = np.zeros((B, H + 2, W + 2), np.int64)
+        pad[:, 1:-1, 1:-1] = img
+        for m0 in range(0, M, BM):
+            for ky in range(3):
+                staged = np.zeros(ROWS + 1, np.int64)   # last entry = the zero row
+                for slot in range(ROWS):
+                    q = m0 - 1 + slot + (ky - 1) * W
+                    if 0 <= q < M and 0 <= (q % HW) // W - ky + 1 < H:
+                        staged[slot] = flat[q]
+                for kx in range(3):
+                    for r in range(min(BM, M - m0)):
+                        m = m0 + r
+                        b, y, x = m // HW, (m % HW) // W, (m % HW) % W
+                        j = r + kx if 0 <= x + kx - 1 < W else ROWS
+                        assert staged[j] == pad[b, y + ky, x + kx], (B, H, W, m0, ky, kx, r)
