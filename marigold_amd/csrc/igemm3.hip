@@ -59,6 +59,9 @@ constexpr int H_LDS = 2 * H_A_STAGE + 3 * H_B_STAGE;  // 116 992 B
 // read), as in igemm2.hip: conflict-free ds_read_b128 on 128-byte rows.
 __device__ __forceinline__ int h_swz(int chunk, int row) { return chunk ^ ((row >> 1) & 7); }
 
+// SPLIT: the step's LDS-DMA pieces are issued between the k-substeps' fragment reads and MFMAs (same issue ORDER as
+// the burst form, so the counted waits are unchanged) instead of in one burst after the barrier.
+template <bool SPLIT>
 __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sA = smem;                       // [2][265 rows][128 B]
@@ -126,16 +129,20 @@ __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
     b_base[it] = n < a.N ? (const char*)(a.Wt + (long long)n * a.ldw + h_swz(p, row) * 8) : nullptr;
   }
   int b_ky = 0, b_c = 0, b_kx = 0;   // the K step whose weight tile is issued next
-  auto b_issue = [&](int stage) {
+  auto b_piece = [&](int stage, int it) {
     const long long kofs = ((long long)(b_ky * 3 + b_kx) * a.Cin + b_c * 64) * 2;
-    const bool live = b_ky < 3;
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-      glds16((live && b_base[it]) ? b_base[it] + kofs : zero, sB + stage * H_B_STAGE + (it * H_NT + wave * 64) * 16);
+    glds16((b_ky < 3 && b_base[it]) ? b_base[it] + kofs : zero, sB + stage * H_B_STAGE + (it * H_NT + wave * 64) * 16);
+  };
+  auto b_advance = [&]() {
     if (++b_kx == 3) {
       b_kx = 0;
       if (++b_c == a.cpt) { b_c = 0; ++b_ky; }
     }
+  };
+  auto b_issue = [&](int stage) {
+    b_piece(stage, 0);
+    b_piece(stage, 1);
+    b_advance();
   };
 
   // ---- fragment addresses (fixed for the tile): output row r, tap kx -> LDS row r + kx, or the zero row ----
@@ -185,9 +192,19 @@ __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
     h_wait_vmcnt<(KX == 0 ? 2 : KX == 1 ? 5 : 7)>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    b_issue(st_b >= 1 ? st_b - 1 : 2);
-    if constexpr (KX == 0) { a_issue(st_a ^ 1, 0); a_issue(st_a ^ 1, 1); a_issue(st_a ^ 1, 2); }
-    if constexpr (KX == 1) { a_issue(st_a ^ 1, 3); a_issue(st_a ^ 1, 4); a_advance(); }
+    const int st_i = st_b >= 1 ? st_b - 1 : 2;   // (st_b + 2) % 3
+    // the step's pieces, in issue order: weights 0, 1, then the next activation tile's 0..2 (kx 0) / 3, 4 (kx 1)
+    constexpr int NP = KX == 0 ? 5 : KX == 1 ? 4 : 2;
+    auto piece = [&](int i) {
+      if (i < 2) b_piece(st_i, i);
+      else a_issue(st_a ^ 1, (KX == 0 ? 0 : 3) + i - 2);
+      if (i == 1) b_advance();
+      if (KX == 1 && i == NP - 1) a_advance();
+    };
+    if constexpr (!SPLIT) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) piece(i);
+    }
     const char* pa = sA + st_a * H_A_STAGE;
     const char* pb = sB + st_b * H_B_STAGE;
 #pragma unroll
@@ -197,6 +214,11 @@ __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
       for (int mi = 0; mi < 2; ++mi) fa[mi] = __builtin_bit_cast(bf16x8, *(const uint4*)(pa + (a_off[mi][KX] ^ (ks << 5))));
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) fb[ni] = __builtin_bit_cast(bf16x8, *(const uint4*)(pb + (b_off[ni] ^ (ks << 5))));
+      if constexpr (SPLIT) {   // pieces i with i * 4 / NP == ks, in order
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+          if (i * 4 / NP == ks) piece(i);
+      }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -286,7 +308,7 @@ int mg_launch_igemm3(const mg_op* op, hipStream_t s, int variant) {
   a.HW = a.H * a.W;
   a.M = B * a.HW;
   a.cpt = a.Cin / 64;
-  MG_REQUIRE(variant == 70, "igemm: unknown halo tile variant %d", variant);
+  MG_REQUIRE(variant == 70 || variant == 71, "igemm: unknown halo tile variant %d", variant);
   MG_REQUIRE(g_zero_page || g_dry_run, "igemm: mg_init() not called");
   MG_REQUIRE(a.A && a.Wt && a.out, "igemm(halo): null pointer");
   MG_REQUIRE(op->i[7] == 9 && op->i[8] == 1 && op->i[9] == 1 && op->i[10] == 0 && op->i[11] == 0 &&
@@ -302,14 +324,15 @@ int mg_launch_igemm3(const mg_op* op, hipStream_t s, int variant) {
              "igemm(halo): 16-byte alignment");
   a.tiles_m = (a.M + H_BM - 1) / H_BM;
   a.tiles_n = (a.N + H_BN - 1) / H_BN;
-  static bool attr_set = false;
-  if (!attr_set && !g_dry_run) {
-    MG_CHECK_HIP(hipFuncSetAttribute((const void*)igemm3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS));
-    attr_set = true;
+  void (*kern)(const Igemm3Args) = variant == 71 ? igemm3_halo_kernel<true> : igemm3_halo_kernel<false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[variant == 71] && !g_dry_run) {
+    MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS));
+    attr_set[variant == 71] = true;
   }
   const long long grid = (long long)a.tiles_m * a.tiles_n;
   MG_REQUIRE(grid > 0 && grid < (1ll << 31), "igemm(halo): bad grid %lld", grid);
-  MG_LAUNCH(igemm3_halo_kernel, dim3((unsigned)grid), dim3(H_NT), H_LDS, s, a);
+  MG_LAUNCH(kern, dim3((unsigned)grid), dim3(H_NT), H_LDS, s, a);
   if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -1,5 +1,5 @@
 """GPU parity tests of EXPERIMENTAL kernels that no product path selects (run with MG_EXPERIMENTAL=1).
-Currently: the halo-shared 3x3 convolution tile (csrc/igemm3.hip, MG_OP_IGEMM tile variant 70)."""
+Currently: the halo-shared 3x3 convolution tile (csrc/igemm3.hip, MG_OP_IGEMM tile variants 70 / 71)."""
 import math
 import os
 
@@ -48,14 +48,14 @@ def test_halo_conv3x3(case):
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()   # noqa: E731
     M = B * H * W
     outs = {}
-    for variant in (70, 23):   # the experimental tile and a validated one on identical buffers
+    for variant in (70, 71, 23):   # the experimental tiles (burst / split DMA issue) and a validated one
         out = torch.full((M, Cout), float("nan"), device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
         op = ops.igemm(nhwc(x).to(dev, torch.bfloat16), Wm.pack_conv3x3(w).to(dev, torch.bfloat16), out, B=B, H=H, W=W,
                        Cin=Cin, Ho=H, Wo=W, N=Cout, taps=9, stride=1, pad=1, bias=b.to(dev),
                        rowvec=None if rv is None else rv.to(dev).contiguous(),
                        residual=None if res is None else nhwc(res).reshape(M, Cout).to(dev, torch.bfloat16),
                        epi=L.EPI_F32 if f32 else L.EPI_BF16, variant=variant)
-        for _ in range(3 if variant == 70 else 1):
+        for _ in range(3 if variant >= 70 else 1):
             ops.launch(op)
         torch.cuda.synchronize()
         outs[variant] = out.float().cpu()
