@@ -48,12 +48,27 @@ __device__ __forceinline__ void h_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr int H_BM = 256, H_BN = 128, H_NT = 512, H_ROWB = 128;
+constexpr int H_BM = 256, H_NT = 512, H_ROWB = 128;
 constexpr int H_A_BLOCKS = 33;                       // 8-row DMA blocks of the activation tile: 264 rows >= 256 + 2
 constexpr int H_ZERO_ROW = H_A_BLOCKS * 8;           // LDS row 264 of every activation stage holds zeros
 constexpr int H_A_STAGE = (H_ZERO_ROW + 1) * H_ROWB;  // 33 920 B
-constexpr int H_B_STAGE = H_BN * H_ROWB;             // 16 384 B
-constexpr int H_LDS = 2 * H_A_STAGE + 3 * H_B_STAGE;  // 116 992 B
+constexpr int h_lds_bytes(int bn, int nstb) { return 2 * H_A_STAGE + nstb * bn * H_ROWB; }   // 256x128x3: 116 992 B
+// Counted wait at the top of a kx step: the loads that may still be in flight once the step's weight tile (issued
+// D = NSTB - 1 steps ago as the FIRST pieces of its step) and, for kx = 0, the whole activation tile (last pieces
+// issued in the kx = 1 step of the previous triple) have landed.  PB = weight pieces per wave per step; the next
+// activation tile goes out as 3 pieces in the kx = 0 step and 2 in the kx = 1 step, after the weights.
+constexpr int h_wait_count(int kx, int d, int pb) {
+  const int a[3] = {3, 2, 0};
+  int younger = a[(kx + 3 - d % 3) % 3];                 // activation pieces that followed the tile in its own step
+  for (int j = 1; j < d; ++j) younger += pb + a[(kx + 3 - j % 3) % 3];
+  if (kx == 0) {                                          // activation tile: everything up to step k-2 must be back
+    const int act = d >= 2 ? pb : 0;                      // (with D = 1 nothing younger than it has been issued)
+    younger = younger < act ? younger : act;
+  }
+  return younger;
+}
+static_assert(h_wait_count(0, 2, 2) == 2 && h_wait_count(1, 2, 2) == 5 && h_wait_count(2, 2, 2) == 7, "256x128x3 waits");
+static_assert(h_wait_count(0, 1, 4) == 0 && h_wait_count(1, 1, 4) == 3 && h_wait_count(2, 1, 4) == 2, "256x256x2 waits");
 
 // XOR swizzle of the 16-byte chunk index by the LDS row (both on the DMA source address and on the fragment
 // read), as in igemm2.hip: conflict-free ds_read_b128 on 128-byte rows.
@@ -61,19 +76,28 @@ __device__ __forceinline__ int h_swz(int chunk, int row) { return chunk ^ ((row 
 
 // SPLIT: the step's LDS-DMA pieces are issued between the k-substeps' fragment reads and MFMAs (same issue ORDER as
 // the burst form, so the counted waits are unchanged) instead of in one burst after the barrier.
-template <bool SPLIT>
+// Geometry: 256 output pixels x BN channels per workgroup, 8 waves as WGM x WGN; NSTB weight stages.
+//   <128, 4, 2, 3>: wave tile 64 x 64, 117 KB LDS  (variants 70 / 71 - the form whose first GPU run was correct)
+//   <256, 2, 4, 2>: wave tile 128 x 64, 132 KB LDS (variants 72 / 73 - not yet run)
+template <int BN, int WGM, int WGN, int NSTB, bool SPLIT>
 __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
+  static_assert(WGM * WGN * 64 == H_NT && (NSTB == 2 || NSTB == 3), "8 waves, 2 or 3 weight stages");
+  constexpr int TM = H_BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
+  constexpr int PB = BN * 8 / H_NT;            // weight pieces per wave per K step
+  constexpr int D = NSTB - 1;                  // weight prefetch distance in K steps
+  constexpr int H_B_STAGE = BN * H_ROWB;
+  static_assert(MI >= 1 && NI >= 1 && PB >= 1 && h_lds_bytes(BN, NSTB) <= 160 * 1024, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sA = smem;                       // [2][265 rows][128 B]
-  char* const sB = smem + 2 * H_A_STAGE;       // [3][128 rows][128 B]
+  char* const sB = smem + 2 * H_A_STAGE;       // [NSTB][BN rows][128 B]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;     // 4 x 2 waves, wave tile 64 x 64
+  const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, half = lane >> 5;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
-  const int m0 = tile_m * H_BM, n0 = tile_n * H_BN;
+  const int m0 = tile_m * H_BM, n0 = tile_n * BN;
   const char* zero = (const char*)a.zero;
 
   // zero rows of both activation stages, visible before any DMA is in flight
@@ -82,29 +106,25 @@ __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
 
   // ---- activation staging: 5 pieces per wave per (ky, channel tile); piece i covers LDS rows blk*8 .. +7,
   //      blk = min(i*8 + wave, 32) (the pieces past block 32 repeat it: same bytes to the same place) ----
-  int a_blk[5], a_slot[5];   // a_blk is wave-uniform (it becomes the LDS-DMA base), a_slot = this lane's LDS row
-  const char* a_ptr[5];
+  uint32_t a_ptr[5];   // byte offsets from a.A (the tensor is < 4 GiB, checked by the launcher)
   unsigned a_valid = 0;
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    a_blk[i] = min(i * 8 + wave, H_A_BLOCKS - 1);
-    a_slot[i] = a_blk[i] * 8 + (lane >> 3);
-  }
+  auto a_blk = [&](int i) { return min(i * 8 + wave, H_A_BLOCKS - 1); };   // wave-uniform: the LDS-DMA base
+  auto a_slot = [&](int i) { return a_blk(i) * 8 + (lane >> 3); };          // this lane's LDS row of piece i
   auto a_setup = [&](int ky) {   // LDS row `slot` holds input pixel m0 - 1 + slot + (ky - 1) * W
     a_valid = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      const long long q = (long long)m0 - 1 + a_slot[i] + (long long)(ky - 1) * a.W;
+      const long long q = (long long)m0 - 1 + a_slot(i) + (long long)(ky - 1) * a.W;
       bool ok = q >= 0 && q < a.M;
       const int qq = ok ? (int)q : 0;
       const int ys = (qq % a.HW) / a.W;        // the output row this input row serves is ys - (ky - 1)
       ok = ok && (unsigned)(ys - ky + 1) < (unsigned)a.H;
-      a_ptr[i] = (const char*)(a.A + (long long)qq * a.lda + h_swz(lane & 7, a_slot[i]) * 8);
+      a_ptr[i] = (uint32_t)(((long long)qq * a.lda + h_swz(lane & 7, a_slot(i)) * 8) * 2);
       a_valid |= ok ? (1u << i) : 0u;
     }
   };
   auto a_issue = [&](int stage, int i) {
-    glds16((a_valid >> i) & 1 ? a_ptr[i] : zero, sA + stage * H_A_STAGE + a_blk[i] * 8 * H_ROWB);
+    glds16((a_valid >> i) & 1 ? (const char*)a.A + a_ptr[i] : zero, sA + stage * H_A_STAGE + a_blk(i) * 8 * H_ROWB);
   };
   int i_ky = 0, i_c = 0;   // the (ky, channel tile) whose activation tile is issued next
   auto a_advance = [&]() {
@@ -119,19 +139,20 @@ __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
     }
   };
 
-  // ---- weight staging: 2 pieces per wave per K step; K step (ky, c, kx) reads k = (ky*3 + kx)*Cin + c*64 ----
-  const char* b_base[2];
+  // ---- weight staging: PB pieces per wave per K step; K step (ky, c, kx) reads k = (ky*3 + kx)*Cin + c*64 ----
+  uint32_t b_base[PB];   // byte offsets from a.Wt (< 4 GiB, checked by the launcher); ~0 = row beyond N
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < PB; ++it) {
     const int ci = it * H_NT + tid;
     const int row = ci >> 3, p = ci & 7;
     const int n = n0 + row;
-    b_base[it] = n < a.N ? (const char*)(a.Wt + (long long)n * a.ldw + h_swz(p, row) * 8) : nullptr;
+    b_base[it] = n < a.N ? (uint32_t)(((long long)n * a.ldw + h_swz(p, row) * 8) * 2) : 0xffffffffu;
   }
   int b_ky = 0, b_c = 0, b_kx = 0;   // the K step whose weight tile is issued next
   auto b_piece = [&](int stage, int it) {
-    const long long kofs = ((long long)(b_ky * 3 + b_kx) * a.Cin + b_c * 64) * 2;
-    glds16((b_ky < 3 && b_base[it]) ? b_base[it] + kofs : zero, sB + stage * H_B_STAGE + (it * H_NT + wave * 64) * 16);
+    const uint32_t kofs = (uint32_t)(((b_ky * 3 + b_kx) * a.Cin + b_c * 64) * 2);
+    glds16((b_ky < 3 && b_base[it] != 0xffffffffu) ? (const char*)a.Wt + (b_base[it] + kofs) : zero,
+           sB + stage * H_B_STAGE + (it * H_NT + wave * 64) * 16);
   };
   auto b_advance = [&]() {
     if (++b_kx == 3) {
@@ -140,16 +161,16 @@ __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
     }
   };
   auto b_issue = [&](int stage) {
-    b_piece(stage, 0);
-    b_piece(stage, 1);
+#pragma unroll
+    for (int it = 0; it < PB; ++it) b_piece(stage, it);
     b_advance();
   };
 
   // ---- fragment addresses (fixed for the tile): output row r, tap kx -> LDS row r + kx, or the zero row ----
-  int a_off[2][3], b_off[2];
+  int a_off[MI][3], b_off[NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int r = wm * 64 + mi * 32 + l31;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int r = wm * TM + mi * 32 + l31;
     const int x = ((m0 + r) % a.HW) % a.W;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
@@ -159,28 +180,28 @@ __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
     }
   }
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int r = wn * 64 + ni * 32 + l31;
+  for (int ni = 0; ni < NI; ++ni) {
+    const int r = wn * TN + ni * 32 + l31;
     b_off[ni] = r * H_ROWB + (h_swz(half, r) << 4);
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[NI][MI];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
+  for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-  // ---- prologue: activation tile of (ky 0, c 0), weight tiles of K steps 0 and 1 ----
+  // ---- prologue: activation tile of (ky 0, c 0), weight tiles of the first D K steps ----
   a_setup(0);
 #pragma unroll
   for (int i = 0; i < 5; ++i) a_issue(0, i);
   a_advance();
-  b_issue(0);
-  b_issue(1);
+#pragma unroll
+  for (int d = 0; d < D; ++d) b_issue(d);
 
-  int st_b = 0;   // weight stage of the current K step; the step issues into (st_b + 2) % 3
+  int st_b = 0;   // weight stage of the current K step; the step issues into (st_b + D) % NSTB
   int st_a = 0;   // activation stage of the current (ky, c)
   auto step = [&](auto kx_tag) {
     constexpr int KX = decltype(kx_tag)::value;
@@ -189,16 +210,16 @@ __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // younger loads that may stay in flight: see the header (issue order inside a step: weights, then activation)
-    h_wait_vmcnt<(KX == 0 ? 2 : KX == 1 ? 5 : 7)>();
+    h_wait_vmcnt<h_wait_count(KX, D, PB)>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    const int st_i = st_b >= 1 ? st_b - 1 : 2;   // (st_b + 2) % 3
-    // the step's pieces, in issue order: weights 0, 1, then the next activation tile's 0..2 (kx 0) / 3, 4 (kx 1)
-    constexpr int NP = KX == 0 ? 5 : KX == 1 ? 4 : 2;
+    const int st_i = st_b >= 1 ? st_b - 1 : NSTB - 1;   // (st_b + D) % NSTB
+    // the step's pieces, in issue order: the weights, then the next activation tile's 0..2 (kx 0) / 3, 4 (kx 1)
+    constexpr int NP = PB + (KX == 0 ? 3 : KX == 1 ? 2 : 0);
     auto piece = [&](int i) {
-      if (i < 2) b_piece(st_i, i);
-      else a_issue(st_a ^ 1, (KX == 0 ? 0 : 3) + i - 2);
-      if (i == 1) b_advance();
+      if (i < PB) b_piece(st_i, i);
+      else a_issue(st_a ^ 1, (KX == 0 ? 0 : 3) + i - PB);
+      if (i == PB - 1) b_advance();
       if (KX == 1 && i == NP - 1) a_advance();
     };
     if constexpr (!SPLIT) {
@@ -209,23 +230,23 @@ __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
     const char* pb = sB + st_b * H_B_STAGE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[MI], fb[NI];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) fa[mi] = __builtin_bit_cast(bf16x8, *(const uint4*)(pa + (a_off[mi][KX] ^ (ks << 5))));
+      for (int mi = 0; mi < MI; ++mi) fa[mi] = __builtin_bit_cast(bf16x8, *(const uint4*)(pa + (a_off[mi][KX] ^ (ks << 5))));
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) fb[ni] = __builtin_bit_cast(bf16x8, *(const uint4*)(pb + (b_off[ni] ^ (ks << 5))));
+      for (int ni = 0; ni < NI; ++ni) fb[ni] = __builtin_bit_cast(bf16x8, *(const uint4*)(pb + (b_off[ni] ^ (ks << 5))));
       if constexpr (SPLIT) {   // pieces i with i * 4 / NP == ks, in order
 #pragma unroll
         for (int i = 0; i < NP; ++i)
           if (i * 4 / NP == ks) piece(i);
       }
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
     }
-    st_b = st_b == 2 ? 0 : st_b + 1;
+    st_b = st_b == NSTB - 1 ? 0 : st_b + 1;
   };
   const int triples = 3 * a.cpt;
   for (int t = 0; t < triples; ++t) {
@@ -240,10 +261,10 @@ __global__ __launch_bounds__(H_NT) void igemm3_halo_kernel(const Igemm3Args a) {
   //      a lane^32 exchange leaves 8 consecutive output channels per lane -> 16-byte stores ----
   const float scale = a.scale;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int mb = m0 + wm * 64 + mi * 32, nb = n0 + wn * 64 + ni * 32;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int mb = m0 + wm * TM + mi * 32, nb = n0 + wn * TN + ni * 32;
 #pragma unroll
       for (int gp = 0; gp < 2; ++gp) {
         float v[8];
@@ -308,7 +329,7 @@ int mg_launch_igemm3(const mg_op* op, hipStream_t s, int variant) {
   a.HW = a.H * a.W;
   a.M = B * a.HW;
   a.cpt = a.Cin / 64;
-  MG_REQUIRE(variant == 70 || variant == 71, "igemm: unknown halo tile variant %d", variant);
+  MG_REQUIRE(variant >= 70 && variant <= 73, "igemm: unknown halo tile variant %d", variant);
   MG_REQUIRE(g_zero_page || g_dry_run, "igemm: mg_init() not called");
   MG_REQUIRE(a.A && a.Wt && a.out, "igemm(halo): null pointer");
   MG_REQUIRE(op->i[7] == 9 && op->i[8] == 1 && op->i[9] == 1 && op->i[10] == 0 && op->i[11] == 0 &&
@@ -319,20 +340,30 @@ int mg_launch_igemm3(const mg_op* op, hipStream_t s, int variant) {
   MG_REQUIRE(a.Cin > 0 && a.Cin % 64 == 0 && a.N > 0 && a.N % 8 == 0, "igemm(halo): Cin %% 64, N %% 8");
   MG_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldo % 8 == 0 && a.ldr % 8 == 0, "igemm(halo): leading dims %% 8");
   MG_REQUIRE((long long)B * a.HW < (1ll << 31) - 1024, "igemm(halo): too many pixels");
+  MG_REQUIRE((long long)a.M * a.lda * 2 < (1ll << 32) - 65536 && (long long)a.N * a.ldw * 2 < (1ll << 32) - 65536,
+             "igemm(halo): operands must be smaller than 4 GiB (32-bit staging offsets)");
   MG_REQUIRE(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.Wt % 16 == 0) && ((uintptr_t)a.out % 16 == 0) &&
                  (!a.res || (uintptr_t)a.res % 16 == 0),
              "igemm(halo): 16-byte alignment");
+  const int bn = variant >= 72 ? 256 : 128;
+  const int lds = variant >= 72 ? h_lds_bytes(256, 2) : h_lds_bytes(128, 3);
   a.tiles_m = (a.M + H_BM - 1) / H_BM;
-  a.tiles_n = (a.N + H_BN - 1) / H_BN;
-  void (*kern)(const Igemm3Args) = variant == 71 ? igemm3_halo_kernel<true> : igemm3_halo_kernel<false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[variant == 71] && !g_dry_run) {
-    MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS));
-    attr_set[variant == 71] = true;
+  a.tiles_n = (a.N + bn - 1) / bn;
+  void (*kern)(const Igemm3Args);
+  switch (variant) {
+    case 70: kern = igemm3_halo_kernel<128, 4, 2, 3, false>; break;   // burst DMA issue after the barrier
+    case 71: kern = igemm3_halo_kernel<128, 4, 2, 3, true>; break;    // pieces issued between the k-substeps
+    case 72: kern = igemm3_halo_kernel<256, 2, 4, 2, false>; break;   // 256 x 256, two weight stages
+    default: kern = igemm3_halo_kernel<256, 2, 4, 2, true>; break;
+  }
+  static bool attr_set[4] = {false, false, false, false};
+  if (!attr_set[variant - 70] && !g_dry_run) {
+    MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set[variant - 70] = true;
   }
   const long long grid = (long long)a.tiles_m * a.tiles_n;
   MG_REQUIRE(grid > 0 && grid < (1ll << 31), "igemm(halo): bad grid %lld", grid);
-  MG_LAUNCH(kern, dim3((unsigned)grid), dim3(H_NT), H_LDS, s, a);
+  MG_LAUNCH(kern, dim3((unsigned)grid), dim3(H_NT), lds, s, a);
   if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
   return 0;
 }

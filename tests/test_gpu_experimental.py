@@ -1,5 +1,5 @@
 """GPU parity tests of EXPERIMENTAL kernels that no product path selects (run with MG_EXPERIMENTAL=1).
-Currently: the halo-shared 3x3 convolution tile (csrc/igemm3.hip, MG_OP_IGEMM tile variants 70 / 71)."""
+Currently: the halo-shared 3x3 convolution tile (csrc/igemm3.hip, MG_OP_IGEMM tile variants 70-73)."""
 import math
 import os
 
@@ -48,7 +48,7 @@ def test_halo_conv3x3(case):
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()   # noqa: E731
     M = B * H * W
     outs = {}
-    for variant in (70, 71, 23):   # the experimental tiles (burst / split DMA issue) and a validated one
+    for variant in (70, 71, 72, 73, 23):   # the experimental tiles (256x128 / 256x256, burst / split issue) and a validated one
         out = torch.full((M, Cout), float("nan"), device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
         op = ops.igemm(nhwc(x).to(dev, torch.bfloat16), Wm.pack_conv3x3(w).to(dev, torch.bfloat16), out, B=B, H=H, W=W,
                        Cin=Cin, Ho=H, Wo=W, N=Cout, taps=9, stride=1, pad=1, bias=b.to(dev),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One-process check of the experimental halo-shared 3x3 tile (variants 70 / 71) on the GPU: parity on a few shapes
+"""One-process check of the experimental halo-shared 3x3 tile (variants 70-73) on the GPU: parity on a few shapes
 against a validated tile, then interleaved timing against the automatic choice on the dominant UNet / VAE
 convolutions.  Not part of the product path."""
 import math
@@ -26,7 +26,7 @@ def parity(B, H, W, Cin, Cout):
     w = (torch.randn(Cout, 9 * Cin, generator=g) / math.sqrt(9 * Cin)).to(dev, torch.bfloat16)
     b = torch.randn(Cout, generator=g).to(dev)
     outs = []
-    for v in (23, 70, 70, 71, 71):
+    for v in (23, 70, 70, 71, 71, 72, 73):
         out = torch.full((B * H * W, Cout), float("nan"), device=dev, dtype=torch.bfloat16)
         O.launch(O.igemm(x, w, out, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, N=Cout, taps=9, stride=1, pad=1, bias=b, variant=v))
         torch.cuda.synchronize()
@@ -34,12 +34,13 @@ def parity(B, H, W, Cin, Cout):
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2), b, padding=1)
     ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
     e23, e70, e71 = ((o - ref).abs().max().item() for o in (outs[0], outs[1], outs[3]))
+    e72, e73 = ((o - ref).abs().max().item() for o in (outs[5], outs[6]))
     same = torch.equal(outs[1], outs[2]) and torch.equal(outs[3], outs[4]) and torch.equal(outs[1], outs[3])
-    print(f"parity B{B} {H}x{W} {Cin}->{Cout}: |err| v23 {e23:.3e} v70 {e70:.3e} v71 {e71:.3e} (scale {ref.abs().max().item():.2f}) "
+    print(f"parity B{B} {H}x{W} {Cin}->{Cout}: |err| v23 {e23:.3e} v70 {e70:.3e} v71 {e71:.3e} v72 {e72:.3e} v73 {e73:.3e} (scale {ref.abs().max().item():.2f}) "
           f"finite {bool(torch.isfinite(outs[1]).all() and torch.isfinite(outs[3]).all())} repeatable+identical {same}", flush=True)
 
 
-def timing(name, B, HW, Cin, N, variants=(0, 33, 70, 71), rounds=3):
+def timing(name, B, HW, Cin, N, variants=(0, 33, 70, 71, 72, 73), rounds=3):
     M, K = B * HW * HW, 9 * Cin
     g = torch.Generator().manual_seed(1)
     x = (torch.randn(M, Cin, generator=g) * 0.5).to(dev, torch.bfloat16)
