@@ -489,3 +489,55 @@ def test_halo_conv_index_model():
                         b, y, x = m // HW, (m % HW) // W, (m % HW) % W
                         j = r + kx if 0 <= x + kx - 1 < W else ROWS
                         assert staged[j] == pad[b, y + ky, x + kx], (B, H, W, m0, ky, kx, r)
+
+
+def test_halo_conv_wait_schedule_model():
+    """Model of the halo tile's per-wave LDS-DMA queue (csrc/igemm3.hip): replay the issue order of the prologue and of
+    every K step, apply the counted `s_waitcnt vmcnt(N)` of the step (oldest loads retire first) and check that the
+    weight tile of the step - and, for kx = 0, the whole activation tile of the triple - have retired, that the
+    counts are the kernel's constants, and that no stage is re-filled while a step still reads it.  Both
+    geometries: 256x128 (2 weight pieces, 3 weight stages) and 256x256 (4 pieces, 2 stages)."""
+    def wait_count(kx, d, pb):          # transcription of igemm3.hip::h_wait_count
+        a = (3, 2, 0)
+        younger = a[(kx + 3 - d % 3) % 3]
+        for j in range(1, d):
+            younger += pb + a[(kx + 3 - j % 3) % 3]
+        if kx == 0:
+            younger = min(younger, pb if d >= 2 else 0)
+        return younger
+
+    for pb, nstb, want in ((2, 3, (2, 5, 7)), (4, 2, (0, 3, 2))):
+        d = nstb - 1
+        assert tuple(wait_count(kx, d, pb) for kx in range(3)) == want
+        for cpt in (1, 2, 5):
+            steps = 9 * cpt
+            queue = []                                   # outstanding loads of one wave, oldest first
+            b_stage_tile, a_stage_tile = {}, {}          # stage -> tile id it holds / is being filled with
+
+            def issue(kind, tile, stage, n):
+                (b_stage_tile if kind == "B" else a_stage_tile)[stage] = tile
+                queue.extend((kind, tile) for _ in range(n))
+
+            issue("A", 0, 0, 5)
+            for s in range(d):
+                issue("B", s, s % nstb, pb)
+            for k in range(steps):
+                kx, triple = k % 3, k // 3
+                n = wait_count(kx, d, pb)
+                del queue[:max(0, len(queue) - n)]       # vmcnt(n): everything but the n youngest has landed
+                assert ("B", k) not in queue, (pb, cpt, k)
+                if kx == 0:
+                    assert ("A", triple) not in queue, (pb, cpt, k)
+                # what this step reads
+                assert b_stage_tile[k % nstb] == k and a_stage_tile[triple % 2] == triple
+                # what it issues (after the barrier): the weight tile D steps ahead into the stage read at step k - 1
+                # (or the dummy past the end), and its share of the next triple's activation tile
+                tgt = (k + d) % nstb
+                assert tgt != k % nstb
+                issue("B", k + d, tgt, pb)
+                if kx == 0:
+                    assert (triple + 1) % 2 != triple % 2
+                    issue("A", triple + 1, (triple + 1) % 2, 3)
+                elif kx == 1:
+                    queue.extend([("A", triple + 1)] * 2)
+            assert len(queue) <= (d * pb + 5)
