@@ -541,3 +541,88 @@ def test_halo_conv_wait_schedule_model():
                 elif kx == 1:
                     queue.extend([("A", triple + 1)] * 2)
             assert len(queue) <= (d * pb + 5)
+
+
+def test_pingpong_gemm_schedule_model():
+    """Happens-before model of the ping-pong K loop that the automatic tile choice uses for N % 256 == 0 layers
+    (csrc/igemm2.hip, LOOP = 2, tile variants 60-63).  The eight waves form two groups that run one barrier apart;
+    every barrier is a rendezvous of all waves, so an event of one group is ordered before an event of the other
+    iff a barrier lies between them.  Replays each group's program (DMA pieces, counted vmcnt waits, barriers,
+    fragment reads + their lgkmcnt(0)) and checks
+      RAW: a half tile is read only after BOTH groups' covering waits, with a barrier in between for the other group;
+      WAR: a DMA piece goes into an LDS slot only after both groups' reads of the slot's previous tile have returned.
+    Burst (variant 60) and mid-MFMA issue (variant 62) forms, several K-tile counts."""
+    def program(group, KT, mid):
+        ev, epoch = [], 0                       # (kind, payload, epoch)
+
+        def add(kind, payload=None):
+            ev.append((kind, payload, epoch))
+
+        def barrier():
+            nonlocal epoch
+            epoch += 1
+
+        for h in range(4):
+            add("issue", (0, h, 0)); add("issue", (0, h, 1))
+        add("wait", 4); barrier()
+        if group == 1:
+            barrier()
+        w12 = 3 if mid else 4
+        reads = {0: (0, 1), 1: (2,), 2: (3,), 3: ()}
+        for t in range(KT):
+            nxt = t + 1 < KT
+            for p in range(4):
+                for h in reads[p]:
+                    add("read", (t, h))
+                if nxt:
+                    add("issue", (t + 1, p, 0))
+                    if p == 3 or not mid:
+                        add("issue", (t + 1, p, 1))
+                if p in (0, 1):
+                    add("wait", w12 if nxt else (2 if p == 0 else 0))
+                if p == 3 and nxt:
+                    add("wait", 4)
+                barrier()
+                add("lgkm")                     # s_waitcnt lgkmcnt(0): this phase's fragment reads have returned
+                if nxt and mid and p < 3:
+                    add("issue", (t + 1, p, 1))
+                barrier()
+        if group == 0:
+            barrier()
+        return ev, epoch
+
+    for mid in (False, True):
+        for KT in (1, 2, 3, 7):
+            progs = [program(g, KT, mid) for g in (0, 1)]
+            assert progs[0][1] == progs[1][1]           # both groups execute the same number of barriers
+            retired_at, read_done_at, issues, reads = [{}, {}], [{}, {}], [[], []], [[], []]
+            for g, (ev, _) in enumerate(progs):
+                queue, pending_reads = [], []
+                for idx, (kind, payload, epoch) in enumerate(ev):
+                    if kind == "issue":
+                        queue.append(payload)
+                        issues[g].append((payload, idx, epoch))
+                    elif kind == "wait":
+                        for piece in queue[:max(0, len(queue) - payload)]:
+                            retired_at[g].setdefault(piece, (idx, epoch))
+                        del queue[:max(0, len(queue) - payload)]
+                    elif kind == "read":
+                        reads[g].append((payload, idx, epoch))
+                        pending_reads.append(payload)
+                    elif kind == "lgkm":
+                        for r in pending_reads:
+                            read_done_at[g][r] = (idx, epoch)
+                        pending_reads = []
+                assert not queue, (mid, KT, g, queue)   # everything issued is eventually waited for
+            for g in (0, 1):
+                for (t, h), ridx, repoch in reads[g]:
+                    for o in (0, 1):
+                        for piece in ((t, h, 0), (t, h, 1)):
+                            widx, wepoch = retired_at[o][piece]
+                            assert (widx < ridx) if o == g else (wepoch < repoch), ("RAW", mid, KT, g, o, t, h)
+                for (t, h, _), iidx, iepoch in issues[g]:
+                    if t < 2:
+                        continue                         # first use of the slot (tile t - 2 shares stage and half)
+                    for o in (0, 1):
+                        didx, depoch = read_done_at[o][(t - 2, h)]
+                        assert (didx < iidx) if o == g else (depoch < iepoch), ("WAR", mid, KT, g, o, t, h)
