@@ -626,3 +626,32 @@ def test_pingpong_gemm_schedule_model():
                     for o in (0, 1):
                         didx, depoch = read_done_at[o][(t - 2, h)]
                         assert (didx < iidx) if o == g else (depoch < iepoch), ("WAR", mid, KT, g, o, t, h)
+
+
+def test_halo_conv_variants_validate_and_reject_without_gpu():
+    """The experimental halo tile's launcher (csrc/igemm3.hip, variants 70-73) accepts the gated GPU test shapes and
+    rejects everything outside its subset with a clear error - through the C ABI's dry run, no device needed."""
+    from marigold_amd import _lib as L, ops as O
+    for B, H, W, Cin, Cout, f32 in ((1, 12, 20, 64, 128, False), (3, 9, 31, 128, 192, False), (2, 300, 1, 64, 64, False),
+                                    (1, 24, 24, 256, 128, True)):
+        M = B * H * W
+        x = torch.zeros(M, Cin, dtype=torch.bfloat16)
+        w = torch.zeros(Cout, 9 * Cin, dtype=torch.bfloat16)
+        out = torch.zeros(M, Cout, dtype=torch.float32 if f32 else torch.bfloat16)
+        for v in (70, 71, 72, 73):
+            seq = O.OpSeq(f"halo/v{v}")
+            seq.add(O.igemm(x, w, out, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, N=Cout, taps=9, stride=1, pad=1,
+                            bias=torch.zeros(Cout), epi=L.EPI_F32 if f32 else L.EPI_BF16, variant=v), "conv")
+            seq.validate()
+    x = torch.zeros(64, 64, dtype=torch.bfloat16)
+    for kw, msg in ((dict(Ho=4, Wo=4, taps=9, stride=2, pad=1), "only 3x3 / stride 1 / pad 1"),
+                    (dict(Ho=8, Wo=8, taps=1, stride=1, pad=0), "only 3x3 / stride 1 / pad 1"),
+                    (dict(Ho=8, Wo=8, taps=9, stride=1, pad=1, epi=L.EPI_GEGLU), "bf16 / fp32 epilogue only")):
+        bad = O.OpSeq("bad")
+        bad.add(O.igemm(x, x, x, B=1, H=8, W=8, Cin=64, N=64, variant=70, **kw), "bad")
+        with pytest.raises(L.MarigoldHipError, match=msg):
+            bad.validate()
+    bad = O.OpSeq("bad")
+    bad.add(O.igemm(x, x, x, B=1, H=8, W=8, Cin=64, Ho=8, Wo=8, N=64, taps=9, stride=1, pad=1, variant=74), "bad")
+    with pytest.raises(L.MarigoldHipError, match="unknown halo tile variant"):
+        bad.validate()
