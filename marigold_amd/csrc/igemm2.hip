@@ -744,6 +744,10 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
     case 46: return launch2<128, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);   // full-width tiles for N = 320
     case 47: return launch2<256, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);
     case 48: return launch2<128, 320, 4, 2, 2, TRANS, false>(a, batch_z, s);
+    // EXPERIMENTAL (gated tests only): 128x320 with 32-deep K tiles and 4 waves (wave tile 64x160) - 56 KB of LDS, two
+    // workgroups per CU, for the K = C linears of the 320-channel level (one workgroup per CU runs them at half the
+    // streaming bandwidth: load, compute and store phases of a 5-step K loop do not overlap)
+    case 49: return launch2<128, 320, 2, 2, 2, TRANS, true, false, 0, 32>(a, batch_z, s);
     case 40: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 1>(a, batch_z, s);  // ablations (sweep only)
     case 41: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 2>(a, batch_z, s);
     case 42: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 3>(a, batch_z, s);

@@ -66,3 +66,29 @@ def test_halo_conv3x3(case):
         scale = want.abs().max().item()
         print(f"[parity] halo/{name}/v{variant}: max|err| {err:.3e} (scale {scale:.2f})")
         assert err <= (2e-3 if f32 else 1.5e-2) * scale, f"{name}/v{variant}"
+
+
+def test_igemm_128x320_bk32_two_workgroups_per_cu():
+    """Tile variant 49 (128x320, 32-deep K tiles, 4 waves): a new instantiation of the generation-2 template for the
+    K = C linears of the 320-channel level - against the validated full-width tile (46) on the same buffers."""
+    from marigold_amd import _lib as L, ops
+    dev = torch.device("cuda:0")
+    L.init(0)
+    g = torch.Generator().manual_seed(3)
+    for M, K, N in ((300, 320, 320), (4096, 1280, 320), (1000, 64, 320)):
+        x = _bf(torch.randn(M, K, generator=g))
+        w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+        b = torch.randn(N, generator=g) * 0.1
+        res = _bf(torch.randn(M, N, generator=g))
+        ref = x @ w.t() + b + res
+        outs = {}
+        for v in (49, 46):
+            out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+            ops.launch(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N, bias=b.to(dev),
+                                  residual=res.to(dev, torch.bfloat16), variant=v))
+            torch.cuda.synchronize()
+            outs[v] = out.float().cpu()
+            err = (outs[v] - ref).abs().max().item()
+            print(f"[parity] linear {M}x{K}x{N}/v{v}: max|err| {err:.3e}")
+            assert torch.isfinite(outs[v]).all() and err <= 1.5e-2 * ref.abs().max().item()
+        assert torch.equal(outs[49], outs[46])   # same K order per accumulator -> identical bits
