@@ -15,3 +15,7 @@ for mode in 0 1 2; do
   MARIGOLD_HALO_CONV=$mode timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > gpurun_out/bench_halo$mode.json 2> gpurun_out/bench_halo$mode.log
   echo "bench halo=$mode rc=$? $(python -c "import json;d=json.load(open('gpurun_out/bench_halo$mode.json'));print(d['value'],d['ms_per_step'])" 2>/dev/null)" | tee -a gpurun_out/status.log
 done
+# 4. tile variant 49 (128x320, BK = 32, two workgroups per CU) on the K = C linears of the 320-channel level
+SWEEP_NO_FLASH=1 SWEEP_ONLY="unet.linear" SWEEP_ROUNDS=3 SWEEP_VARIANTS=0,46,49,53 timeout 120 python tools/sweep.py > gpurun_out/sweep_v49.log 2>&1
+echo "sweep v49 rc=$?" | tee -a gpurun_out/status.log
+tail -8 gpurun_out/sweep_v49.log
