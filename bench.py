@@ -241,59 +241,63 @@ def main():
     # ---- per-kernel-class roofline from HIP-event timings of every launch (rank 0) --------------
     kernels, roof, stages, flops_per_map = {}, None, {}, 0
     if rank == 0 and not args.no_profile:
-        progs = [("denoise", p.seq) for p in pipe.unet._programs.values()] + \
-                [(f"vae.{k[0]}", v[0]) for k, v in pipe.vae._programs.items()]
-        all_ops, all_ms, rows = [], [], []
-        for name, seq in progs:
-            cap = seq._captured
-            if cap:   # profile the plain launch sequence, not the graph
-                continue
-            ms = seq.profile()
-            all_ops += seq.ops
-            all_ms += ms
-            stages[name] = {"ms": round(sum(ms), 3), "gflop": round(opstats.program_flops(seq.ops) / 1e9, 1),
-                            "launches": len(ms)}
-            rows += [(name, lab, m, op) for lab, m, op in zip(seq.labels, ms, seq.ops)]
-        kernels = opstats.summarize(all_ops, all_ms)
-        flops_per_map = sum(d["flops"] for d in kernels.values())
-        if args.dump_ops:
-            os.makedirs(os.path.dirname(os.path.abspath(args.dump_ops)), exist_ok=True)
-            with open(args.dump_ops, "w") as f:
-                f.write("stage\tlabel\tclass\tms\tGFLOP\tMB\tTFLOP/s\tGB/s\n")
-                for name, lab, m, op in rows:
-                    c, fl, by = opstats.op_cost(op)
-                    s = max(m, 1e-6) * 1e-3
-                    f.write(f"{name}\t{lab}\t{c}\t{m:.4f}\t{fl / 1e9:.2f}\t{by / 1e6:.2f}\t{fl / s / 1e12:.1f}\t{by / s / 1e9:.0f}\n")
-        if kernels:
-            dom = max(kernels, key=lambda c: kernels[c]["ms"])
-            d = kernels[dom]
-            if opstats.BOUND.get(dom) == "mfma":
-                roof = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2),
-                        "peak": opstats.MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(d["tflops"] / opstats.MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "launches_per_map": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                        "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 2)}
-            else:
-                roof = {"bound": "hbm", "kernel": dom, "achieved": round(d["gbs"], 1),
-                        "peak": opstats.HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(d["gbs"] / opstats.HBM_PEAK_GBS, 4), "traffic": None,
-                        "launches_per_map": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
-            # the PMC passes were collected for the headline workload only
-            try:
-                headline = (args.kind, args.ensemble, args.denoise, args.res, args.scheduler, args.tiny) == \
-                    ("depth", 10, 10, 768, "ddim", False)
-                t = pmc_traffic(dom) if headline else None
-                if t is not None:
-                    roof["traffic"] = round(t["bytes_per_launch"])      # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)
-                    roof["traffic_unit"] = "bytes/launch"
-                    roof["traffic_launches_profiled"] = t["launches"]
-                    roof["traffic_source"] = t["source"]
-                    roof["algorithmic_bytes_per_launch"] = round(kernels[dom]["bytes"] / kernels[dom]["launches"])
-            except Exception as e:  # noqa: BLE001 - a reporting nicety must never cost the benchmark line
-                log(f"[bench] traffic annotation skipped: {e}")
-            for d in kernels.values():
-                for k in ("ms", "tflops", "gbs"):
-                    d[k] = round(d[k], 3)
+        try:
+            progs = [("denoise", p.seq) for p in pipe.unet._programs.values()] + \
+                    [(f"vae.{k[0]}", v[0]) for k, v in pipe.vae._programs.items()]
+            all_ops, all_ms, rows = [], [], []
+            for name, seq in progs:
+                cap = seq._captured
+                if cap:   # profile the plain launch sequence, not the graph
+                    continue
+                ms = seq.profile()
+                all_ops += seq.ops
+                all_ms += ms
+                stages[name] = {"ms": round(sum(ms), 3), "gflop": round(opstats.program_flops(seq.ops) / 1e9, 1),
+                                "launches": len(ms)}
+                rows += [(name, lab, m, op) for lab, m, op in zip(seq.labels, ms, seq.ops)]
+            kernels = opstats.summarize(all_ops, all_ms)
+            flops_per_map = sum(d["flops"] for d in kernels.values())
+            if args.dump_ops:
+                os.makedirs(os.path.dirname(os.path.abspath(args.dump_ops)), exist_ok=True)
+                with open(args.dump_ops, "w") as f:
+                    f.write("stage\tlabel\tclass\tms\tGFLOP\tMB\tTFLOP/s\tGB/s\n")
+                    for name, lab, m, op in rows:
+                        c, fl, by = opstats.op_cost(op)
+                        s = max(m, 1e-6) * 1e-3
+                        f.write(f"{name}\t{lab}\t{c}\t{m:.4f}\t{fl / 1e9:.2f}\t{by / 1e6:.2f}\t{fl / s / 1e12:.1f}\t{by / s / 1e9:.0f}\n")
+            if kernels:
+                dom = max(kernels, key=lambda c: kernels[c]["ms"])
+                d = kernels[dom]
+                if opstats.BOUND.get(dom) == "mfma":
+                    roof = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2),
+                            "peak": opstats.MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(d["tflops"] / opstats.MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                            "launches_per_map": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                            "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 2)}
+                else:
+                    roof = {"bound": "hbm", "kernel": dom, "achieved": round(d["gbs"], 1),
+                            "peak": opstats.HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(d["gbs"] / opstats.HBM_PEAK_GBS, 4), "traffic": None,
+                            "launches_per_map": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
+                # the PMC passes were collected for the headline workload only
+                try:
+                    headline = (args.kind, args.ensemble, args.denoise, args.res, args.scheduler, args.tiny) == \
+                        ("depth", 10, 10, 768, "ddim", False)
+                    t = pmc_traffic(dom) if headline else None
+                    if t is not None:
+                        roof["traffic"] = round(t["bytes_per_launch"])      # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)
+                        roof["traffic_unit"] = "bytes/launch"
+                        roof["traffic_launches_profiled"] = t["launches"]
+                        roof["traffic_source"] = t["source"]
+                        roof["algorithmic_bytes_per_launch"] = round(kernels[dom]["bytes"] / kernels[dom]["launches"])
+                except Exception as e:  # noqa: BLE001 - a reporting nicety must never cost the benchmark line
+                    log(f"[bench] traffic annotation skipped: {e}")
+                for d in kernels.values():
+                    for k in ("ms", "tflops", "gbs"):
+                        d[k] = round(d[k], 3)
+        except Exception as e:  # noqa: BLE001 - the per-kernel breakdown is reporting; the benchmark line must survive it
+            log(f"[bench] per-kernel profile failed: {type(e).__name__}: {e}")
+            kernels, roof, stages, flops_per_map = {}, None, {}, 0
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
