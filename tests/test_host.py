@@ -655,3 +655,114 @@ def test_halo_conv_variants_validate_and_reject_without_gpu():
     bad.add(O.igemm(x, x, x, B=1, H=8, W=8, Cin=64, Ho=8, Wo=8, N=64, taps=9, stride=1, pad=1, variant=74), "bad")
     with pytest.raises(L.MarigoldHipError, match="unknown halo tile variant"):
         bad.validate()
+
+
+@pytest.mark.parametrize("BN,WGM,WGN,NSTB", [(128, 4, 2, 3), (256, 2, 4, 2)])
+def test_halo_conv_dataflow_model(BN, WGM, WGN, NSTB):
+    """Executable model of csrc/igemm3.hip's data path, transcribed from the kernel: LDS-DMA pieces (which lane
+    stages which 16-byte chunk of which pixel / weight row, with the XOR swizzle on the SOURCE chunk), the two
+    activation stages + NSTB weight stages and the order in which the K steps fill and read them (DMA data is made
+    to land AT ISSUE, the worst case for overwriting a stage that is still being read), the fragment addresses
+    (`offset ^ (ks << 5)`, zero-row redirect) and the wave -> sub-tile geometry.  The product assembled from those
+    fragments must equal a zero-padded 3x3 convolution, including image borders, a partial last pixel tile and a
+    channel count that is not a multiple of the tile width."""
+    rng = np.random.default_rng(BN)
+    B, H, W, Cin, N = 2, 9, 15, 128, BN + 40         # M = 270: one full + one partial 256-pixel tile; N edge
+    HW, M, cpt = H * W, B * H * W, Cin // 64
+    A = rng.integers(-3, 4, size=(M, Cin)).astype(np.float64)
+    Wt = rng.integers(-3, 4, size=(N, 9 * Cin)).astype(np.float64)          # k = (ky*3 + kx)*Cin + c
+    pad = np.zeros((B, H + 2, W + 2, Cin))
+    pad[:, 1:-1, 1:-1] = A.reshape(B, H, W, Cin)
+    ref = np.zeros((M, N))
+    for ky in range(3):
+        for kx in range(3):
+            ref += pad[:, ky:ky + H, kx:kx + W].reshape(M, Cin) @ Wt[:, (ky * 3 + kx) * Cin:(ky * 3 + kx + 1) * Cin].T
+    BM, NT, ZERO_ROW, A_BLOCKS = 256, 512, 264, 33
+    TM, TN = BM // WGM, BN // WGN
+    MI, NI, PB, D = TM // 32, TN // 32, BN * 8 // NT, NSTB - 1
+    swz = lambda chunk, row: chunk ^ ((row >> 1) & 7)   # noqa: E731
+    out = np.full((M, N), np.nan)
+    for tile_m in range((M + BM - 1) // BM):
+        for tile_n in range((N + BN - 1) // BN):
+            m0, n0 = tile_m * BM, tile_n * BN
+            sA = np.full((2, ZERO_ROW + 1, 8, 8), np.nan)
+            sA[:, ZERO_ROW] = 0.0
+            sB = np.full((NSTB, BN, 8, 8), np.nan)
+            state = dict(i_ky=0, i_c=0, b_ky=0, b_c=0, b_kx=0)
+
+            def a_piece(stage, i):
+                for wave in range(8):
+                    blk = min(i * 8 + wave, A_BLOCKS - 1)
+                    for lane in range(64):
+                        slot, p = blk * 8 + (lane >> 3), lane & 7
+                        q = m0 - 1 + slot + (state["i_ky"] - 1) * W
+                        ok = state["i_ky"] < 3 and 0 <= q < M and 0 <= (q % HW) // W - state["i_ky"] + 1 < H
+                        c0 = state["i_c"] * 64 + swz(p, slot) * 8
+                        sA[stage, slot, p] = A[q, c0:c0 + 8] if ok else 0.0
+
+            def a_advance():
+                state["i_c"] += 1
+                if state["i_c"] == cpt:
+                    state["i_c"], state["i_ky"] = 0, state["i_ky"] + 1
+
+            def b_tile(stage):
+                kofs = (state["b_ky"] * 3 + state["b_kx"]) * Cin + state["b_c"] * 64
+                for it in range(PB):
+                    for tid in range(NT):
+                        ci = it * NT + tid
+                        row, p = ci >> 3, ci & 7
+                        n = n0 + row
+                        live = state["b_ky"] < 3 and n < N
+                        sB[stage, row, p] = Wt[n, kofs + swz(p, row) * 8:kofs + swz(p, row) * 8 + 8] if live else 0.0
+                state["b_kx"] += 1
+                if state["b_kx"] == 3:
+                    state["b_kx"] = 0
+                    state["b_c"] += 1
+                    if state["b_c"] == cpt:
+                        state["b_c"], state["b_ky"] = 0, state["b_ky"] + 1
+
+            for i in range(5):
+                a_piece(0, i)
+            a_advance()
+            for d in range(D):
+                b_tile(d)
+            acc = np.zeros((BM, BN))
+            st_b = st_a = 0
+            for _triple in range(3 * cpt):
+                for kx in range(3):
+                    # what the step reads is captured BEFORE its own DMA lands (issue comes right after the barrier)
+                    b_tile(st_b - 1 if st_b >= 1 else NSTB - 1)
+                    if kx == 0:
+                        for i in (0, 1, 2):
+                            a_piece(st_a ^ 1, i)
+                    elif kx == 1:
+                        for i in (3, 4):
+                            a_piece(st_a ^ 1, i)
+                        a_advance()
+                    for wave in range(8):
+                        wm, wn = wave // WGN, wave % WGN
+                        for ks in range(4):
+                            fa = np.zeros((MI, 32, 16))
+                            fb = np.zeros((NI, 32, 16))
+                            for half in range(2):
+                                for l31 in range(32):
+                                    for mi in range(MI):
+                                        r = wm * TM + mi * 32 + l31
+                                        x = ((m0 + r) % HW) % W
+                                        j = r + kx if 0 <= x + kx - 1 < W else ZERO_ROW
+                                        off = (j * 128 + (swz(half, j) << 4)) ^ (ks << 5)
+                                        fa[mi, l31, half * 8:half * 8 + 8] = sA[st_a, off // 128, (off % 128) // 16]
+                                    for ni in range(NI):
+                                        r = wn * TN + ni * 32 + l31
+                                        off = (r * 128 + (swz(half, r) << 4)) ^ (ks << 5)
+                                        fb[ni, l31, half * 8:half * 8 + 8] = sB[st_b, off // 128, (off % 128) // 16]
+                            for mi in range(MI):
+                                for ni in range(NI):
+                                    acc[wm * TM + mi * 32:wm * TM + mi * 32 + 32,
+                                        wn * TN + ni * 32:wn * TN + ni * 32 + 32] += fa[mi] @ fb[ni].T
+                    st_b = 0 if st_b == NSTB - 1 else st_b + 1
+                st_a ^= 1
+            rows, cols = min(BM, M - m0), min(BN, N - n0)
+            out[m0:m0 + rows, n0:n0 + cols] = acc[:rows, :cols]
+    assert np.isfinite(out).all()
+    np.testing.assert_array_equal(out, ref)
