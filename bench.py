@@ -151,18 +151,37 @@ def main():
     if args.cpu_baseline_only:
         print("CPU_BASELINE " + json.dumps(cpu_baseline(args, args.cpu_baseline_only)), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run` with one rank
+        # per GPU (never fall back to one GPU: a run that cannot get N ranks fails)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                  os.path.abspath(__file__)] + sys.argv[1:])
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU"
+    n_dev = torch.cuda.device_count()
+    shared_gpu = os.environ.get("MARIGOLD_BENCH_SHARE_GPU") == "1"   # test rigs only: several ranks on one device
+    assert shared_gpu or world <= n_dev, f"--gpus {args.gpus} but only {n_dev} GPU(s) visible"
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device("cuda", local_rank % n_dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        dist.init_process_group("gloo" if shared_gpu else "nccl", **({} if shared_gpu else {"device_id": dev}))
+        seen = torch.ones(1, device="cpu" if shared_gpu else dev)
+        dist.all_reduce(seen)
+        assert int(seen.item()) == args.gpus == dist.get_world_size(), \
+            f"the process group sees {int(seen.item())} ranks, --gpus {args.gpus}"
+        world = dist.get_world_size()
 
     from marigold_amd.util.host import usable_cores
     torch.set_num_threads(max(1, min(32, usable_cores() // max(1, world))))   # weight synthesis is the only host-heavy part
@@ -227,7 +246,7 @@ def main():
         out = pipe(img, **kw)
     barrier()
     dt = time.perf_counter() - t1
-    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tt = torch.tensor([dt], device="cpu" if (world > 1 and dist.get_backend() == "gloo") else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())

@@ -31,6 +31,8 @@ struct Igemm2Args {
   const bf16_t* res;
   const void* zero;
   int H, W, Cin, Ho, Wo, N, taps, stride, pad, Hu, Wu, epi, ldo, ldr, lda, ldt, ldw;
+  int tw;      // tap window width: 3 (taps = 9), 2 (taps = 4, the sub-pixel form of nearest-2x + conv3x3), 1
+  int subpix;  // 1: batch entry z = 2a+b is output parity (a, b): window rows y-1+a.., cols x-1+b.., output pixel (2y+a, 2x+b)
   int M, rows_per_img, tiles_m, tiles_n, cpt, KT, rv_stride, up2, ctr;
   int n_begin, n_end;  // output-column range of this launch (tiles start at n_begin, bound n_end <= N)
   int splits, kps;     // split-K: `splits` workgroups per tile, each `kps` K steps; partials go to `ws`
@@ -118,6 +120,9 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   // [128,256) their second 64 rows; B slots [0,128) = the first 32 columns of the four wave columns, ...
   auto a_row_of = [](int slot) { return PP ? ((slot >> 6) & 1) * 128 + (slot >> 7) * 64 + (slot & 63) : slot; };
   auto b_row_of = [](int slot) { return PP ? ((slot >> 5) & 3) * 64 + (slot >> 7) * 32 + (slot & 31) : slot; };
+  // sub-pixel form (nearest-2x up-sampling folded into the weights): parity (a, b) = (z >> 1, z & 1) reads source rows
+  // y - 1 + a + ty, ty in {0, 1}, i.e. pads 1 - a on top / 1 - b on the left
+  const int pad_y = a.subpix ? 1 - (z >> 1) : a.pad, pad_x = a.subpix ? 1 - (z & 1) : a.pad;
   // ---- staging rows owned by this thread (fixed over the K loop) ----
   int a_by[A_IT], a_bx[A_IT], a_qoff[A_IT];
   long long a_img[A_IT];
@@ -132,8 +137,8 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     const int img = mm / a.rows_per_img;
     const int rem = mm - img * a.rows_per_img;
     const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-    a_by[it] = ok ? oy * a.stride - a.pad : -(1 << 28);  // rows beyond M never pass the bounds test
-    a_bx[it] = ox * a.stride - a.pad;
+    a_by[it] = ok ? oy * a.stride - pad_y : -(1 << 28);  // rows beyond M never pass the bounds test
+    a_bx[it] = ox * a.stride - pad_x;
     a_img[it] = (long long)img * a.H * a.W;
   }
   const char* b_ptr[B_IT];
@@ -155,7 +160,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   const int hb = a.Hu ? a.Hu : a.H, wb = a.Hu ? a.Wu : a.W;  // bounds in (virtual) input space
   auto tap_setup = [&](int tap) {
     int dy = 0, dx = 0;
-    if (a.taps == 9) { dy = tap / 3; dx = tap - dy * 3; }
+    if (a.tw > 1) { dy = tap / a.tw; dx = tap - dy * a.tw; }
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       int iy = a_by[it] + dy, ix = a_bx[it] + dx;
@@ -543,6 +548,12 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
         }
         if constexpr (!TRANS) {
           const int m = mb + l31, n = nb + 16 * gp + 8 * half;
+          long long orow = m;
+          if (a.subpix) {   // low-resolution pixel (img, y, x) of parity (a, b) -> pixel (2y + a, 2x + b) of the 2H x 2W map
+            const int img = m / a.rows_per_img, rem = m - img * a.rows_per_img;
+            const int y = rem / a.Wo, x = rem - y * a.Wo;
+            orow = (long long)img * 4 * a.rows_per_img + (long long)(2 * y + (z >> 1)) * (2 * a.Wo) + 2 * x + (z & 1);
+          }
           if (a.splits > 1) {  // split-K: raw partial sums, everything else happens in splitk_reduce_kernel
             if (m < a.M && n < a.n_end) {
               float* o = a.ws + ((long long)split * a.M + m) * a.N + n;
@@ -562,7 +573,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
               v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
             }
             if (a.epi == MG_EPI_F32) {
-              float* o = (float*)a.out + (long long)z * a.sO + (long long)m * a.ldo + n;
+              float* o = (float*)a.out + (long long)z * a.sO + orow * a.ldo + n;
               *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
               *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
             } else {
@@ -574,7 +585,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
               uint4 pk;
               pk.x = cvt_pk_bf16(v[0], v[1]); pk.y = cvt_pk_bf16(v[2], v[3]);
               pk.z = cvt_pk_bf16(v[4], v[5]); pk.w = cvt_pk_bf16(v[6], v[7]);
-              *(uint4*)((bf16_t*)a.out + (long long)z * a.sO + (long long)m * a.ldo + n) = pk;
+              *(uint4*)((bf16_t*)a.out + (long long)z * a.sO + orow * a.ldo + n) = pk;
             }
           }
         } else {
@@ -792,6 +803,8 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.cpt = a.Cin / 64;
   a.KT = a.taps * a.cpt;
   a.up2 = (a.Hu == 2 * a.H) && (a.Wu == 2 * a.W);
+  a.tw = a.taps == 9 ? 3 : (a.taps == 4 ? 2 : 1);
+  a.subpix = a.taps == 4;
   a.splits = variant ? -1 : 0;   // split-K only under the automatic tile choice
   a.kps = 0;
   a.ws = nullptr;
@@ -799,7 +812,12 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.tiles_m = a.tiles_n = 0;
   MG_REQUIRE(g_zero_page || g_dry_run, "igemm: mg_init() not called");
   MG_REQUIRE(a.A && a.Wt && (a.out || out2), "igemm: null pointer");
-  MG_REQUIRE(a.taps == 1 || a.taps == 9, "igemm: taps must be 1 or 9 (got %d)", a.taps);
+  MG_REQUIRE(a.taps == 1 || a.taps == 9 || a.taps == 4, "igemm: taps must be 1, 9 or 4 (got %d)", a.taps);
+  if (a.subpix) {
+    MG_REQUIRE(batch_z == 4 && a.stride == 1 && a.Hu == 0 && a.Ho == a.H && a.Wo == a.W && trans_from < 0 && !a.res && !a.rowvec &&
+               a.epi != MG_EPI_GEGLU && a.sA == 0 && a.sO == 0,
+               "igemm: the sub-pixel form (taps = 4) takes batch_z = 4 parities of one stride-1 input, bias only");
+  }
   MG_REQUIRE(a.Cin > 0 && a.Cin % 64 == 0, "igemm: Cin %d must be a multiple of 64", a.Cin);
   MG_REQUIRE(a.N > 0 && a.N % 4 == 0, "igemm: N %d must be a multiple of 4", a.N);
   MG_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "igemm: lda/ldw must be multiples of 8");

@@ -77,6 +77,9 @@ class WeightStore:
     def conv3x3(self, name):
         return self._memo(("c3", name), lambda: Wm.bf16(Wm.pack_conv3x3(self.sd[f"{name}.weight"].float()), self.device))
 
+    def conv3x3_subpix(self, name):
+        return self._memo(("c3s", name), lambda: Wm.bf16(Wm.pack_conv3x3_subpix(self.sd[f"{name}.weight"].float()), self.device))
+
     def mat(self, name):  # Linear or 1x1 conv -> [N][K]
         def f():
             w = self.sd[f"{name}.weight"].float()
@@ -200,6 +203,12 @@ class Builder:
             Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
         if out is None:
             out = self.new(x.B, Ho, Wo, cout)
+        if up and up == (2 * x.H, 2 * x.W) and stride == 1 and pad == 1 and rowvec is None and residual is None:
+            # exact 2x nearest up-sampling: four 2x2 convolutions on the low-resolution input (4/9 of the MACs)
+            self.add(O.igemm(x.t, self.ws.conv3x3_subpix(name), out.t, B=x.B, H=x.H, W=x.W, Cin=x.C, Ho=x.H, Wo=x.W,
+                             N=cout, taps=4, stride=1, pad=1, bias=self.ws.bias(name), batch_z=4,
+                             zstrides=(0, cout * 4 * x.C, 0, 0)), name)
+            return out
         self.add(O.igemm(x.t, self.ws.conv3x3(name), out.t, B=x.B, H=x.H, W=x.W, Cin=x.C, Ho=Ho, Wo=Wo,
                          N=cout, taps=9, stride=stride, pad=pad, up=up, bias=self.ws.bias(name),
                          rowvec=rowvec, rowvec_bcast=rowvec is not None,

@@ -230,7 +230,10 @@ def _score_iid(args, dataset, data, names):
     for target in args.target_names:
         path = f"{stem}_{target}.npy"
         if not os.path.exists(path):
+            # keep the columns aligned with `names` (metric-major per target): a missing target leaves empty cells
+            # and is not counted in the averages (the reference updates its tracker by metric name too)
             logging.warning(f"Can't find prediction: {path}")
+            values += [None] * len(args.metrics)
             continue
         pred, gt = np.load(path)[None].astype(np.float32), data[target][None].astype(np.float32)
         if target in args.targets_to_eval_in_linear_space:
@@ -266,9 +269,11 @@ def eval_main(kind, argv=None) -> int:
             if scored is None:
                 continue
             label, values = scored
+            assert len(values) == len(names)
             for n, v in zip(names, values):
-                tracker.update(n, v)
-            f.write(label + "," + ",".join(str(v) for v in values) + "\n")
+                if v is not None:
+                    tracker.update(n, v)
+            f.write(label + "," + ",".join("" if v is None else str(v) for v in values) + "\n")
     text = (f"Evaluation metrics:\n    of predictions: {args.prediction_dir}\n    on dataset: {dataset.disp_name}\n"
             f"    with samples in: {dataset.filename_ls_path}\n")
     if kind == "depth":

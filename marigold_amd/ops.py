@@ -207,6 +207,13 @@ class OpSeq:
         L.check(lib.mg_program_run(prog, stream if stream is not None else current_stream_handle()),
                 f"mg_program_run({self.name})")
 
+    def run_range(self, first, count, stream=None):
+        """Replay ops [first, first+count) only (step-wise inspection of a denoising program in the parity tests)."""
+        lib = L.load()
+        L.check(lib.mg_program_run_range(self.compile(), int(first), int(count),
+                                         stream if stream is not None else current_stream_handle()),
+                f"mg_program_run_range({self.name})")
+
     def validate(self):
         """Dry-run every op through its launcher's contract checks (works without a GPU)."""
         lib = L.load()

@@ -195,7 +195,11 @@ class _MarigoldPipelineBase:
         local = torch.cat(preds, dim=0) if preds else None
         if self._member_parallel and mdist.world_size(self._member_group) > 1:
             C = self._pred_channels
-            hh, ww = rgb_norm.shape[-2:]
+            # decoded maps are latent size x 2^(levels-1), which is smaller than the image when its size is not a
+            # multiple of 8 (KITTI 1242x375 -> 768x231 -> latent 96x28 -> decoded 768x224); ranks without members
+            # need the shape too, so it is computed, not taken from `local`
+            f = 2 ** (len(self.vae.config.block_out_channels) - 1)
+            hh, ww = (f * d for d in self._latent_hw(rgb_norm.shape[-2:]))
             return mdist.gather_members(local, E, (C, hh, ww), self.device, self._member_group,
                                         getattr(self, "_member_root", None))
         return local

@@ -28,6 +28,27 @@ def pack_conv3x3(w):
     return w.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
 
 
+def pack_conv3x3_subpix(w):
+    """Nearest-2x up-sampling followed by conv3x3 (diffusers Upsample2D) as four 2x2 convolutions on the
+    low-resolution input, one per output parity (a, b): output row 2y+a reads virtual rows 2y+a+dy-1, i.e. source rows
+    {y-1, y, y} (a = 0) or {y, y, y+1} (a = 1) for dy = 0, 1, 2 - taps that hit the same source pixel are summed here,
+    in fp32, before the bf16 rounding.  [Cout,Cin,3,3] -> [4 (z = 2a+b)][Cout][(ty*2+tx)*Cin + c]; 4/9 of the MACs."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    sets = (((0,), (1, 2)), ((0, 1), (2,)))   # sets[a][ty] = the dy that land on source row y - 1 + a + ty
+    out = w.new_zeros(4, co, 2, 2, ci)
+    for a in range(2):
+        for b in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    acc = 0
+                    for dy in sets[a][ty]:
+                        for dx in sets[b][tx]:
+                            acc = acc + w[:, :, dy, dx]
+                    out[2 * a + b, :, ty, tx, :] = acc
+    return out.reshape(4, co, 4 * ci).contiguous()
+
+
 def pack_conv1x1(w):
     return w.reshape(w.shape[0], w.shape[1]).contiguous()
 

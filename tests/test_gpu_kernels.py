@@ -138,6 +138,76 @@ def test_igemm_conv3x3(dev, case):
     _close(f"conv3x3/{name}", out.float().permute(0, 3, 1, 2), ref)
 
 
+# The dominant shapes of the benchmark configuration, at their real spatial size, against
+# torch conv2d fp32 on the host cores: VAE decoder 128->128 @768^2, 512->512 @192^2 (the 256x256 ping-pong tile),
+# UNet 320->320 @96^2 at B = 10 (the 128x320 full-width tile) and the stride-1 up-sampling convolution.
+DOMINANT_CONVS = [
+    ("vae_128_128_768sq_b2", 2, 768, 768, 128, 128, None),
+    ("vae_512_512_192sq_b2", 2, 192, 192, 512, 512, None),
+    ("unet_320_320_96sq_b10", 10, 96, 96, 320, 320, None),
+    ("unet_up_640_640_48to96_b2", 2, 48, 48, 640, 640, (96, 96)),
+]
+
+
+@pytest.mark.parametrize("case", DOMINANT_CONVS, ids=[c[0] for c in DOMINANT_CONVS])
+def test_igemm_conv3x3_dominant_shapes(dev, case):
+    from marigold_amd import ops, weights as Wm
+    name, B, H, W, Cin, Cout, up = case
+    from marigold_amd.util.host import usable_cores
+    torch.set_num_threads(min(32, usable_cores()))
+    g = torch.Generator().manual_seed(len(name))
+    x = _bf(torch.randn(B, Cin, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    xin = F.interpolate(x, size=up, mode="nearest") if up else x
+    Ho, Wo = xin.shape[-2:]
+    res = _bf(torch.randn(B, Cout, Ho, Wo, generator=g))
+    ref = F.conv2d(xin, w, bias, padding=1) + res
+    out = torch.full((B, Ho, Wo, Cout), float("nan"), device=dev, dtype=torch.bfloat16)
+    op = ops.igemm(_nhwc(x).to(dev, torch.bfloat16), Wm.pack_conv3x3(w).to(dev, torch.bfloat16), out, B=B, H=H, W=W,
+                   Cin=Cin, Ho=Ho, Wo=Wo, N=Cout, taps=9, stride=1, pad=1, up=up, bias=bias.to(dev),
+                   residual=_nhwc(res).to(dev, torch.bfloat16))
+    _run(op)
+    _close(f"conv3x3/{name}", out.float().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,variant", [(2, 6, 10, 64, 128, 0), (1, 16, 16, 192, 320, 0), (2, 24, 20, 128, 256, 62),
+                                                     (1, 9, 7, 64, 64, 23), (2, 48, 48, 640, 640, 0)])
+def test_igemm_subpixel_upsample_conv(dev, B, H, W, Cin, Cout, variant):
+    """Nearest-2x + conv3x3 (diffusers Upsample2D) in its sub-pixel form: four 2x2 convolutions on the low-resolution
+    input with taps pre-summed in the weights (weights.pack_conv3x3_subpix), vs conv2d on the up-sampled input."""
+    from marigold_amd import ops, weights as Wm
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = _bf(torch.randn(B, Cin, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
+    out = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), device=dev, dtype=torch.bfloat16)
+    ws = Wm.pack_conv3x3_subpix(w).to(dev, torch.bfloat16)
+    _run(ops.igemm(_nhwc(x).to(dev, torch.bfloat16), ws, out, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, N=Cout, taps=4, stride=1,
+                   pad=1, bias=bias.to(dev), batch_z=4, zstrides=(0, Cout * 4 * Cin, 0, 0), variant=variant))
+    # the pre-summed taps are rounded to bf16 once more than the reference's weights: 2e-2 instead of 1.5e-2
+    _close(f"subpixel up-conv B{B} {H}x{W} {Cin}->{Cout} v{variant}", out.float().permute(0, 3, 1, 2), ref, tol=2e-2)
+
+
+def test_flash_attn64_benchmark_shape(dev):
+    """The level-0 self-attention of the 768^2 map: 5 heads x 9216 tokens (96^2 latent), vs CPU SDPA fp32."""
+    from marigold_amd import ops
+    B, heads, T = 1, 5, 9216
+    C = heads * 64
+    g = torch.Generator().manual_seed(11)
+    qkv = _bf(torch.randn(B, T, 3 * C, generator=g))
+    q, k, v = qkv.split(C, dim=-1)
+    qh, kh, vh = (t.reshape(B, T, heads, 64).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, T, C)
+    qkd = qkv.to(dev, torch.bfloat16)
+    vt = v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16)
+    out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.flash_attn64(qkd, qkd[:, :, C:], vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=T,
+                          sq=T * 3 * C, sk=T * 3 * C, svt=C * T, so=T * C, scale=0.125))
+    _close("flash_attn64/5 heads x 9216 tokens", out, ref)
+
+
 def test_igemm_linear_geglu_f32_trans_batched(dev):
     from marigold_amd import _lib as L, ops, weights as Wm
     g = torch.Generator().manual_seed(5)
