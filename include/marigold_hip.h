@@ -14,7 +14,7 @@
  * Every kernel launch is described by one fixed-size `mg_op`; a sequence of them is a
  * *program* (mg_program_*) that the library replays with no host logic in between (and
  * optionally as a captured hipGraph).  The Python host mirrors the reference's
- * unet/vae/scheduler interface by building such programs (marigold_amd/unet_program.py ...).
+ * unet/vae/scheduler interface by building such programs (marigold_amd/engine.py, modules.py).
  */
 #ifndef MARIGOLD_HIP_H
 #define MARIGOLD_HIP_H
@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 1
+#define MG_ABI_VERSION 2
 
 enum mg_op_kind {
   /* conv3x3 / conv1x1 / Linear / batched GEMM as ONE implicit-GEMM bf16 MFMA kernel.
@@ -34,8 +34,11 @@ enum mg_op_kind {
    *  p[0] A bf16 [B][H][W][lda>=Cin]   p[1] Wt bf16 [N][ldw>=taps*Cin] (k = (ky*3+kx)*Cin+c)
    *  p[2] out                          p[3] bias f32[N] | NULL
    *  p[4] rowvec f32 [B][N] | NULL (time-embedding add)   p[5] residual bf16 [M][ldr] | NULL
-   *  p[6] out2 (transposed section)    i[0] B  i[1] H  i[2] W  i[3] Cin  i[4] Ho  i[5] Wo
-   *  i[6] N  i[7] taps(1|9)  i[8] stride  i[9] pad  i[10] Hu  i[11] Wu (virtual nearest-
+   *  p[6] out2 (transposed section)    p[7] A1 bf16 [B][H][W][lda1] | NULL: second channel source - channels [C0, Cin)
+   *  of every tap come from A1, [0, C0) from A (the UNet's skip concat; i[24] = C0, i[25] = lda1)
+   *  i[0] B  i[1] H  i[2] W  i[3] Cin  i[4] Ho  i[5] Wo
+   *  i[6] N  i[7] taps (1 | 9 | 4 = the sub-pixel form of nearest-2x + conv3x3: batch_z = 4 output parities, see
+   *  MG_OP_CONV3X3)  i[8] stride  i[9] pad  i[10] Hu  i[11] Wu (virtual nearest-
    *  upsampled input size, 0 = none)  i[12] epilogue (MG_EPI_*)  i[13] ldo  i[14] trans_from
    *  (columns >= this go to out2 as [img][n-trans_from][ldt] transposed; -1 = none)
    *  i[15] batch_z  i[16] ldr  i[17] lda  i[18] ldt  i[19] tile variant (0 = auto; 1..13 force a
@@ -47,10 +50,13 @@ enum mg_op_kind {
   MG_OP_IGEMM = 1,
   /* GroupNorm, 3 launches (stats partials -> per-(b,c) scale/shift -> apply [+SiLU]).
    * Replaces torch group_norm + silu in every ResNet block / Transformer2D input norm.
-   *  STATS:    p[0] x bf16 [B][HW][C]  p[1] partials f32 [B][chunks][C][2]; i: B,HW,C,chunks
-   *  FINALIZE: p[0] partials p[1] gamma f32 p[2] beta f32 p[3] scale_shift f32 [B][C][2];
+   *  STATS:    p[0] x bf16 [B][HW][C]  p[1] partials f32 [B][chunks][Ctot][2]; i: B,HW,C,chunks, Ctot (0 = C),
+   *            coff - x holds channels [coff, coff+C) of a Ctot-channel norm (the UNet's skip concat
+   *            torch.cat([hidden, skip]) is normalised source by source, never materialised)
+   *  FINALIZE: p[0] partials p[1] gamma f32 p[2] beta f32 p[3] scale_shift f32 [B][2][C];
    *            i: B,C,groups,chunks,HW ; f[0] eps
-   *  APPLY:    p[0] x  p[1] scale_shift  p[2] out bf16 ; i: B,HW,C,silu */
+   *  APPLY:    p[0] x  p[1] scale_shift  p[2] out bf16 [B][HW][C]  p[3] x1 | NULL ; i: B,HW,C,silu, C0 - with x1 the
+   *            output channels [0,C0) come from x ([B][HW][C0]) and [C0,C) from x1 ([B][HW][C-C0]) */
   MG_OP_GN_STATS = 2,
   MG_OP_GN_FINALIZE = 3,
   MG_OP_GN_APPLY = 4,
@@ -115,6 +121,20 @@ enum mg_op_kind {
    *  p[0] src0 f32 [B|1][C0][H][W]  p[1] src1 f32 [B][C1][H][W] | NULL  p[2] out bf16 [B*H*W][Kp];
    *  i: B,H,W,C0,C1,Kp, src0_broadcast */
   MG_OP_IM2COL_SMALL = 16,
+  /* Patch-resident conv3x3 (stride 1, pad 1) with the ResNet block's GroupNorm + SiLU fused into the operand staging
+   * (diffusers ResnetBlock2D: norm1 -> silu -> conv1, norm2 -> silu -> conv2), the UNet's skip concat folded into the
+   * channel loop (torch.cat([hidden, skip]) in the up blocks) and Upsample2D's nearest-2x + conv in sub-pixel form.
+   *  p[0] A0 bf16 [B][H][W][lda0 >= C0]  p[1] Wt bf16 [N][ldw >= 9*Cin], k = (ky*3+kx)*Cin + c, Cin = C0 + C1
+   *       (sub-pixel mode: [4][N][4*Cin], parity z = 2a+b, k = (ty*2+tx)*Cin + c - weights.py::pack_conv3x3_subpix)
+   *  p[2] out bf16 [B][H][W][ldo] (sub-pixel: [B][2H][2W][ldo])  p[3] bias f32 [N] | NULL
+   *  p[4] rowvec f32 [B][N] | NULL  p[5] residual bf16 (out's shape, row stride ldr) | NULL
+   *  p[6] A1 bf16 [B][H][W][lda1 >= C1] | NULL (second channel source)
+   *  p[7] scale_shift f32 [B][2][Cin] | NULL: input = silu?(x * scale + shift) for in-image pixels (MG_OP_GN_FINALIZE's
+   *       output; zero padding stays zero)
+   *  i[0] B  i[1] H  i[2] W  i[3] C0  i[4] C1  i[5] N  i[6] sub-pixel 2x mode  i[7] silu  i[8] lda0  i[9] lda1
+   *  i[10] ldo  i[11] ldr  i[12] ldw  i[13] rowvec broadcast  i[14] tile variant (0 = auto)
+   *  l[0] parity stride of Wt in elements (sub-pixel mode) */
+  MG_OP_CONV3X3 = 17,
   /* Test-time ensembling (marigold/util/ensemble.py).
    * DEPTH_STATS : one pass over [E][HW]: per-member min,max,mean and the centred E x E
    *               second-moment matrix (closed form of the pairwise-RMSE cost, :138-145).
@@ -148,9 +168,9 @@ enum { MG_POST_NONE = 0, MG_POST_DEPTH = 1, MG_POST_NORMALS = 2, MG_POST_UNIT = 
 
 typedef struct mg_op {
   int32_t kind;
-  int32_t i[24];
+  int32_t i[32];
   float f[8];
-  void* p[8];
+  void* p[12];
   int64_t l[4];
 } mg_op;
 

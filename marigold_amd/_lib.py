@@ -9,13 +9,14 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmarigold_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enum mg_op_kind
 OP_IGEMM, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_LAYERNORM = 1, 2, 3, 4, 5
 OP_FLASH_ATTN64, OP_SOFTMAX_ROWS, OP_SOFTMAX_PAIRS = 6, 7, 8
 OP_CONV_CIN_SMALL, OP_CONV_COUT_SMALL, OP_CONCAT_C, OP_SCHED_STEP = 9, 10, 11, 12
 OP_LINEAR_SMALL_M, OP_LATENT_1X1, OP_POST_NCHW, OP_IM2COL_SMALL = 13, 14, 15, 16
+OP_CONV3X3 = 17
 OP_ENS_DEPTH_STATS, OP_ENS_DEPTH_MEDIAN, OP_ENS_DEPTH_NORM, OP_ENS_NORMALS = 20, 21, 22, 23
 OP_RESIZE = 24
 OP_MEMSET, OP_COPY = 30, 31
@@ -34,8 +35,8 @@ EXPORTS = [
 
 
 class MgOp(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_int32), ("i", ctypes.c_int32 * 24), ("f", ctypes.c_float * 8),
-                ("p", ctypes.c_void_p * 8), ("l", ctypes.c_int64 * 4)]
+    _fields_ = [("kind", ctypes.c_int32), ("i", ctypes.c_int32 * 32), ("f", ctypes.c_float * 8),
+                ("p", ctypes.c_void_p * 12), ("l", ctypes.c_int64 * 4)]
 
 
 class MarigoldHipError(RuntimeError):

@@ -129,9 +129,8 @@ void mg_set_error(const char* fmt, ...);
 // launchers (one per .hip file)
 int mg_launch_igemm(const mg_op* op, hipStream_t s);
 int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant);  // -1: shape needs generation 1
-int mg_launch_igemm3(const mg_op* op, hipStream_t s, int variant);  // experimental halo-shared 3x3 tile (variants 70..79)
 extern int g_igemm_gen;  // 2 (default) | 1 (env MARIGOLD_IGEMM_GEN=1)
-extern int g_halo_conv;  // 0 (default) | 1: halo tile 71 | 2: 71, and 73 where N % 256 == 0 (env MARIGOLD_HALO_CONV)
+int mg_launch_conv_patch(const mg_op* op, hipStream_t s);
 int mg_launch_norm(const mg_op* op, hipStream_t s);
 int mg_launch_attention(const mg_op* op, hipStream_t s);
 int mg_launch_misc(const mg_op* op, hipStream_t s);

@@ -1,0 +1,426 @@
+// Patch-resident 3x3 convolution (MG_OP_CONV3X3): the stride-1 / pad-1 convolutions of the ResNet blocks
+// (diffusers ResnetBlock2D conv1 / conv2, Upsample2D conv - reached from marigold/marigold_depth_pipeline.py:461-463,
+// 491-492, 512-513) with the GroupNorm scale/shift + SiLU of the block fused into the operand staging, the skip
+// concat of the UNet's up blocks folded into the channel loop, and nearest-2x up-sampling in sub-pixel form.
+//
+// Why a second convolution kernel beside the implicit GEMM of igemm2.hip.  The implicit GEMM streams one 64-channel
+// K tile per (tap, channel tile): every input pixel travels global -> LDS nine times (once per tap), which is what
+// (a) made the taps re-fetch from HBM once the activation outgrew L2/MALL (round 1: 2.1x the algorithmic traffic),
+// (b) costs nine LDS-DMA pieces per pixel row and (c) rules out touching the operand on its way in (LDS-DMA bypasses
+// the registers, and a fix-up per staged tile would repeat the GroupNorm + SiLU arithmetic nine times).  Here a
+// workgroup owns a TH x TW tile of output pixels and keeps the (TH+2) x (TW+2) input patch of one 64-channel tile
+// RESIDENT in LDS while all nine taps run over it: each input pixel is staged once per channel tile (1.27x instead
+// of 9x for 16 x 16), the nine taps are nine shifted fragment addresses into the same patch ("im2col" happens in the
+// ds_read addresses of the wavefront), and the GroupNorm affine + SiLU is applied ONCE per staged element, in place,
+// by the waves between the MFMA groups of the previous channel tile.
+//
+//   LDS   [patch buffer 0 | patch buffer 1 | weight ring: NSTB stages of BN rows x 128 B]
+//   K loop  for channel tile c:  for tap t:  { wait + barrier | patch DMA of tile c+1 (taps 0-2) | fix-up slices of
+//           patch c+1 (taps 3-5) | 4 k-substeps: fragment reads (patch rows shifted by the tap, weight rows), the next
+//           weight tile's LDS-DMA pieces, MFMAs }
+//   weights k = tap * Cin + c (the igemm layout); sub-pixel mode: four 2x2 windows, [z][N][4*Cin] (weights.py).
+// Numerics are those of the unfused chain: the fix-up computes silu(x * scale + shift) in fp32 and rounds it to bf16
+// exactly as gn_apply_kernel does, the MFMAs accumulate the same products in fp32 (channel tile outermost instead of
+// tap outermost, so sums differ in the last fp32 bits only).
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+struct ConvPArgs {
+  const bf16_t* A0;
+  const bf16_t* A1;
+  const bf16_t* Wt;
+  bf16_t* out;
+  const float* bias;
+  const float* rowvec;
+  const bf16_t* res;
+  const float* ss;       // fused GroupNorm: [B][2][Cin] fp32 (scale, shift) or nullptr
+  const void* zero;
+  int B, H, W, C0, Cin, N, lda0, lda1, ldo, ldr, ldw, rv_stride, silu, subpix;
+  int tiles_x, tiles_y, tiles_n, chunks, c0t, T, tw;
+  long long sW;
+};
+
+template <int N>
+__device__ __forceinline__ void cp_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// TH x TW output pixels x BN output channels per workgroup; WGM x WGN waves (wave tile TM x TN); NSTB weight stages.
+template <int TH, int TW, int BN, int WGM, int WGN, int NSTB, bool FIX>
+__global__ __launch_bounds__(WGM* WGN * 64) void conv_patch_kernel(const ConvPArgs a) {
+  constexpr int NW = WGM * WGN, NT = NW * 64;
+  constexpr int BM = TH * TW, TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
+  constexpr int ROWB = 128;                                  // bytes per LDS row: 64 bf16 channels
+  constexpr int PRMAX = ((TH + 2) * (TW + 2) + 7) / 8 * 8;   // patch rows, padded to whole 8-row DMA pieces
+  constexpr int NPW = PRMAX / 8;                             // wave-pieces (64 lanes x 16 B = 8 rows) per patch
+  constexpr int NSLOT = (NPW + NW - 1) / NW;                 // patch pieces per wave
+  constexpr int PATCH = PRMAX * ROWB;
+  constexpr int B_IT = BN * 8 / NT;                          // weight pieces per wave and K step
+  constexpr int BSTAGE = BN * ROWB;
+  constexpr int D = NSTB - 1;
+  constexpr int NFIX = (PRMAX * 8 + NT - 1) / NT;            // fix-up vectors per thread
+  static_assert(TW == 16 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0 && (BN * 8) % NT == 0, "tile geometry");
+  static_assert(NSTB >= 2 && NSTB <= 3, "2 or 3 weight stages");
+  static_assert((NT / 8) % 16 == 0, "the fix-up's channel group must not depend on the iteration");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const patch0 = smem;
+  char* const ring = smem + 2 * PATCH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // ---- which tile: output channels fastest (the blocks that share an input patch are neighbours on one XCD) ----
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % a.tiles_n; bid /= a.tiles_n;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+  const int img = bid % a.B;
+  const int z = bid / a.B;                                   // output parity 2a+b in sub-pixel mode, else 0
+  const int n0 = tile_n * BN, y0 = ty * TH, x0 = tx * TW;
+  const int pad_y = a.subpix ? 1 - (z >> 1) : 1, pad_x = a.subpix ? 1 - (z & 1) : 1;
+  const int PW = TW + a.tw - 1, PR = (TH + a.tw - 1) * PW;
+  const bf16_t* __restrict__ Wb = a.Wt + (long long)z * a.sW;
+  const char* zero = (const char*)a.zero;
+
+  // ---- patch staging slots of this thread: LDS row r, 16-byte slot ps <- channel group j of input pixel (iy, ix) ----
+  int p_off[NSLOT];     // pixel index (img * H + iy) * W + ix, or -1 (outside the image / beyond the patch)
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) {
+    const int i = k * NW + wave;
+    const int r = i * 8 + (lane >> 3);
+    const int pr = r / PW, pc = r - pr * PW;
+    const int iy = y0 - pad_y + pr, ix = x0 - pad_x + pc;
+    const bool ok = i < NPW && r < PR && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    p_off[k] = ok ? (img * a.H + iy) * a.W + ix : -1;
+  }
+  // XOR swizzle of the 16-byte slot (applied on the DMA source, undone by the fragment read): slot ps of row r holds
+  // channel group ps ^ ((r >> 1) & 7)
+  auto slot_j8 = [&](int k) {
+    const int i = k * NW + wave;
+    const int r = i * 8 + (lane >> 3);
+    return ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+  };
+  auto issue_patch_slot = [&](int k, int c, int pb) {
+    const int i = k * NW + wave;
+    if (i >= NPW) return;                                   // wave-uniform
+    const char* src = zero;
+    if (p_off[k] >= 0) {
+      const int j8 = slot_j8(k);
+      src = c < a.c0t ? (const char*)(a.A0 + (long long)p_off[k] * a.lda0 + c * 64 + j8)
+                      : (const char*)(a.A1 + (long long)p_off[k] * a.lda1 + (c - a.c0t) * 64 + j8);
+    }
+    glds16(src, patch0 + pb * PATCH + i * 1024);
+  };
+
+  // ---- weight staging rows of this thread ----
+  const char* b_base[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int ci = it * NT + tid;
+    const int r = ci >> 3, p = ci & 7;
+    const int n = n0 + r;
+    b_base[it] = n < a.N ? (const char*)(Wb + (long long)n * a.ldw + (p ^ ((r >> 1) & 7)) * 8) : zero;
+  }
+  auto issue_b_piece = [&](int it, long long koff_bytes, int stage) {
+    glds16(b_base[it] + koff_bytes, ring + stage * BSTAGE + (it * NT + wave * 64) * 16);
+  };
+  auto koff_of = [&](int c, int t) { return ((long long)t * a.Cin + c * 64) * 2; };
+
+  // ---- fragment rows ----
+  int prow0[MI], rowB[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int p = wm * TM + mi * 32 + l31;
+    prow0[mi] = (p >> 4) * PW + (p & 15);
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) rowB[ni] = wn * TN + ni * 32 + l31;
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  // ---- fix-up (fused GroupNorm affine + SiLU on the staged patch, in place) ----
+  // vector e = it NT + tid: row e >> 3, slot e & 7 = tid & 7, channel group (tid & 7) ^ ((row >> 1) & 7) where
+  // (row >> 1) & 7 = (tid >> 4) & 7 for every it (NT / 8 is a multiple of 16): one set of 8 scales / shifts per thread
+  unsigned fix_mask = 0;     // bit it: the row is an in-image pixel (padding rows must stay zero)
+  const int fix_j8 = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+  if constexpr (FIX) {
+#pragma unroll
+    for (int it = 0; it < NFIX; ++it) {
+      const int r = (it * NT + tid) >> 3;
+      const int pr = r / PW, pc = r - pr * PW;
+      const int iy = y0 - pad_y + pr, ix = x0 - pad_x + pc;
+      if (r < PR && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) fix_mask |= 1u << it;
+    }
+  }
+  float fsc[8], fsh[8];
+  auto fix_load = [&](int c) {
+    const float* scp = a.ss + (long long)img * 2 * a.Cin + c * 64 + fix_j8;
+    const float4 s0 = *(const float4*)scp, s1 = *(const float4*)(scp + 4);
+    const float4 h0 = *(const float4*)(scp + a.Cin), h1 = *(const float4*)(scp + a.Cin + 4);
+    fsc[0] = s0.x; fsc[1] = s0.y; fsc[2] = s0.z; fsc[3] = s0.w; fsc[4] = s1.x; fsc[5] = s1.y; fsc[6] = s1.z; fsc[7] = s1.w;
+    fsh[0] = h0.x; fsh[1] = h0.y; fsh[2] = h0.z; fsh[3] = h0.w; fsh[4] = h1.x; fsh[5] = h1.y; fsh[6] = h1.z; fsh[7] = h1.w;
+  };
+  auto fix_vec = [&](int it, int pb) {
+    if (!((fix_mask >> it) & 1u)) return;
+    uint4* p = (uint4*)(patch0 + pb * PATCH + (it * NT + tid) * 16);
+    const uint4 u = *p;
+    float v[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = __builtin_fmaf(v[j], fsc[j], fsh[j]);
+      if (a.silu) v[j] = silu_fast_f(v[j]);
+    }
+    uint4 o;
+    o.x = cvt_pk_bf16_f32(v[0], v[1]); o.y = cvt_pk_bf16_f32(v[2], v[3]);
+    o.z = cvt_pk_bf16_f32(v[4], v[5]); o.w = cvt_pk_bf16_f32(v[6], v[7]);
+    *p = o;
+  };
+
+  const int T = a.T, chunks = a.chunks;
+  const int S = chunks * T;
+
+  // ---- prologue: patch of channel tile 0, the first D weight tiles ----
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) issue_patch_slot(k, 0, 0);
+  {
+    int c = 0, t = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (d < S) {
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) issue_b_piece(it, koff_of(c, t), d);
+      }
+      if (++t == T) { t = 0; ++c; }
+    }
+  }
+  if constexpr (FIX) {
+    fix_load(0);
+    cp_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int it = 0; it < NFIX; ++it) fix_vec(it, 0);
+    // the K loop's first barrier (after its lgkmcnt-complete wait) publishes the fixed patch
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // K-step state: (c, t) of the step being computed, (ci, ti) of the weight tile to issue (D steps ahead)
+  int c = 0, t = 0, ci = 0, ti = 0;
+  for (int d = 0; d < D; ++d) { if (++ti == T) { ti = 0; ++ci; } }
+  int st_c = 0, st_i = D % NSTB;
+
+  auto k_step = [&](int s, auto issue_tag) {
+    constexpr bool ISSUE = decltype(issue_tag)::value;      // a weight tile s + D exists
+    if constexpr (ISSUE) {
+      cp_wait_vmcnt<(D - 1) * B_IT>();
+    } else {
+      const int younger = S - 1 - s;
+      if (D >= 2 && younger >= 1) cp_wait_vmcnt<B_IT>();
+      else cp_wait_vmcnt<0>();
+    }
+    if constexpr (FIX) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fix-up stores have left
+    __builtin_amdgcn_s_barrier();
+    const int pb = c & 1;
+    const bool next_chunk = c + 1 < chunks;
+    // stage the next channel tile's patch (its buffer was last read in the previous channel tile)
+    if (next_chunk && t < 3) {
+#pragma unroll
+      for (int k = 0; k < NSLOT; ++k)
+        if (k % 3 == t) issue_patch_slot(k, c + 1, pb ^ 1);
+    }
+    if constexpr (FIX) {
+      // slices of the fix-up of patch c+1: it landed for every wave at the barrier of tap 3 (issued in taps 0-2, waited
+      // with the weight tiles); taps 3, 4, 5 each fix a third
+      if (next_chunk && t >= 3 && t < 6) {
+        if (t == 3) fix_load(c + 1);
+#pragma unroll
+        for (int it = 0; it < NFIX; ++it)
+          if (it % 3 == t - 3) fix_vec(it, pb ^ 1);
+      }
+    }
+    const char* sP = patch0 + pb * PATCH;
+    const char* sB = ring + st_c * BSTAGE;
+    const int dy = t / a.tw, dx = t - dy * a.tw;
+    const int toff = dy * PW + dx;
+    int abase[MI], af[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int r = prow0[mi] + toff;
+      abase[mi] = r * ROWB;
+      af[mi] = ((r >> 1) & 7) << 4;
+    }
+    const long long koff_i = ISSUE ? koff_of(ci, ti) : 0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int q16 = (ks * 2 + half) << 4;
+      bf16x8 fa[MI], fb[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fa[mi] = __builtin_bit_cast(bf16x8, *(const uint4*)(sP + abase[mi] + (af[mi] ^ q16)));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int r = rowB[ni];
+        fb[ni] = __builtin_bit_cast(bf16x8, *(const uint4*)(sB + r * ROWB + ((((r >> 1) & 7) << 4) ^ q16)));
+      }
+      if constexpr (ISSUE) {
+#pragma unroll
+        for (int it = ks; it < B_IT; it += 4) issue_b_piece(it, koff_i, st_i);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+    if (++t == T) { t = 0; ++c; }
+    if constexpr (ISSUE) { if (++ti == T) { ti = 0; ++ci; } }
+    st_c = (st_c + 1 == NSTB) ? 0 : st_c + 1;
+    st_i = (st_i + 1 == NSTB) ? 0 : st_i + 1;
+  };
+  {
+    int s = 0;
+    for (; s + D < S; ++s) k_step(s, std::true_type{});
+    for (; s < S; ++s) k_step(s, std::false_type{});
+  }
+
+  // ---------------- epilogue (the non-transposed epilogue of igemm2.hip with the tile's pixel map) ----------------
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int p = wm * TM + mi * 32 + l31;
+    const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
+    const bool pix_ok = oy < a.H && ox < a.W;
+    long long orow = ((long long)img * a.H + oy) * a.W + ox;
+    if (a.subpix) orow = ((long long)img * 2 * a.H + 2 * oy + (z >> 1)) * (2 * a.W) + 2 * ox + (z & 1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int nb = n0 + wn * TN + ni * 32;
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) half_swap(acc[ni][mi][8 * gp + j], acc[ni][mi][8 * gp + 4 + j], v[j], v[4 + j]);
+        const int n = nb + 16 * gp + 8 * half;
+        if (pix_ok && n < a.N) {
+          if (a.bias) {
+            const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+          }
+          if (a.rowvec) {
+            const float* rv = a.rowvec + (long long)img * a.rv_stride + n;
+            const float4 r0 = *(const float4*)rv, r1 = *(const float4*)(rv + 4);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+            v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+          }
+          if (a.res) {
+            const uint4 r4 = *(const uint4*)(a.res + orow * a.ldr + n);
+            v[0] += bflo(r4.x); v[1] += bfhi(r4.x); v[2] += bflo(r4.y); v[3] += bfhi(r4.y);
+            v[4] += bflo(r4.z); v[5] += bfhi(r4.z); v[6] += bflo(r4.w); v[7] += bfhi(r4.w);
+          }
+          uint4 pk;
+          pk.x = cvt_pk_bf16_f32(v[0], v[1]); pk.y = cvt_pk_bf16_f32(v[2], v[3]);
+          pk.z = cvt_pk_bf16_f32(v[4], v[5]); pk.w = cvt_pk_bf16_f32(v[6], v[7]);
+          *(uint4*)(a.out + orow * a.ldo + n) = pk;
+        }
+      }
+    }
+  }
+}
+
+template <int TH, int TW, int BN, int WGM, int WGN, int NSTB>
+int launch_patch(const ConvPArgs& a0, hipStream_t s) {
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int PRMAX = ((TH + 2) * (TW + 2) + 7) / 8 * 8;
+  constexpr int LDS = 2 * PRMAX * 128 + NSTB * BN * 128;
+  static_assert(LDS <= 160 * 1024, "LDS budget exceeds 160 KiB");
+  ConvPArgs a = a0;
+  a.tiles_x = (a.W + TW - 1) / TW;
+  a.tiles_y = (a.H + TH - 1) / TH;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const long long grid = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.B * (a.subpix ? 4 : 1);
+  MG_REQUIRE(grid > 0 && grid < (1ll << 31), "conv3x3: bad grid %lld", grid);
+  void (*kern)(const ConvPArgs) = a.ss ? conv_patch_kernel<TH, TW, BN, WGM, WGN, NSTB, true>
+                                       : conv_patch_kernel<TH, TW, BN, WGM, WGN, NSTB, false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[a.ss ? 1 : 0] && !g_dry_run) {
+    MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set[a.ss ? 1 : 0] = true;
+  }
+  MG_LAUNCH(kern, dim3((unsigned)grid), dim3(NT), LDS, s, a);
+  if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// Tile choice: 16 x 16 pixels x 256 channels / 8 waves (wave tile 128 x 64) where N is a multiple of 256;
+// 8 x 16 x 320 / 8 waves (wave tile 32 x 160) for the 320-channel level; 16 x 16 x 128 (wave tile 64 x 64) otherwise.
+int mg_conv3x3_auto_variant(int N) {
+  if (N % 256 == 0) return 1;
+  if (N % 320 == 0) return 3;
+  return 2;
+}
+
+int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
+  ConvPArgs a;
+  a.A0 = (const bf16_t*)op->p[0];
+  a.Wt = (const bf16_t*)op->p[1];
+  a.out = (bf16_t*)op->p[2];
+  a.bias = (const float*)op->p[3];
+  a.rowvec = (const float*)op->p[4];
+  a.res = (const bf16_t*)op->p[5];
+  a.A1 = (const bf16_t*)op->p[6];
+  a.ss = (const float*)op->p[7];
+  a.zero = g_zero_page;
+  a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C0 = op->i[3];
+  const int C1 = op->i[4];
+  a.Cin = a.C0 + C1;
+  a.N = op->i[5];
+  a.subpix = op->i[6];
+  a.silu = op->i[7];
+  a.lda0 = op->i[8] > 0 ? op->i[8] : a.C0;
+  a.lda1 = op->i[9] > 0 ? op->i[9] : C1;
+  a.ldo = op->i[10] > 0 ? op->i[10] : a.N;
+  a.ldr = op->i[11] > 0 ? op->i[11] : a.N;
+  a.T = a.subpix ? 4 : 9;
+  a.tw = a.subpix ? 2 : 3;
+  a.ldw = op->i[12] > 0 ? op->i[12] : a.T * a.Cin;
+  a.rv_stride = op->i[13] ? 0 : a.N;
+  const int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N);
+  a.sW = op->l[0];
+  a.chunks = a.Cin / 64;
+  a.c0t = a.C0 / 64;
+  a.tiles_x = a.tiles_y = a.tiles_n = 0;
+  MG_REQUIRE(g_zero_page || g_dry_run, "conv3x3: mg_init() not called");
+  MG_REQUIRE(a.A0 && a.Wt && a.out, "conv3x3: null pointer");
+  MG_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, "conv3x3: empty problem");
+  MG_REQUIRE(a.C0 > 0 && a.C0 % 64 == 0 && C1 >= 0 && C1 % 64 == 0, "conv3x3: C0 %d / C1 %d must be multiples of 64", a.C0, C1);
+  MG_REQUIRE((C1 == 0) == (a.A1 == nullptr), "conv3x3: second source given without channels (or the reverse)");
+  MG_REQUIRE(a.N > 0 && a.N % 8 == 0 && a.ldo % 8 == 0 && a.ldr % 8 == 0, "conv3x3: N %d, ldo, ldr must be multiples of 8", a.N);
+  MG_REQUIRE(a.lda0 % 8 == 0 && a.lda1 % 8 == 0 && a.ldw % 8 == 0, "conv3x3: lda/ldw must be multiples of 8");
+  MG_REQUIRE((uintptr_t)a.A0 % 16 == 0 && (uintptr_t)a.A1 % 16 == 0 && (uintptr_t)a.Wt % 16 == 0 && (uintptr_t)a.out % 16 == 0 &&
+             (uintptr_t)a.res % 16 == 0 && (uintptr_t)a.bias % 16 == 0 && (uintptr_t)a.rowvec % 16 == 0 && (uintptr_t)a.ss % 16 == 0,
+             "conv3x3: pointers need 16-byte alignment");
+  MG_REQUIRE((long long)a.T * a.Cin * 2 + 256 <= MG_ZERO_BYTES, "conv3x3: K %d exceeds the zero region", a.T * a.Cin);
+  MG_REQUIRE((long long)a.B * a.H * a.W * 4 < (1ll << 31), "conv3x3: too many pixels");
+  if (a.subpix) MG_REQUIRE(!a.ss && !a.res && !a.rowvec && a.sW > 0, "conv3x3: the sub-pixel mode takes bias only and a parity stride");
+  switch (variant) {
+    case 1: return launch_patch<16, 16, 256, 2, 4, 2>(a, s);
+    case 2: return launch_patch<16, 16, 128, 4, 2, 3>(a, s);
+    case 3: return launch_patch<8, 16, 320, 4, 2, 2>(a, s);
+    case 4: return launch_patch<16, 16, 128, 4, 2, 2>(a, s);
+    case 5: return launch_patch<8, 16, 128, 2, 2, 3>(a, s);
+    default: MG_REQUIRE(false, "conv3x3: unknown tile variant %d", variant);
+  }
+  return 0;
+}

@@ -333,26 +333,13 @@ int launch_variant(const IgemmArgs& a, int batch_z, hipStream_t s) {
 int mg_launch_igemm(const mg_op* op, hipStream_t s) {
   {
     const int v = op->i[19];
-    if (v >= 70 && v < 80) return mg_launch_igemm3(op, s, v);
-    if (v == 0 && mg_igemm_generation() == 2 && g_halo_conv) {
-      // A/B switch for the experimental halo tile (never on by default): plain 3x3 / stride 1 / pad 1 convolutions
-      // with enough 256-row tiles to fill the chip; everything else keeps the automatic choice below.
-      const long long M = (long long)op->i[0] * op->i[4] * op->i[5];
-      const int N = op->i[6];
-      const bool plain3x3 = op->i[7] == 9 && op->i[8] == 1 && op->i[9] == 1 && op->i[10] == 0 && op->i[11] == 0 &&
-                            op->i[14] < 0 && op->i[15] <= 1 && (op->i[12] == MG_EPI_BF16 || op->i[12] == MG_EPI_F32) &&
-                            N % 8 == 0 && op->i[13] % 8 == 0 && op->i[3] % 64 == 0;
-      if (plain3x3 && N % 128 == 0 && ((M + 255) / 256) * (N / 128) >= 200) {
-        const bool wide = g_halo_conv == 2 && N % 256 == 0 && ((M + 255) / 256) * (N / 256) >= 512;
-        return mg_launch_igemm3(op, s, wide ? 73 : 71);
-      }
-    }
     if ((v == 0 && mg_igemm_generation() == 2) || v >= 20) {
       const int rc = mg_launch_igemm2(op, s, v);
       if (rc >= 0) return rc;
       MG_REQUIRE(op->i[12] != MG_EPI_GEGLU, "igemm: GEGLU shape unsupported by the generation-2 kernel");
     }
   }
+  MG_REQUIRE(!op->p[7], "igemm: the generation-1 kernel has no second channel source");
   IgemmArgs a;
   a.A = (const bf16_t*)op->p[0];
   a.Wt = (const bf16_t*)op->p[1];

@@ -24,6 +24,8 @@ namespace {
 
 struct Igemm2Args {
   const bf16_t* A;
+  const bf16_t* A1;   // second channel source (channels [C0, Cin) of every tap; the UNet's skip concat) or nullptr
+  int C0, lda1, c0t;  // channels / row stride of the sources; c0t = K tiles per tap that come from A (= cpt without A1)
   const bf16_t* Wt;
   void* out;
   const float* bias;
@@ -112,6 +114,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   const int m0 = tile_m * BM, n0 = a.n_begin + tile_n * BN;
 
   const bf16_t* __restrict__ Ab = a.A + (long long)z * a.sA;
+  const bf16_t* __restrict__ A1b = a.A1;
   const bf16_t* __restrict__ Wb = a.Wt + (long long)z * a.sW;
   const char* zero = (const char*)a.zero;
 
@@ -158,8 +161,10 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   }
   const char* a_ptr[A_IT];
   const int hb = a.Hu ? a.Hu : a.H, wb = a.Hu ? a.Wu : a.W;  // bounds in (virtual) input space
-  auto tap_setup = [&](int tap) {
+  auto tap_setup = [&](int tap, bool second = false) {
     int dy = 0, dx = 0;
+    const bf16_t* __restrict__ Sb = second ? A1b : Ab;
+    const int ld = second ? a.lda1 : a.lda;
     if (a.tw > 1) { dy = tap / a.tw; dx = tap - dy * a.tw; }
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -169,16 +174,16 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
         if (a.up2) { iy >>= 1; ix >>= 1; }
         else { iy = ok ? (iy * a.H) / a.Hu : 0; ix = ok ? (ix * a.W) / a.Wu : 0; }
       }
-      const char* pv = (const char*)(Ab + (a_img[it] + (long long)iy * a.W + ix) * a.lda + a_qoff[it]);
+      const char* pv = (const char*)(Sb + (a_img[it] + (long long)iy * a.W + ix) * ld + a_qoff[it]);
       a_ptr[it] = ok ? pv : zero;
     }
   };
   int i_tap = kt0 / a.cpt, i_c = kt0 - i_tap * a.cpt;  // (tap, channel tile) of the NEXT tile to issue
-  tap_setup(i_tap);
-  if (i_c) {
+  tap_setup(i_tap, i_c >= a.c0t);
+  if (const int skip = i_c >= a.c0t ? i_c - a.c0t : i_c) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it)
-      if (a_ptr[it] != zero) a_ptr[it] += i_c * ROWB;
+      if (a_ptr[it] != zero) a_ptr[it] += skip * ROWB;
   }
   // LDS map: [stage][A rows | B rows]; the ping-pong schedule keeps [A stage 0 | A stage 1 | B stage 0 | B stage 1]
   // so that both stages of an operand are within the 16-bit immediate offset of one base address.
@@ -200,6 +205,8 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
       i_c = 0;
       ++i_tap;
       if (i_tap < a.taps) tap_setup(i_tap);
+    } else if (i_c == a.c0t) {
+      tap_setup(i_tap, true);   // the remaining channel tiles of this tap come from the second source
     }
   };
   auto issue = [&](int stage) {
@@ -690,6 +697,7 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   }
   Igemm2Args b = a;
   b.cpt = a.Cin / BK;
+  b.c0t = a.A1 ? a.C0 / BK : b.cpt;
   b.KT = a.taps * b.cpt;
   b.tiles_m = (a.M + BM - 1) / BM;
   b.tiles_n = (a.n_end - a.n_begin + BN - 1) / BN;
@@ -792,7 +800,11 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   const int trans_from = op->i[14];
   const int batch_z = op->i[15] > 0 ? op->i[15] : 1;
   a.ldr = op->i[16] > 0 ? op->i[16] : a.N;
-  a.lda = op->i[17] > 0 ? op->i[17] : a.Cin;
+  a.A1 = (const bf16_t*)op->p[7];
+  a.C0 = a.A1 ? op->i[24] : a.Cin;
+  a.lda1 = a.A1 ? (op->i[25] > 0 ? op->i[25] : a.Cin - a.C0) : 0;
+  a.c0t = 0;
+  a.lda = op->i[17] > 0 ? op->i[17] : a.C0;
   a.ldt = op->i[18];
   a.ldw = op->i[20] > 0 ? op->i[20] : a.taps * a.Cin;
   a.rv_stride = op->i[21] ? 0 : a.N;
@@ -821,6 +833,10 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   MG_REQUIRE(a.Cin > 0 && a.Cin % 64 == 0, "igemm: Cin %d must be a multiple of 64", a.Cin);
   MG_REQUIRE(a.N > 0 && a.N % 4 == 0, "igemm: N %d must be a multiple of 4", a.N);
   MG_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "igemm: lda/ldw must be multiples of 8");
+  if (a.A1) {
+    MG_REQUIRE(a.C0 > 0 && a.C0 < a.Cin && a.C0 % 64 == 0 && a.lda1 % 8 == 0 && (uintptr_t)a.A1 % 16 == 0 && batch_z == 1 && a.Hu == 0,
+               "igemm: bad second source (C0 %d of Cin %d must be a multiple of 64, no up-sampling / batching)", a.C0, a.Cin);
+  }
   MG_REQUIRE(a.M > 0 && a.stride >= 1, "igemm: empty problem");
   MG_REQUIRE(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.Wt % 16 == 0), "igemm: A/Wt need 16-B alignment");
   // generation-2 preconditions (16-byte epilogue accesses, zero-region reach)

@@ -16,7 +16,7 @@ constexpr int GN_NV = 4;  // channel vectors per thread: supports C <= 256*8*GN_
 // FIXED order - bit-reproducible, no atomics.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x,
                                                        float* __restrict__ partials, int HW, int C,
-                                                       int chunks) {
+                                                       int chunks, int Ctot, int coff) {
   extern __shared__ float lds[];  // [tyn][C][2]
   const int cv = C >> 3;
   const int txn = cv < 256 ? cv : 256;
@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     }
   }
   __syncthreads();
-  float* out = partials + ((long long)b * chunks + chunk) * 2 * C;
+  // channels [coff, coff + C) of a Ctot-channel norm: the skip concat of the UNet's up blocks is normalised without
+  // being materialised, each source contributes its own channels' partial sums
+  float* out = partials + (((long long)b * chunks + chunk) * Ctot + coff) * 2;
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     float t = 0.f;
     for (int y = 0; y < tyn; ++y) t += lds[(long long)y * 2 * C + i];
@@ -125,7 +127,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x,
                                                        const float* __restrict__ ss,
                                                        bf16_t* __restrict__ out, int HW, int C, int silu,
-                                                       int chunks) {
+                                                       int chunks, const bf16_t* __restrict__ x1, int C0) {
+  // C = C0 + C1 output channels: [0, C0) from x ([B][HW][C0]), [C0, C) from x1 ([B][HW][C - C0]) - the concat of the
+  // UNet's up blocks (torch.cat([hidden, skip], dim=1)) happens in this pass' addressing
   const int cv = C >> 3;
   const int txn = cv < 256 ? cv : 256;
   const int tyn = 256 / txn;
@@ -134,7 +138,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int rpc = (HW + chunks - 1) / chunks;
   const int r0 = chunk * rpc, r1 = min(HW, r0 + rpc);
-  const bf16_t* xb = x + (long long)b * HW * C;
   bf16_t* ob = out + (long long)b * HW * C;
   auto norm8 = [&](const uint4& u, const float (&sc)[8], const float (&sh)[8]) {
     float v[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
@@ -154,16 +157,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     const float4 h0 = *(const float4*)(scp + C), h1 = *(const float4*)(scp + C + 4);
     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-    const bf16_t* col = xb + vc * 8;
+    const bool second = vc * 8 >= C0;
+    const int ldx = second ? C - C0 : C0;
+    const bf16_t* col = second ? x1 + (long long)b * HW * ldx + (vc * 8 - C0) : x + (long long)b * HW * ldx + vc * 8;
     bf16_t* ocol = ob + vc * 8;
     int r = r0 + ty;
     for (; r + tyn < r1; r += 2 * tyn) {
-      const uint4 u0 = *(const uint4*)(col + (long long)r * C);
-      const uint4 u1 = *(const uint4*)(col + (long long)(r + tyn) * C);
+      const uint4 u0 = *(const uint4*)(col + (long long)r * ldx);
+      const uint4 u1 = *(const uint4*)(col + (long long)(r + tyn) * ldx);
       *(uint4*)(ocol + (long long)r * C) = norm8(u0, sc, sh);
       *(uint4*)(ocol + (long long)(r + tyn) * C) = norm8(u1, sc, sh);
     }
-    if (r < r1) *(uint4*)(ocol + (long long)r * C) = norm8(*(const uint4*)(col + (long long)r * C), sc, sh);
+    if (r < r1) *(uint4*)(ocol + (long long)r * C) = norm8(*(const uint4*)(col + (long long)r * ldx), sc, sh);
   }
 }
 
@@ -256,8 +261,10 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
       MG_REQUIRE(C % 8 == 0 && C <= 256 * 8 * GN_NV, "gn_stats: unsupported C %d", C);
       MG_REQUIRE(B > 0 && HW > 0 && chunks > 0 && chunks <= HW, "gn_stats: bad dims");
       const int cvv = C / 8, tynn = 256 / (cvv < 256 ? cvv : 256);
+      const int Ctot = op->i[4] > 0 ? op->i[4] : C, coff = op->i[5];
+      MG_REQUIRE(coff >= 0 && coff + C <= Ctot && coff % 8 == 0, "gn_stats: channel window [%d,+%d) outside %d", coff, C, Ctot);
       MG_LAUNCH(gn_stats_kernel, dim3(chunks, B), dim3(256), (size_t)tynn * 2 * C * sizeof(float), s,
-                         (const bf16_t*)op->p[0], (float*)op->p[1], HW, C, chunks);
+                         (const bf16_t*)op->p[0], (float*)op->p[1], HW, C, chunks, Ctot, coff);
       break;
     }
     case MG_OP_GN_FINALIZE: {
@@ -275,8 +282,11 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
       const int cvv = C / 8, tynn = 256 / (cvv < 256 ? cvv : 256);
       int chunks = (2048 + B - 1) / B;
       chunks = max(1, min(chunks, HW / max(1, 8 * tynn)));
+      const bf16_t* x1 = (const bf16_t*)op->p[3];
+      const int C0 = x1 ? op->i[4] : C;
+      MG_REQUIRE(C0 > 0 && C0 <= C && C0 % 8 == 0, "gn_apply: first source has %d of %d channels", C0, C);
       MG_LAUNCH(gn_apply_kernel, dim3(chunks, B), dim3(256), 0, s, (const bf16_t*)op->p[0],
-                (const float*)op->p[1], (bf16_t*)op->p[2], HW, C, op->i[3], chunks);
+                (const float*)op->p[1], (bf16_t*)op->p[2], HW, C, op->i[3], chunks, x1, C0);
       break;
     }
     case MG_OP_LAYERNORM: {

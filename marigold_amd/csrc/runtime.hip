@@ -16,7 +16,6 @@ void* g_zero_page = nullptr;
 void* g_splitk_ws = nullptr;
 thread_local bool g_dry_run = false;
 int g_igemm_gen = 2;
-int g_halo_conv = 0;   // MARIGOLD_HALO_CONV=1|2: route eligible 3x3 convolutions to the experimental halo tile (A/B runs)
 static thread_local char g_err[512] = "";
 static std::mutex g_init_mutex;
 static int g_device = -1;
@@ -37,6 +36,7 @@ struct mg_program {
 static int dispatch(const mg_op* op, hipStream_t s) {
   switch (op->kind) {
     case MG_OP_IGEMM: return mg_launch_igemm(op, s);
+    case MG_OP_CONV3X3: return mg_launch_conv_patch(op, s);
     case MG_OP_GN_STATS:
     case MG_OP_GN_FINALIZE:
     case MG_OP_GN_APPLY:
@@ -75,8 +75,6 @@ static void read_gen_env() {
   done = true;
   const char* e = getenv("MARIGOLD_IGEMM_GEN");
   if (e && e[0] == '1') g_igemm_gen = 1;
-  e = getenv("MARIGOLD_HALO_CONV");
-  if (e && (e[0] == '1' || e[0] == '2')) g_halo_conv = e[0] - '0';
 }
 int mg_igemm_generation(void) { read_gen_env(); return g_igemm_gen; }
 int mg_geglu_interleave(void) { read_gen_env(); return g_igemm_gen == 1 ? 16 : 32; }

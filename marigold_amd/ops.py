@@ -43,14 +43,23 @@ def current_stream_handle():
 def igemm(a, w, out, *, B, H, W, Cin, Ho, Wo, N, taps=1, stride=1, pad=0, up=None, bias=None,
           rowvec=None, residual=None, epi=L.EPI_BF16, ldo=None, out2=None, trans_from=-1, ldt=0,
           batch_z=1, ldr=0, lda=0, ldw=0, zstrides=(0, 0, 0, 0), scale=1.0, variant=0,
-          rowvec_bcast=False, n_alg=0, k_alg=0):
+          rowvec_bcast=False, n_alg=0, k_alg=0, a1=None, C0=0, lda1=0):
     hu, wu = up if up else (0, 0)
     if ldo is None:
         ldo = N // 2 if epi == L.EPI_GEGLU else N
     return make_op(L.OP_IGEMM,
                    i=[B, H, W, Cin, Ho, Wo, N, taps, stride, pad, hu, wu, epi, ldo, trans_from,
-                      batch_z, ldr, lda, ldt, variant, ldw, int(rowvec_bcast), n_alg, k_alg],
-                   f=[scale], p=[a, w, out, bias, rowvec, residual, out2], l=list(zstrides))
+                      batch_z, ldr, lda, ldt, variant, ldw, int(rowvec_bcast), n_alg, k_alg, C0, lda1],
+                   f=[scale], p=[a, w, out, bias, rowvec, residual, out2, a1], l=list(zstrides))
+
+
+def conv3x3(a0, w, out, *, B, H, W, C0, N, a1=None, C1=0, subpix=False, ss=None, silu=False, bias=None, rowvec=None,
+            residual=None, lda0=0, lda1=0, ldo=0, ldr=0, ldw=0, rowvec_bcast=False, variant=0, wz=0):
+    """Patch-resident conv3x3 / pad 1 (MG_OP_CONV3X3): fused GroupNorm scale/shift (+SiLU) on the input, second
+    channel source, sub-pixel 2x up-sampling."""
+    return make_op(L.OP_CONV3X3,
+                   i=[B, H, W, C0, C1, N, int(subpix), int(silu), lda0, lda1, ldo, ldr, ldw, int(rowvec_bcast), variant],
+                   p=[a0, w, out, bias, rowvec, residual, a1, ss], l=[wz])
 
 
 def linear(x, w, out, *, M, K, N, **kw):
@@ -58,16 +67,16 @@ def linear(x, w, out, *, M, K, N, **kw):
     return igemm(x, w, out, B=1, H=M, W=1, Cin=K, Ho=M, Wo=1, N=N, taps=1, **kw)
 
 
-def gn_stats(x, partials, *, B, HW, C, chunks):
-    return make_op(L.OP_GN_STATS, i=[B, HW, C, chunks], p=[x, partials])
+def gn_stats(x, partials, *, B, HW, C, chunks, Ctot=0, coff=0):
+    return make_op(L.OP_GN_STATS, i=[B, HW, C, chunks, Ctot, coff], p=[x, partials])
 
 
 def gn_finalize(partials, gamma, beta, ss, *, B, C, groups, chunks, HW, eps):
     return make_op(L.OP_GN_FINALIZE, i=[B, C, groups, chunks, HW], f=[eps], p=[partials, gamma, beta, ss])
 
 
-def gn_apply(x, ss, out, *, B, HW, C, silu):
-    return make_op(L.OP_GN_APPLY, i=[B, HW, C, int(silu)], p=[x, ss, out])
+def gn_apply(x, ss, out, *, B, HW, C, silu, x1=None, C0=0):
+    return make_op(L.OP_GN_APPLY, i=[B, HW, C, int(silu), C0], p=[x, ss, out, x1])
 
 
 def layernorm(x, gamma, beta, out, *, M, C, eps=1e-5):

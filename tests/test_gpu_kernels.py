@@ -190,6 +190,150 @@ def test_igemm_subpixel_upsample_conv(dev, B, H, W, Cin, Cout, variant):
     _close(f"subpixel up-conv B{B} {H}x{W} {Cin}->{Cout} v{variant}", out.float().permute(0, 3, 1, 2), ref, tol=2e-2)
 
 
+# --------------------------------------------------------------------------- patch-resident conv3x3 (MG_OP_CONV3X3)
+def _ref_fused_conv(x, w, bias, ss, silu, temb, res, up2=False):
+    """torch fp32 reference of the fused chain on bf16-rounded inputs: (GroupNorm affine [+ SiLU], rounded to bf16 like
+    gn_apply's output) -> [nearest 2x] -> conv3x3 pad 1 -> + bias + temb + residual."""
+    h = x
+    if ss is not None:
+        sc, sh = ss[:, 0][:, :, None, None], ss[:, 1][:, :, None, None]
+        h = h * sc + sh
+        if silu:
+            h = h * torch.sigmoid(h)
+        h = _bf(h)
+    if up2:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    out = F.conv2d(h, w, bias, padding=1)
+    if temb is not None:
+        out = out + temb[:, :, None, None]
+    if res is not None:
+        out = out + res
+    return out
+
+
+PATCH_CASES = [
+    # name, B, H, W, C0, C1, N, fused-norm, silu, temb, residual, variant
+    ("v1_plain", 2, 16, 16, 64, 0, 256, False, False, False, False, 1),
+    ("v1_edges_fused", 2, 20, 37, 128, 0, 256, True, True, True, True, 1),
+    ("v1_two_source_fused", 1, 32, 48, 128, 64, 512, True, True, True, False, 1),
+    ("v2_plain_n128", 2, 24, 16, 192, 0, 128, False, False, False, True, 2),
+    ("v2_fused_nedge", 1, 17, 33, 64, 64, 192, True, False, True, True, 2),
+    ("v4_fused_2stage", 1, 16, 32, 128, 0, 128, True, True, False, False, 4),
+    ("v3_n320", 2, 24, 32, 320, 0, 320, True, True, True, True, 3),
+    ("v3_two_source_n640", 1, 9, 21, 320, 320, 640, True, True, False, True, 3),
+    ("v5_small", 1, 8, 16, 64, 0, 128, True, True, False, False, 5),
+    ("auto_n640", 1, 16, 16, 64, 0, 640, False, False, False, False, 0),
+    ("deep_k_fused", 1, 16, 16, 1280, 640, 256, True, True, True, True, 1),
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=[c[0] for c in PATCH_CASES])
+def test_conv3x3_patch(dev, case):
+    from marigold_amd import ops, weights as Wm
+    name, B, H, W, C0, C1, N, fused, silu, use_temb, use_res, variant = case
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    Cin = C0 + C1
+    x = _bf(torch.randn(B, Cin, H, W, generator=g))
+    w = _bf(torch.randn(N, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    bias = torch.randn(N, generator=g) * 0.1
+    ss = torch.stack([1.0 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], dim=1) if fused else None
+    temb = torch.randn(B, N, generator=g) * 0.2 if use_temb else None
+    res = _bf(torch.randn(B, N, H, W, generator=g)) if use_res else None
+    ref = _ref_fused_conv(x, w, bias, ss, silu, temb, res)
+    xh = _nhwc(x)
+    a0 = xh[..., :C0].contiguous().to(dev, torch.bfloat16)
+    a1 = xh[..., C0:].contiguous().to(dev, torch.bfloat16) if C1 else None
+    out = torch.full((B, H, W, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    # the op holds raw device pointers: keep every operand alive for both launches
+    wd, bd = Wm.pack_conv3x3(w).to(dev, torch.bfloat16), bias.to(dev)
+    ssd = None if ss is None else ss.to(dev).contiguous()
+    td = None if temb is None else temb.to(dev).contiguous()
+    rd = None if res is None else _nhwc(res).to(dev, torch.bfloat16)
+    op = ops.conv3x3(a0, wd, out, B=B, H=H, W=W, C0=C0, N=N, a1=a1, C1=C1, ss=ssd, silu=silu, bias=bd, rowvec=td, residual=rd,
+                     variant=variant)
+    _run(op)
+    first = out.clone()
+    _close(f"conv3x3p/{name}", out.float().permute(0, 3, 1, 2), ref)
+    out.fill_(float("nan"))
+    _run(op)
+    assert torch.equal(first, out), "bit-repeatable"
+
+
+@pytest.mark.parametrize("B,H,W,Cin,N,variant", [(2, 16, 16, 64, 256, 1), (1, 9, 21, 192, 128, 2), (2, 24, 24, 320, 320, 3),
+                                                 (1, 48, 48, 640, 640, 0)])
+def test_conv3x3_patch_subpixel(dev, B, H, W, Cin, N, variant):
+    from marigold_amd import ops, weights as Wm
+    g = torch.Generator().manual_seed(H + W + Cin)
+    x = _bf(torch.randn(B, Cin, H, W, generator=g))
+    w = _bf(torch.randn(N, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = _ref_fused_conv(x, w, bias, None, False, None, None, up2=True)
+    out = torch.full((B, 2 * H, 2 * W, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.conv3x3(_nhwc(x).to(dev, torch.bfloat16), Wm.pack_conv3x3_subpix(w).to(dev, torch.bfloat16), out, B=B, H=H, W=W,
+                     C0=Cin, N=N, subpix=True, bias=bias.to(dev), wz=N * 4 * Cin, variant=variant))
+    _close(f"conv3x3p/subpixel B{B} {H}x{W} {Cin}->{N} v{variant}", out.float().permute(0, 3, 1, 2), ref, tol=2e-2)
+
+
+def test_conv3x3_patch_equals_unfused_chain(dev):
+    """The fused kernel feeds the MFMAs the same operands as gn_apply -> concat -> implicit GEMM (same fp32 affine +
+    SiLU, same bf16 rounding of the normalised activation); only the fp32 accumulation order differs (channel tile
+    outermost here, tap outermost there), so the outputs agree to one bf16 rounding of the result."""
+    from marigold_amd import ops, weights as Wm
+    B, H, W, C0, C1, N = 2, 32, 32, 128, 64, 256
+    Cin = C0 + C1
+    g = torch.Generator().manual_seed(5)
+    a0 = torch.randn(B, H, W, C0, generator=g).to(dev, torch.bfloat16)
+    a1 = torch.randn(B, H, W, C1, generator=g).to(dev, torch.bfloat16)
+    w = Wm.pack_conv3x3(torch.randn(N, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dev, torch.bfloat16)
+    ss = torch.stack([1.0 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], dim=1).to(dev).contiguous()
+    bias = (torch.randn(N, generator=g) * 0.1).to(dev)
+    h = torch.empty(B, H, W, Cin, device=dev, dtype=torch.bfloat16)
+    _run(ops.gn_apply(a0, ss, h, B=B, HW=H * W, C=Cin, silu=True, x1=a1, C0=C0))
+    ref = torch.empty(B, H, W, N, device=dev, dtype=torch.bfloat16)
+    _run(ops.igemm(h, w, ref, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, N=N, taps=9, stride=1, pad=1, bias=bias))
+    out = torch.empty_like(ref)
+    _run(ops.conv3x3(a0, w, out, B=B, H=H, W=W, C0=C0, N=N, a1=a1, C1=C1, ss=ss, silu=True, bias=bias))
+    d = (out.float() - ref.float()).abs().max().item()
+    scale = ref.float().abs().max().item()
+    frac = (out != ref).float().mean().item()
+    print(f"[parity] fused conv3x3p vs gn_apply+concat+igemm: max|diff| {d:.3e} (scale {scale:.2f}), {100 * frac:.2f} % of outputs differ")
+    assert d <= scale / 128 and frac < 0.2
+
+
+def test_igemm_two_sources_and_gn_channel_windows(dev):
+    """conv_shortcut over the un-materialised skip concat (1x1 and 3x3, two A sources) and GroupNorm statistics /
+    apply over two sources."""
+    from marigold_amd import ops, weights as Wm
+    B, H, W, C0, C1, N = 2, 12, 20, 128, 192, 320
+    Cin = C0 + C1
+    g = torch.Generator().manual_seed(9)
+    x = _bf(torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.3)
+    xh = _nhwc(x)
+    a0 = xh[..., :C0].contiguous().to(dev, torch.bfloat16)
+    a1 = xh[..., C0:].contiguous().to(dev, torch.bfloat16)
+    for taps, variant in ((1, 0), (9, 0), (9, 62), (1, 53), (9, 33)):
+        w = _bf(torch.randn(N, Cin, 3, 3, generator=g) / math.sqrt(taps * Cin)) if taps == 9 else _bf(torch.randn(N, Cin, 1, 1, generator=g) / math.sqrt(Cin))
+        ref = F.conv2d(x, w, None, padding=1 if taps == 9 else 0)
+        wd = (Wm.pack_conv3x3(w) if taps == 9 else w.reshape(N, Cin)).to(dev, torch.bfloat16)
+        out = torch.full((B, H, W, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.igemm(a0, wd, out, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, N=N, taps=taps, stride=1, pad=1 if taps == 9 else 0,
+                       a1=a1, C0=C0, variant=variant))
+        _close(f"igemm two sources taps={taps} v{variant}", out.float().permute(0, 3, 1, 2), ref)
+    # GroupNorm over the concat: statistics per source into one partial table, finalize, two-source apply
+    groups, chunks, eps = 32, 4, 1e-5
+    gamma, beta = (1.0 + 0.1 * torch.randn(Cin, generator=g)), 0.1 * torch.randn(Cin, generator=g)
+    part = torch.zeros(B * chunks * Cin * 2, device=dev)
+    ss = torch.zeros(B, 2, Cin, device=dev)
+    _run(ops.gn_stats(a0, part, B=B, HW=H * W, C=C0, chunks=chunks, Ctot=Cin, coff=0))
+    _run(ops.gn_stats(a1, part, B=B, HW=H * W, C=C1, chunks=chunks, Ctot=Cin, coff=C0))
+    _run(ops.gn_finalize(part, gamma.to(dev), beta.to(dev), ss, B=B, C=Cin, groups=groups, chunks=chunks, HW=H * W, eps=eps))
+    out = torch.full((B, H, W, Cin), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.gn_apply(a0, ss, out, B=B, HW=H * W, C=Cin, silu=True, x1=a1, C0=C0))
+    ref = F.silu(F.group_norm(x, groups, gamma, beta, eps))
+    _close("groupnorm over two sources", out.float().permute(0, 3, 1, 2), ref)
+
+
 def test_flash_attn64_benchmark_shape(dev):
     """The level-0 self-attention of the 768^2 map: 5 heads x 9216 tokens (96^2 latent), vs CPU SDPA fp32."""
     from marigold_amd import ops
