@@ -206,6 +206,7 @@ void mg_program_destroy(mg_program* prog);
 
 /* Named wrappers - what a binding for the reference's seams would call directly. */
 int mg_conv2d_igemm(const mg_op* conv_desc, void* stream);   /* kind must be MG_OP_IGEMM */
+int mg_conv3x3(const mg_op* conv_desc, void* stream);        /* kind must be MG_OP_CONV3X3 (ResnetBlock2D norm+silu+conv) */
 int mg_sched_step(const float* x, const float* model_out, const float* noise, float* out,
                   int64_t n, float cx, float cm, float cn, void* stream);
 int mg_ensemble_normals(const float* normals, float* out, float* unc, int E, int64_t hw,

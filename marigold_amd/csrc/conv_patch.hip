@@ -363,12 +363,14 @@ int launch_patch(const ConvPArgs& a0, hipStream_t s) {
 
 }  // namespace
 
-// Tile choice: 16 x 16 pixels x 256 channels / 8 waves (wave tile 128 x 64) where N is a multiple of 256;
-// 8 x 16 x 320 / 8 waves (wave tile 32 x 160) for the 320-channel level; 16 x 16 x 128 (wave tile 64 x 64) otherwise.
-int mg_conv3x3_auto_variant(int N) {
+// Tile choice (profiles/r2_sweep3_patch_conv.log, TFLOP/s at the benchmark batch): 16 x 16 pixels x 256 channels /
+// 8 waves (wave tile 128 x 64) where N is a multiple of 256 (VAE 512 / 256 channels: 1100-1130); 8 x 16 x 320 / 8 waves
+// (wave tile 32 x 160) for the 320-channel level (930-1050) and the 640-channel sub-pixel convolution; 16 x 16 x 128 /
+// 8 waves / 2 weight stages (wave tile 64 x 64) otherwise (N = 640: 990-1060, N = 128: 830-1020).
+int mg_conv3x3_auto_variant(int N, int subpix) {
   if (N % 256 == 0) return 1;
-  if (N % 320 == 0) return 3;
-  return 2;
+  if (N == 320 || (subpix && N % 320 == 0)) return 3;
+  return 4;
 }
 
 int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
@@ -396,7 +398,7 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
   a.tw = a.subpix ? 2 : 3;
   a.ldw = op->i[12] > 0 ? op->i[12] : a.T * a.Cin;
   a.rv_stride = op->i[13] ? 0 : a.N;
-  const int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N);
+  const int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N, a.subpix);
   a.sW = op->l[0];
   a.chunks = a.Cin / 64;
   a.c0t = a.C0 / 64;

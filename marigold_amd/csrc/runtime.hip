@@ -216,6 +216,11 @@ int mg_conv2d_igemm(const mg_op* conv_desc, void* stream) {
   return mg_launch_igemm(conv_desc, (hipStream_t)stream);
 }
 
+int mg_conv3x3(const mg_op* conv_desc, void* stream) {
+  MG_REQUIRE(conv_desc && conv_desc->kind == MG_OP_CONV3X3, "mg_conv3x3: op kind must be MG_OP_CONV3X3");
+  return mg_launch_conv_patch(conv_desc, (hipStream_t)stream);
+}
+
 int mg_sched_step(const float* x, const float* model_out, const float* noise, float* out, int64_t n,
                   float cx, float cm, float cn, void* stream) {
   mg_op op;

@@ -9,6 +9,7 @@ the pipeline boundary).  Buffers come from a size-keyed pool that is recycled al
 program order, so the working set of a forward stays small and cache-friendly.
 """
 import math
+import os
 from collections import defaultdict
 
 import torch
@@ -19,6 +20,9 @@ from . import weights as Wm
 from .arch import UNetConfig, VAEConfig, unet_up_resnet_channels
 
 LATENT_SCALE = 0.18215  # marigold_depth_pipeline.py:118
+# A/B switches for tuning runs (defaults are the product configuration)
+USE_PATCH = os.environ.get("MARIGOLD_PATCH_CONV", "1") != "0"      # patch-resident conv3x3 kernel where eligible
+FUSE_GN = os.environ.get("MARIGOLD_FUSE_GN", "auto")               # auto | all | none: GroupNorm apply inside the conv
 
 
 class Act:
@@ -178,19 +182,71 @@ class Builder:
         self.seq.add(op, label)
 
     # ---- primitive layers ----------------------------------------------------------------
-    def group_norm(self, x, name, eps, silu):
-        C, B, HW = x.C, x.B, x.HW
+    def gn_scale_shift(self, srcs, name, eps):
+        """GroupNorm statistics over the channel concat of ``srcs`` (never materialised: one statistics launch per
+        source into a shared partial table) -> fp32 [B][2][C] (scale, shift) buffer."""
+        B, HW = srcs[0].B, srcs[0].HW
+        C = sum(x.C for x in srcs)
         # ~768 (chunk, image) blocks: covers the 256 CUs three times over while keeping the
         # second-level reduction (gn_finalize) short; >= 32 rows per chunk
         chunks = max(1, min(HW // 32, max(16, 768 // B)))
         part = self.raw(B * chunks * C * 2 * 4)
         ss = self.raw(B * 2 * C * 4)
-        out = self.new(x.B, x.H, x.W, C)
-        self.add(O.gn_stats(x.t, part, B=B, HW=HW, C=C, chunks=chunks), f"{name}.stats")
+        coff = 0
+        for k, x in enumerate(srcs):
+            self.add(O.gn_stats(x.t, part, B=B, HW=HW, C=x.C, chunks=chunks, Ctot=C, coff=coff),
+                     f"{name}.stats" + (f"{k}" if len(srcs) > 1 else ""))
+            coff += x.C
         self.add(O.gn_finalize(part, self.ws.vec(f"{name}.weight"), self.ws.vec(f"{name}.bias"), ss, B=B,
                                C=C, groups=self.groups, chunks=chunks, HW=HW, eps=eps), f"{name}.finalize")
-        self.add(O.gn_apply(x.t, ss, out.t, B=B, HW=HW, C=C, silu=silu), f"{name}.apply")
-        self.free(part, ss)
+        self.free(part)
+        return ss
+
+    def gn_apply(self, srcs, ss, name, silu):
+        """Materialise silu?(norm(concat(srcs))) as one NHWC tensor (the concat happens in the pass' addressing)."""
+        x = srcs[0]
+        C = sum(y.C for y in srcs)
+        out = self.new(x.B, x.H, x.W, C)
+        self.add(O.gn_apply(x.t, ss, out.t, B=x.B, HW=x.HW, C=C, silu=silu,
+                            x1=srcs[1].t if len(srcs) > 1 else None, C0=x.C), f"{name}.apply")
+        return out
+
+    def group_norm(self, x, name, eps, silu):
+        ss = self.gn_scale_shift([x], name, eps)
+        out = self.gn_apply([x], ss, name, silu)
+        self.free(ss)
+        return out
+
+    # ---- patch-resident conv3x3 (MG_OP_CONV3X3) ------------------------------------------------------
+    @staticmethod
+    def patch_eligible(H, W):
+        """16-pixel-wide tiles: maps that waste little of them (the 24x24 / 12x12 levels stay on the implicit GEMM,
+        whose split-K also fills the chip there)."""
+        return (H >= 32 and W >= 32) or (H % 16 == 0 and W % 16 == 0)
+
+    def fuse_norm_into_conv(self, B, H, W, Cin, N):
+        """Apply the GroupNorm affine + SiLU inside the convolution's operand staging?  The fix-up runs once per
+        workgroup and channel tile, i.e. (output-channel tiles) x 1.27 (halo) times per element, on VALU that the
+        MFMAs do not hide: it pays when one workgroup covers all output channels (N <= 320) or when the separate
+        pass would be HBM-bound on a tensor that no cache holds (profiles/r2_sweep3_patch_conv.log)."""
+        mode = FUSE_GN
+        if mode != "auto":
+            return mode == "all"
+        tiles_n = 1 if N in (128, 256, 320) else -(-N // (256 if N % 256 == 0 else 128))
+        return tiles_n == 1 or B * H * W * Cin * 2 >= (192 << 20)
+
+    def conv3x3p(self, srcs, name, cout, *, ss=None, silu=False, rowvec=None, residual=None, out=None, subpix=False):
+        x = srcs[0]
+        skip = srcs[1] if len(srcs) > 1 else None
+        H, W = (2 * x.H, 2 * x.W) if subpix else (x.H, x.W)
+        if out is None:
+            out = self.new(x.B, H, W, cout)
+        Cin = x.C + (skip.C if skip else 0)
+        w = self.ws.conv3x3_subpix(name) if subpix else self.ws.conv3x3(name)
+        self.add(O.conv3x3(x.t, w, out.t, B=x.B, H=x.H, W=x.W, C0=x.C, N=cout, a1=skip.t if skip else None,
+                           C1=skip.C if skip else 0, subpix=subpix, ss=ss, silu=silu, bias=self.ws.bias(name),
+                           rowvec=rowvec, rowvec_bcast=rowvec is not None,
+                           residual=None if residual is None else residual.t, wz=cout * 4 * Cin if subpix else 0), name)
         return out
 
     def conv3x3(self, x, name, cout, *, stride=1, pad=1, up=None, rowvec=None, residual=None, out=None):
@@ -203,6 +259,11 @@ class Builder:
             Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
         if out is None:
             out = self.new(x.B, Ho, Wo, cout)
+        if USE_PATCH and stride == 1 and pad == 1 and self.patch_eligible(x.H, x.W):
+            if up is None:
+                return self.conv3x3p([x], name, cout, rowvec=rowvec, residual=residual, out=out)
+            if up == (2 * x.H, 2 * x.W) and rowvec is None and residual is None:
+                return self.conv3x3p([x], name, cout, out=out, subpix=True)
         if up and up == (2 * x.H, 2 * x.W) and stride == 1 and pad == 1 and rowvec is None and residual is None:
             # exact 2x nearest up-sampling: four 2x2 convolutions on the low-resolution input (4/9 of the MACs)
             self.add(O.igemm(x.t, self.ws.conv3x3_subpix(name), out.t, B=x.B, H=x.H, W=x.W, Cin=x.C, Ho=x.H, Wo=x.W,
@@ -238,14 +299,16 @@ class Builder:
         self.add(O.post_nchw(tmp, out, B=x.B, HW=x.HW, Cout=cout, ldi=npad, post=post, scale=scale), f"{key}.post")
         self.free(tmp)
 
-    def dense(self, x, wt, bias, N, *, residual=None, out=None, epi=L.EPI_BF16, label="", K=None, out_dtype_bytes=2):
-        """x: Act viewed as [M][C]; wt: [N][K] bf16."""
-        M, K = x.M, (K or x.C)
+    def dense(self, x, wt, bias, N, *, residual=None, out=None, epi=L.EPI_BF16, label="", K=None, out_dtype_bytes=2,
+              skip=None):
+        """x: Act viewed as [M][C]; wt: [N][K] bf16.  ``skip``: second channel source (K = x.C + skip.C)."""
+        M, K = x.M, (K or x.C + (skip.C if skip is not None else 0))
         n_out = N // 2 if epi == L.EPI_GEGLU else N
         if out is None:
             out = Act(self.pool.get(M * n_out * out_dtype_bytes), x.B, x.H, x.W, n_out)
         self.add(O.linear(x.t, wt, out.t, M=M, K=K, N=N, bias=bias, epi=epi,
-                          residual=None if residual is None else residual.t), label)
+                          residual=None if residual is None else residual.t,
+                          a1=None if skip is None else skip.t, C0=x.C if skip is not None else 0), label)
         return out
 
     def layer_norm(self, x, name):
@@ -255,19 +318,35 @@ class Builder:
         return out
 
     # ---- composite blocks ----------------------------------------------------------------
-    def resnet(self, x, name, cout, eps, temb_row=None):
-        h = self.group_norm(x, f"{name}.norm1", eps, True)
-        h1 = self.conv3x3(h, f"{name}.conv1", cout, rowvec=temb_row)
-        self.free(h)
-        h2 = self.group_norm(h1, f"{name}.norm2", eps, True)
-        self.free(h1)
+    def resnet(self, x, name, cout, eps, temb_row=None, skip=None):
+        """diffusers ResnetBlock2D on the channel concat of ``x`` and ``skip`` (the UNet's up blocks; the concat is
+        never materialised on the patch path).  norm -> SiLU is applied inside the convolution's operand staging where
+        ``fuse_norm_into_conv`` says it pays, else by one pass that also performs the concat."""
+        srcs = [x] + ([skip] if skip is not None else [])
+        Cin = sum(y.C for y in srcs)
+        patch = USE_PATCH and self.patch_eligible(x.H, x.W)
+
+        def norm_conv(inputs, norm, conv, rowvec=None, residual=None, out=None):
+            ss = self.gn_scale_shift(inputs, norm, eps)
+            cin = sum(y.C for y in inputs)
+            if patch and self.fuse_norm_into_conv(x.B, x.H, x.W, cin, cout):
+                y = self.conv3x3p(inputs, conv, cout, ss=ss, silu=True, rowvec=rowvec, residual=residual, out=out)
+            else:
+                h = self.gn_apply(inputs, ss, norm, True)
+                y = self.conv3x3(h, conv, cout, rowvec=rowvec, residual=residual, out=out)
+                self.free(h)
+            self.free(ss)
+            return y
+
+        h1 = norm_conv(srcs, f"{name}.norm1", f"{name}.conv1", rowvec=temb_row)
         if self.ws.has(f"{name}.conv_shortcut"):
             res = self.dense(x, self.ws.mat(f"{name}.conv_shortcut"), self.ws.bias(f"{name}.conv_shortcut"),
-                             cout, label=f"{name}.conv_shortcut")
-            out = self.conv3x3(h2, f"{name}.conv2", cout, residual=res, out=res)  # in-place residual add
+                             cout, label=f"{name}.conv_shortcut", skip=skip)
+            out = norm_conv([h1], f"{name}.norm2", f"{name}.conv2", residual=res, out=res)  # in-place residual add
         else:
-            out = self.conv3x3(h2, f"{name}.conv2", cout, residual=x)
-        self.free(h2)
+            assert skip is None and Cin == cout
+            out = norm_conv([h1], f"{name}.norm2", f"{name}.conv2", residual=x)
+        self.free(h1)
         return out
 
     def self_attention(self, h, y, prefix, heads):
@@ -441,12 +520,11 @@ def emit_unet_forward(bld, cfg, ctx, rgb_latent, x_latent, eps_out, temb_table, 
     rheads = list(cfg.heads)[::-1]
     for (i, j, _rin, _skip, cout) in unet_up_resnet_channels(cfg):
         skip = skips.pop()
-        cat = bld.new(B, x.H, x.W, x.C + skip.C)
-        bld.add(O.concat_c(x.t, skip.t, cat.t, M=x.M, C1=x.C, C2=skip.C), f"up_blocks.{i}.cat.{j}")
-        bld.free(x, skip)
         name = f"up_blocks.{i}.resnets.{j}"
-        y = bld.resnet(cat, name, cout, 1e-5, trow(name, cout))
-        bld.free(cat)
+        # torch.cat([hidden, skip], dim=1) is folded into the consumers: two statistics launches, two-source operand
+        # staging in conv1 / conv_shortcut (or the normalisation pass that materialises the input where it is not fused)
+        y = bld.resnet(x, name, cout, 1e-5, trow(name, cout), skip=skip)
+        bld.free(x, skip)
         if i > 0:
             y = bld.transformer(y, f"up_blocks.{i}.attentions.{j}", rheads[i], ctx)
         x = y

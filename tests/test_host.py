@@ -26,7 +26,7 @@ def test_library_loads_and_exports_header_symbols():
     assert set(names) == set(_lib.EXPORTS)
     assert lib.mg_abi_version() == _lib.ABI_VERSION
     import ctypes
-    assert ctypes.sizeof(_lib.MgOp) == 232
+    assert ctypes.sizeof(_lib.MgOp) == 296   # kind + i[32] + f[8] (+4 pad) + p[12] + l[4]
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -480,88 +480,6 @@ def test_iid_output_container_and_pipeline_contract():
     assert tuple(prog.x.shape) == (2, 8, 8, 16) and tuple(prog.eps.shape) == (2, 8, 8, 16)
 
 
-def test_halo_conv_index_model():
-    """Index model of the experimental halo-shared 3x3 tile (csrc/igemm3.hip): one staged activation tile of
-    256 + 2 pixels per (ky, channel tile) serves the three kx taps - LDS row `slot` holds input pixel
-    m0 - 1 + slot + (ky - 1) * W (zero when that pixel's own image row is not the row this ky reads for it), the
-    fragment of output pixel r for tap kx is row r + kx, or the zero row when x + kx - 1 leaves the image row.
-    Checked against a plain zero-padded im2col for several image shapes, including W = 1 and tiles that span
-    images."""
-    rng = np.random.default_rng(5)
-    BM, ROWS = 256, 264
-    for B, H, W in ((2, 5, 7), (3, 9, 31), (1, 20, 13), (2, 3, 1), (1, 1, 300)):
-        HW, M = H * W, B * H * W
-        img = rng.integers(1, 1000, size=(B, H, W)).astype(np.int64)   # one "channel" is enough for the index logic
-        flat = img.reshape(-1)
-        pad = np.zeros((B, H + 2, W + 2), np.int64)
-        pad[:, 1:-1, 1:-1] = img
-        for m0 in range(0, M, BM):
-            for ky in range(3):
-                staged = np.zeros(ROWS + 1, np.int64)   # last entry = the zero row
-                for slot in range(ROWS):
-                    q = m0 - 1 + slot + (ky - 1) * W
-                    if 0 <= q < M and 0 <= (q % HW) // W - ky + 1 < H:
-                        staged[slot] = flat[q]
-                for kx in range(3):
-                    for r in range(min(BM, M - m0)):
-                        m = m0 + r
-                        b, y, x = m // HW, (m % HW) // W, (m % HW) % W
-                        j = r + kx if 0 <= x + kx - 1 < W else ROWS
-                        assert staged[j] == pad[b, y + ky, x + kx], (B, H, W, m0, ky, kx, r)
-
-
-def test_halo_conv_wait_schedule_model():
-    """Model of the halo tile's per-wave LDS-DMA queue (csrc/igemm3.hip): replay the issue order of the prologue and of
-    every K step, apply the counted `s_waitcnt vmcnt(N)` of the step (oldest loads retire first) and check that the
-    weight tile of the step - and, for kx = 0, the whole activation tile of the triple - have retired, that the
-    counts are the kernel's constants, and that no stage is re-filled while a step still reads it.  Both
-    geometries: 256x128 (2 weight pieces, 3 weight stages) and 256x256 (4 pieces, 2 stages)."""
-    def wait_count(kx, d, pb):          # transcription of igemm3.hip::h_wait_count
-        a = (3, 2, 0)
-        younger = a[(kx + 3 - d % 3) % 3]
-        for j in range(1, d):
-            younger += pb + a[(kx + 3 - j % 3) % 3]
-        if kx == 0:
-            younger = min(younger, pb if d >= 2 else 0)
-        return younger
-
-    for pb, nstb, want in ((2, 3, (2, 5, 7)), (4, 2, (0, 3, 2))):
-        d = nstb - 1
-        assert tuple(wait_count(kx, d, pb) for kx in range(3)) == want
-        for cpt in (1, 2, 5):
-            steps = 9 * cpt
-            queue = []                                   # outstanding loads of one wave, oldest first
-            b_stage_tile, a_stage_tile = {}, {}          # stage -> tile id it holds / is being filled with
-
-            def issue(kind, tile, stage, n):
-                (b_stage_tile if kind == "B" else a_stage_tile)[stage] = tile
-                queue.extend((kind, tile) for _ in range(n))
-
-            issue("A", 0, 0, 5)
-            for s in range(d):
-                issue("B", s, s % nstb, pb)
-            for k in range(steps):
-                kx, triple = k % 3, k // 3
-                n = wait_count(kx, d, pb)
-                del queue[:max(0, len(queue) - n)]       # vmcnt(n): everything but the n youngest has landed
-                assert ("B", k) not in queue, (pb, cpt, k)
-                if kx == 0:
-                    assert ("A", triple) not in queue, (pb, cpt, k)
-                # what this step reads
-                assert b_stage_tile[k % nstb] == k and a_stage_tile[triple % 2] == triple
-                # what it issues (after the barrier): the weight tile D steps ahead into the stage read at step k - 1
-                # (or the dummy past the end), and its share of the next triple's activation tile
-                tgt = (k + d) % nstb
-                assert tgt != k % nstb
-                issue("B", k + d, tgt, pb)
-                if kx == 0:
-                    assert (triple + 1) % 2 != triple % 2
-                    issue("A", triple + 1, (triple + 1) % 2, 3)
-                elif kx == 1:
-                    queue.extend([("A", triple + 1)] * 2)
-            assert len(queue) <= (d * pb + 5)
-
-
 def test_pingpong_gemm_schedule_model():
     """Happens-before model of the ping-pong K loop that the automatic tile choice uses for N % 256 == 0 layers
     (csrc/igemm2.hip, LOOP = 2, tile variants 60-63).  The eight waves form two groups that run one barrier apart;
@@ -646,142 +564,3 @@ def test_pingpong_gemm_schedule_model():
                         didx, depoch = read_done_at[o][(t - 2, h)]
                         assert (didx < iidx) if o == g else (depoch < iepoch), ("WAR", mid, KT, g, o, t, h)
 
-
-def test_halo_conv_variants_validate_and_reject_without_gpu():
-    """The experimental halo tile's launcher (csrc/igemm3.hip, variants 70-73) accepts the gated GPU test shapes and
-    rejects everything outside its subset with a clear error - through the C ABI's dry run, no device needed."""
-    from marigold_amd import _lib as L, ops as O
-    for B, H, W, Cin, Cout, f32 in ((1, 12, 20, 64, 128, False), (3, 9, 31, 128, 192, False), (2, 300, 1, 64, 64, False),
-                                    (1, 24, 24, 256, 128, True)):
-        M = B * H * W
-        x = torch.zeros(M, Cin, dtype=torch.bfloat16)
-        w = torch.zeros(Cout, 9 * Cin, dtype=torch.bfloat16)
-        out = torch.zeros(M, Cout, dtype=torch.float32 if f32 else torch.bfloat16)
-        for v in (70, 71, 72, 73):
-            seq = O.OpSeq(f"halo/v{v}")
-            seq.add(O.igemm(x, w, out, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, N=Cout, taps=9, stride=1, pad=1,
-                            bias=torch.zeros(Cout), epi=L.EPI_F32 if f32 else L.EPI_BF16, variant=v), "conv")
-            seq.validate()
-    x = torch.zeros(64, 64, dtype=torch.bfloat16)
-    for kw, msg in ((dict(Ho=4, Wo=4, taps=9, stride=2, pad=1), "only 3x3 / stride 1 / pad 1"),
-                    (dict(Ho=8, Wo=8, taps=1, stride=1, pad=0), "only 3x3 / stride 1 / pad 1"),
-                    (dict(Ho=8, Wo=8, taps=9, stride=1, pad=1, epi=L.EPI_GEGLU), "bf16 / fp32 epilogue only")):
-        bad = O.OpSeq("bad")
-        bad.add(O.igemm(x, x, x, B=1, H=8, W=8, Cin=64, N=64, variant=70, **kw), "bad")
-        with pytest.raises(L.MarigoldHipError, match=msg):
-            bad.validate()
-    bad = O.OpSeq("bad")
-    bad.add(O.igemm(x, x, x, B=1, H=8, W=8, Cin=64, Ho=8, Wo=8, N=64, taps=9, stride=1, pad=1, variant=74), "bad")
-    with pytest.raises(L.MarigoldHipError, match="unknown halo tile variant"):
-        bad.validate()
-
-
-@pytest.mark.parametrize("BN,WGM,WGN,NSTB", [(128, 4, 2, 3), (256, 2, 4, 2)])
-def test_halo_conv_dataflow_model(BN, WGM, WGN, NSTB):
-    """Executable model of csrc/igemm3.hip's data path, transcribed from the kernel: LDS-DMA pieces (which lane
-    stages which 16-byte chunk of which pixel / weight row, with the XOR swizzle on the SOURCE chunk), the two
-    activation stages + NSTB weight stages and the order in which the K steps fill and read them (DMA data is made
-    to land AT ISSUE, the worst case for overwriting a stage that is still being read), the fragment addresses
-    (`offset ^ (ks << 5)`, zero-row redirect) and the wave -> sub-tile geometry.  The product assembled from those
-    fragments must equal a zero-padded 3x3 convolution, including image borders, a partial last pixel tile and a
-    channel count that is not a multiple of the tile width."""
-    rng = np.random.default_rng(BN)
-    B, H, W, Cin, N = 2, 9, 15, 128, BN + 40         # M = 270: one full + one partial 256-pixel tile; N edge
-    HW, M, cpt = H * W, B * H * W, Cin // 64
-    A = rng.integers(-3, 4, size=(M, Cin)).astype(np.float64)
-    Wt = rng.integers(-3, 4, size=(N, 9 * Cin)).astype(np.float64)          # k = (ky*3 + kx)*Cin + c
-    pad = np.zeros((B, H + 2, W + 2, Cin))
-    pad[:, 1:-1, 1:-1] = A.reshape(B, H, W, Cin)
-    ref = np.zeros((M, N))
-    for ky in range(3):
-        for kx in range(3):
-            ref += pad[:, ky:ky + H, kx:kx + W].reshape(M, Cin) @ Wt[:, (ky * 3 + kx) * Cin:(ky * 3 + kx + 1) * Cin].T
-    BM, NT, ZERO_ROW, A_BLOCKS = 256, 512, 264, 33
-    TM, TN = BM // WGM, BN // WGN
-    MI, NI, PB, D = TM // 32, TN // 32, BN * 8 // NT, NSTB - 1
-    swz = lambda chunk, row: chunk ^ ((row >> 1) & 7)   # noqa: E731
-    out = np.full((M, N), np.nan)
-    for tile_m in range((M + BM - 1) // BM):
-        for tile_n in range((N + BN - 1) // BN):
-            m0, n0 = tile_m * BM, tile_n * BN
-            sA = np.full((2, ZERO_ROW + 1, 8, 8), np.nan)
-            sA[:, ZERO_ROW] = 0.0
-            sB = np.full((NSTB, BN, 8, 8), np.nan)
-            state = dict(i_ky=0, i_c=0, b_ky=0, b_c=0, b_kx=0)
-
-            def a_piece(stage, i):
-                for wave in range(8):
-                    blk = min(i * 8 + wave, A_BLOCKS - 1)
-                    for lane in range(64):
-                        slot, p = blk * 8 + (lane >> 3), lane & 7
-                        q = m0 - 1 + slot + (state["i_ky"] - 1) * W
-                        ok = state["i_ky"] < 3 and 0 <= q < M and 0 <= (q % HW) // W - state["i_ky"] + 1 < H
-                        c0 = state["i_c"] * 64 + swz(p, slot) * 8
-                        sA[stage, slot, p] = A[q, c0:c0 + 8] if ok else 0.0
-
-            def a_advance():
-                state["i_c"] += 1
-                if state["i_c"] == cpt:
-                    state["i_c"], state["i_ky"] = 0, state["i_ky"] + 1
-
-            def b_tile(stage):
-                kofs = (state["b_ky"] * 3 + state["b_kx"]) * Cin + state["b_c"] * 64
-                for it in range(PB):
-                    for tid in range(NT):
-                        ci = it * NT + tid
-                        row, p = ci >> 3, ci & 7
-                        n = n0 + row
-                        live = state["b_ky"] < 3 and n < N
-                        sB[stage, row, p] = Wt[n, kofs + swz(p, row) * 8:kofs + swz(p, row) * 8 + 8] if live else 0.0
-                state["b_kx"] += 1
-                if state["b_kx"] == 3:
-                    state["b_kx"] = 0
-                    state["b_c"] += 1
-                    if state["b_c"] == cpt:
-                        state["b_c"], state["b_ky"] = 0, state["b_ky"] + 1
-
-            for i in range(5):
-                a_piece(0, i)
-            a_advance()
-            for d in range(D):
-                b_tile(d)
-            acc = np.zeros((BM, BN))
-            st_b = st_a = 0
-            for _triple in range(3 * cpt):
-                for kx in range(3):
-                    # what the step reads is captured BEFORE its own DMA lands (issue comes right after the barrier)
-                    b_tile(st_b - 1 if st_b >= 1 else NSTB - 1)
-                    if kx == 0:
-                        for i in (0, 1, 2):
-                            a_piece(st_a ^ 1, i)
-                    elif kx == 1:
-                        for i in (3, 4):
-                            a_piece(st_a ^ 1, i)
-                        a_advance()
-                    for wave in range(8):
-                        wm, wn = wave // WGN, wave % WGN
-                        for ks in range(4):
-                            fa = np.zeros((MI, 32, 16))
-                            fb = np.zeros((NI, 32, 16))
-                            for half in range(2):
-                                for l31 in range(32):
-                                    for mi in range(MI):
-                                        r = wm * TM + mi * 32 + l31
-                                        x = ((m0 + r) % HW) % W
-                                        j = r + kx if 0 <= x + kx - 1 < W else ZERO_ROW
-                                        off = (j * 128 + (swz(half, j) << 4)) ^ (ks << 5)
-                                        fa[mi, l31, half * 8:half * 8 + 8] = sA[st_a, off // 128, (off % 128) // 16]
-                                    for ni in range(NI):
-                                        r = wn * TN + ni * 32 + l31
-                                        off = (r * 128 + (swz(half, r) << 4)) ^ (ks << 5)
-                                        fb[ni, l31, half * 8:half * 8 + 8] = sB[st_b, off // 128, (off % 128) // 16]
-                            for mi in range(MI):
-                                for ni in range(NI):
-                                    acc[wm * TM + mi * 32:wm * TM + mi * 32 + 32,
-                                        wn * TN + ni * 32:wn * TN + ni * 32 + 32] += fa[mi] @ fb[ni].T
-                    st_b = 0 if st_b == NSTB - 1 else st_b + 1
-                st_a ^= 1
-            rows, cols = min(BM, M - m0), min(BN, N - n0)
-            out[m0:m0 + rows, n0:n0 + cols] = acc[:rows, :cols]
-    assert np.isfinite(out).all()
-    np.testing.assert_array_equal(out, ref)
