@@ -41,9 +41,9 @@ enum mg_op_kind {
    *  MG_OP_CONV3X3)  i[8] stride  i[9] pad  i[10] Hu  i[11] Wu (virtual nearest-
    *  upsampled input size, 0 = none)  i[12] epilogue (MG_EPI_*)  i[13] ldo  i[14] trans_from
    *  (columns >= this go to out2 as [img][n-trans_from][ldt] transposed; -1 = none)
-   *  i[15] batch_z  i[16] ldr  i[17] lda  i[18] ldt  i[19] tile variant (0 = auto; 1..13 force a
-   *  generation-1 tile, 20..53 a generation-2 tile, 60..63 the 256x256 ping-pong schedule - used by the
-   *  tuning sweep and the parity tests, see igemm2.hip::dispatch_tile)  i[20] ldw
+   *  i[15] batch_z  i[16] ldr  i[17] lda  i[18] ldt  i[19] tile variant (0 = auto; 20..53 force a tile,
+   *  60..63 the 256x256 ping-pong schedule - used by the tuning sweep and the parity tests, see
+   *  igemm2.hip::dispatch_tile)  i[20] ldw
    *  i[21] rowvec broadcast (1 = a single [N] row shared by every image)
    *  i[22], i[23] un-padded N, K for FLOP accounting (0 = as launched; ignored by the kernel)
    *  l[0..3] z-strides (elements) of A, Wt, out, residual      f[0] scale on the accumulator */
@@ -82,21 +82,6 @@ enum mg_op_kind {
    *  p[0] S f32 [M][lds]  p[1] P bf16 [M][ldp] ; i: M, pairs(=heads), lds, ldp ;
    *  f[0] softmax scale.  Columns >= 2*pairs of P are zero-filled up to ldp. */
   MG_OP_SOFTMAX_PAIRS = 8,
-  /* Direct conv3x3 (pad 1) from <= 8 fp32 NCHW channels (two sources: rgb latent + target
-   * latent, folding the torch.cat of marigold_depth_pipeline.py:456-458) to bf16 NHWC.
-   *  p[0] src0 f32 [B|1][C0][H][W]  p[1] src1 f32 [B][C1][H][W] | NULL
-   *  p[2] W f32 [Cout][9][C0+C1]  p[3] bias f32  p[4] out bf16 [B][H][W][Cout];
-   *  i: B,H,W,C0,C1,Cout, src0_broadcast */
-  MG_OP_CONV_CIN_SMALL = 9,
-  /* Direct conv3x3 (pad 1) bf16 NHWC -> <= 8 fp32 NCHW channels with the pipeline's pointwise
-   * tail fused (MG_POST_*: depth = mean over channels, clip, (x+1)/2 - marigold_depth_
-   * pipeline.py:515,473-475; normals = clip, L2 normalise - marigold_normals_pipeline.py:
-   * 438-440).  p[0] x bf16  p[1] W f32 [Cout][9][Cin]  p[2] bias f32  p[3] out f32 NCHW;
-   *  i: B,H,W,Cin,Cout,post ; f[0] output scale */
-  MG_OP_CONV_COUT_SMALL = 10,
-  /* Channel concat of two NHWC tensors (UNet skip connections).  p[0] a [M][C1] p[1] b [M][C2]
-   * p[2] out [M][C1+C2]; i: M,C1,C2 */
-  MG_OP_CONCAT_C = 11,
   /* Scheduler update (DDIM / LCM, diffusers *.step at marigold_depth_pipeline.py:466-468):
    * out = f[0]*x + f[1]*model_out + f[2]*noise.  p[0] x f32 p[1] model_out f32
    * p[2] noise f32 | NULL  p[3] out f32 ; l[0] n elements */
@@ -111,8 +96,12 @@ enum mg_op_kind {
    * p[2] b f32 p[3] out f32 [B][Co][HW] ; i: B,Ci,Co,HW ; f[0] input scale */
   MG_OP_LATENT_1X1 = 14,
   /* Pointwise tail of a small-Cout convolution computed by MG_OP_IGEMM into a padded fp32 buffer:
-   * out NCHW = post(in[m][0..Cout) * f[0]) with the MG_POST_* tails of MG_OP_CONV_COUT_SMALL.
-   *  p[0] in f32 [B*HW][ldi]  p[1] out f32 NCHW ; i: B, HW, Cout, ldi, post ; f[0] scale */
+   * out NCHW = post(in[m][0..Cout) * f[0]): MG_POST_DEPTH = mean over channels, clip, (x+1)/2 (marigold_depth_
+   * pipeline.py:515,473-475); MG_POST_NORMALS = clip, L2 normalise (marigold_normals_pipeline.py:438-440); MG_POST_UNIT;
+   * MG_POST_SCHED = the DDIM / LCM update of MG_OP_SCHED_STEP applied to conv_out's result in place of storing it:
+   * out <- f[1]*out + f[2]*in + f[3]*noise (out = the latent x_t, NCHW; marigold_depth_pipeline.py:466-468).
+   *  p[0] in f32 [B*HW][ldi]  p[1] out f32 NCHW  p[2] noise f32 NCHW | NULL (MG_POST_SCHED) ;
+   *  i: B, HW, Cout, ldi, post ; f[0] scale, f[1..3] cx, cm, cn */
   MG_OP_POST_NCHW = 15,
   /* im2col of a 3x3 / pad 1 neighbourhood for the <= 8-channel convolutions at the latent / image
    * boundary (conv_in of the UNet incl. the torch.cat of marigold_depth_pipeline.py:456-458, of the
@@ -159,12 +148,18 @@ enum mg_op_kind {
    *  i: planes (= B*C), Hin, Win, Hout, Wout, mode (0 bilinear, 1 bicubic, 2 nearest-exact),
    *  dtype (1: uint8 in/out - computed in float, rounded half-to-even; 0: fp32) */
   MG_OP_RESIZE = 24,
+  /* Colour-mapped depth image (marigold/util/image_util.py:38-76 colorize_depth_maps followed by the pipeline's
+   * (x * 255).astype(uint8), marigold_depth_pipeline.py:318-327): out[px] = LUT[min(int(clip((d-f[0])/(f[1]-f[0]),0,1)*256),255)].
+   *  p[0] depth f32 [n]  p[1] LUT uint8 [256][3] (matplotlib's table)  p[2] out uint8 [n][3] (HWC) ; l[0] n ;
+   *  f[0] min_depth f[1] max_depth */
+  MG_OP_COLORIZE = 25,
   MG_OP_MEMSET = 30, /* p[0] dst ; i[0] byte value ; l[0] bytes */
   MG_OP_COPY = 31    /* p[0] src p[1] dst ; l[0] bytes (device to device) */
 };
 
 enum { MG_EPI_BF16 = 0, MG_EPI_GEGLU = 1, MG_EPI_F32 = 2 };
-enum { MG_POST_NONE = 0, MG_POST_DEPTH = 1, MG_POST_NORMALS = 2, MG_POST_UNIT = 3 /* IID: clip, (x+1)/2 */ };
+enum { MG_POST_NONE = 0, MG_POST_DEPTH = 1, MG_POST_NORMALS = 2, MG_POST_UNIT = 3 /* IID: clip, (x+1)/2 */,
+       MG_POST_SCHED = 4 /* scheduler update in place of the store, see MG_OP_POST_NCHW */ };
 
 typedef struct mg_op {
   int32_t kind;
@@ -180,9 +175,7 @@ typedef struct mg_program mg_program;
 int mg_abi_version(void);
 const char* mg_last_error(void);
 int mg_init(int device);                 /* idempotent; allocates the zero page */
-/* GEMM kernel generation in force (2; 1 with MARIGOLD_IGEMM_GEN=1) and the GEGLU weight-row
- * interleave (32 / 16) the host must pack ff.net.0.proj with. */
-int mg_igemm_generation(void);
+/* GEGLU weight-row interleave the host must pack ff.net.0.proj with (32: 16 u rows, then their 16 gate rows). */
 int mg_geglu_interleave(void);
 int mg_device_info(int* cu_count, int* lds_bytes, int64_t* hbm_bytes, char* arch, int arch_len);
 

@@ -14,19 +14,20 @@ ABI_VERSION = 2
 # enum mg_op_kind
 OP_IGEMM, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_LAYERNORM = 1, 2, 3, 4, 5
 OP_FLASH_ATTN64, OP_SOFTMAX_ROWS, OP_SOFTMAX_PAIRS = 6, 7, 8
-OP_CONV_CIN_SMALL, OP_CONV_COUT_SMALL, OP_CONCAT_C, OP_SCHED_STEP = 9, 10, 11, 12
+OP_SCHED_STEP = 12
 OP_LINEAR_SMALL_M, OP_LATENT_1X1, OP_POST_NCHW, OP_IM2COL_SMALL = 13, 14, 15, 16
 OP_CONV3X3 = 17
 OP_ENS_DEPTH_STATS, OP_ENS_DEPTH_MEDIAN, OP_ENS_DEPTH_NORM, OP_ENS_NORMALS = 20, 21, 22, 23
 OP_RESIZE = 24
+OP_COLORIZE = 25
 OP_MEMSET, OP_COPY = 30, 31
 EPI_BF16, EPI_GEGLU, EPI_F32 = 0, 1, 2
-POST_NONE, POST_DEPTH, POST_NORMALS, POST_UNIT = 0, 1, 2, 3
+POST_NONE, POST_DEPTH, POST_NORMALS, POST_UNIT, POST_SCHED = 0, 1, 2, 3, 4
 
 OP_NAMES = {v: k[3:].lower() for k, v in list(globals().items()) if k.startswith("OP_")}
 
 EXPORTS = [
-    "mg_abi_version", "mg_last_error", "mg_init", "mg_igemm_generation", "mg_geglu_interleave", "mg_device_info", "mg_launch",
+    "mg_abi_version", "mg_last_error", "mg_init", "mg_geglu_interleave", "mg_device_info", "mg_launch",
     "mg_program_create", "mg_program_num_ops", "mg_program_run", "mg_program_validate", "mg_program_run_range",
     "mg_program_capture", "mg_program_profile", "mg_program_destroy", "mg_conv2d_igemm", "mg_conv3x3",
     "mg_sched_step", "mg_ensemble_normals", "mg_event_create", "mg_event_record",
@@ -61,7 +62,6 @@ def load():
         raise MarigoldHipError(f"{LIB_PATH} lacks ABI symbols: {missing}")
     lib.mg_last_error.restype = ctypes.c_char_p
     lib.mg_launch.argtypes = [ctypes.POINTER(MgOp), ctypes.c_void_p]
-    lib.mg_igemm_generation.restype = ctypes.c_int
     lib.mg_geglu_interleave.restype = ctypes.c_int
     lib.mg_conv2d_igemm.argtypes = [ctypes.POINTER(MgOp), ctypes.c_void_p]
     lib.mg_conv3x3.argtypes = [ctypes.POINTER(MgOp), ctypes.c_void_p]

@@ -9,7 +9,7 @@ import os
 import torch
 from safetensors.torch import load_file, save_file
 
-from .arch import UNetConfig, VAEConfig
+from . import config_check as CC
 from .modules import AutoencoderKLHIP, UNet2DConditionModelHIP
 from .schedulers import DDIMScheduler, LCMScheduler
 
@@ -59,29 +59,46 @@ def _resolve(path):
             f"download it first (script/download_weights.sh in the reference) and pass the folder") from e
 
 
+# scheduler_config.json fields that do not enter the arithmetic of this path, with the only value accepted
+_SCHED_INERT = {"trained_betas": (None,), "thresholding": (False,), "clip_sample_range": None, "dynamic_thresholding_ratio": None,
+                "sample_max_value": None, "skip_prk_steps": None}
+
+
+def _scheduler_kwargs(sname, scfg):
+    allowed = set(_SCHEDULERS[sname]._defaults)
+    kw = {}
+    for k, v in scfg.items():
+        if k.startswith("_"):
+            continue
+        if k in allowed:
+            kw[k] = v
+        elif k in _SCHED_INERT:
+            ok = _SCHED_INERT[k]
+            if ok is not None and v not in ok:
+                raise CC.UnsupportedConfigError(f"scheduler/scheduler_config.json: {k} = {v!r} is not implemented")
+        else:
+            raise CC.UnsupportedConfigError(f"scheduler/scheduler_config.json: unknown field '{k}' = {v!r}")
+    return kw
+
+
 def load_pipeline(cls, path, variant=None, torch_dtype=None, **kw):
     path = _resolve(path)
     index = _json(os.path.join(path, "model_index.json"))
-    ucfg = _json(os.path.join(path, "unet", "config.json"))
-    unet_cfg = UNetConfig(in_channels=ucfg.get("in_channels", 8), out_channels=ucfg.get("out_channels", 4),
-                          block_out_channels=tuple(ucfg.get("block_out_channels", (320, 640, 1280, 1280))),
-                          layers_per_block=ucfg.get("layers_per_block", 2),
-                          heads=tuple(ucfg.get("attention_head_dim", (5, 10, 20, 20))),
-                          cross_attention_dim=ucfg.get("cross_attention_dim", 1024),
-                          norm_groups=ucfg.get("norm_num_groups", 32))
-    vcfg = _json(os.path.join(path, "vae", "config.json"))
-    vae_cfg = VAEConfig(block_out_channels=tuple(vcfg.get("block_out_channels", (128, 256, 512, 512))),
-                        layers_per_block=vcfg.get("layers_per_block", 2),
-                        latent_channels=vcfg.get("latent_channels", 4),
-                        norm_groups=vcfg.get("norm_num_groups", 32))
+    # every field of the two config files is checked against what the engine implements: a value it cannot honour
+    # (or a field it does not know) raises instead of loading a model that would compute something else
+    unet_cfg = CC.unet_config_from_json(_json(os.path.join(path, "unet", "config.json")))
+    vae_cfg = CC.vae_config_from_json(_json(os.path.join(path, "vae", "config.json")))
+    if torch_dtype is not None and torch_dtype not in (torch.bfloat16,):
+        import logging
+        logging.warning(f"torch_dtype={torch_dtype} is ignored: the HIP engine computes in bf16 with fp32 accumulation "
+                        f"and keeps latents / predictions in fp32")
     unet = UNet2DConditionModelHIP(_weights(os.path.join(path, "unet"), variant), unet_cfg)
     vae = AutoencoderKLHIP(_rename_legacy_vae_keys(_weights(os.path.join(path, "vae"), variant)), vae_cfg)
     scfg = _json(os.path.join(path, "scheduler", "scheduler_config.json"))
     sname = scfg.get("_class_name", "DDIMScheduler")
     if sname not in _SCHEDULERS:
         raise RuntimeError(f"Unsupported scheduler type: {sname}")
-    allowed = set(_SCHEDULERS[sname]._defaults)
-    scheduler = _SCHEDULERS[sname](**{k: v for k, v in scfg.items() if k in allowed})
+    scheduler = _SCHEDULERS[sname](**_scheduler_kwargs(sname, scfg))
     text_encoder = tokenizer = empty = None
     emb = os.path.join(path, "empty_text_embed.safetensors")
     if os.path.exists(emb):
@@ -110,13 +127,14 @@ def save_synthetic_checkpoint(path, cls_name, unet_sd, vae_sd, unet_cfg, vae_cfg
               os.path.join(path, "unet", "diffusion_pytorch_model.safetensors"))
     save_file({k: v.contiguous() for k, v in vae_sd.items()},
               os.path.join(path, "vae", "diffusion_pytorch_model.safetensors"))
+    # the full published key sets (config_check.SD2_*), with the fields this architecture instance changes
     with open(os.path.join(path, "unet", "config.json"), "w") as f:
-        json.dump(dict(_class_name="UNet2DConditionModel", in_channels=unet_cfg.in_channels,
+        json.dump(dict(CC.SD2_UNET_CONFIG, in_channels=unet_cfg.in_channels,
                        out_channels=unet_cfg.out_channels, block_out_channels=list(unet_cfg.block_out_channels),
                        layers_per_block=unet_cfg.layers_per_block, attention_head_dim=list(unet_cfg.heads),
                        cross_attention_dim=unet_cfg.cross_attention_dim, norm_num_groups=unet_cfg.norm_groups), f)
     with open(os.path.join(path, "vae", "config.json"), "w") as f:
-        json.dump(dict(_class_name="AutoencoderKL", block_out_channels=list(vae_cfg.block_out_channels),
+        json.dump(dict(CC.SD2_VAE_CONFIG, block_out_channels=list(vae_cfg.block_out_channels),
                        layers_per_block=vae_cfg.layers_per_block, latent_channels=vae_cfg.latent_channels,
                        norm_num_groups=vae_cfg.norm_groups), f)
     with open(os.path.join(path, "scheduler", "scheduler_config.json"), "w") as f:

@@ -9,7 +9,7 @@
 //    max/sum are lane-local plus a single lane^32 exchange, and the exponentiated P registers
 //    feed the PV MFMA as its B operand with no cross-lane shuffle - V^T is read from LDS in the
 //    matching key order (two ds_read_b64 per fragment).  V^T itself is produced by the QKV
-//    projection's transposed epilogue (igemm.hip), never by a transpose pass.
+//    projection's transposed epilogue (igemm2.hip), never by a transpose pass.
 //  * softmax_rows: fp32 -> bf16 row softmax for the VAE's single-head d=512 attention, whose
 //    scores are materialised by the GEMM kernel (288 GB HBM: 340 MB/member is cheap).
 //  * softmax_pairs: 2-key softmax of the collapsed cross-attention (see marigold_hip.h).

@@ -128,8 +128,7 @@ void mg_set_error(const char* fmt, ...);
 
 // launchers (one per .hip file)
 int mg_launch_igemm(const mg_op* op, hipStream_t s);
-int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant);  // -1: shape needs generation 1
-extern int g_igemm_gen;  // 2 (default) | 1 (env MARIGOLD_IGEMM_GEN=1)
+int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant);  // -1: shape outside the kernel's contract
 int mg_launch_conv_patch(const mg_op* op, hipStream_t s);
 int mg_launch_norm(const mg_op* op, hipStream_t s);
 int mg_launch_attention(const mg_op* op, hipStream_t s);

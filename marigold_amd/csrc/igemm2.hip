@@ -1,9 +1,9 @@
-// Implicit-GEMM bf16 MFMA kernel, generation 2 (the default): same contract as igemm.hip
+// Implicit-GEMM bf16 MFMA kernel
 // (MG_OP_IGEMM in include/marigold_hip.h: conv3x3 / conv1x1 / Linear / batched GEMM replacing the
 // torch conv2d / linear / matmul calls inside diffusers' UNet2DConditionModel / AutoencoderKL,
 // reference call sites marigold/marigold_depth_pipeline.py:461-463, 491-492, 512-513).
 //
-// What changed against generation 1, all of it aimed at the two things the first profile showed
+// Design points, all of them aimed at the two things the first profile of a plain tile loop showed
 // (UNet GEMMs at 14 % of the MFMA roof, the loop draining its DMA queue at every barrier):
 //   * NSTAGE-deep LDS ring filled by global_load_lds_dwordx4 with COUNTED `s_waitcnt vmcnt(N)` and a
 //     raw `s_barrier`: up to NSTAGE-1 K tiles stay in flight across the barrier (one barrier per
@@ -782,7 +782,7 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
 
 int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu);
 
-// Generation-2 entry: returns -1 when the op needs the generation-1 kernel (unsupported shape).
+// returns -1 when the shape is outside the kernel's contract (mg_launch_igemm turns that into an error)
 int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   Igemm2Args a;
   a.A = (const bf16_t*)op->p[0];
@@ -910,4 +910,11 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
   }
   if (t128x64 >= 96) return 35;
   return 23;
+}
+
+int mg_launch_igemm(const mg_op* op, hipStream_t s) {
+  const int rc = mg_launch_igemm2(op, s, op->i[19]);
+  MG_REQUIRE(rc >= 0, "igemm: unsupported shape (N %d, ldo %d, residual stride %d must be multiples of 8; GEGLU needs N %% 32 == 0; "
+             "out / residual 16-byte aligned; K within the zero region)", op->i[6], op->i[13], op->i[16]);
+  return rc;
 }

@@ -1,130 +1,9 @@
-// Small / HBM-bound kernels around the MFMA path: the 4<->C channel convolutions at the latent
-// and image boundaries (fp32 NCHW <-> bf16 NHWC), skip concat, the scheduler update, the
-// time-embedding dense layers and the post_quant 1x1 conv.
+// Small / HBM-bound kernels around the MFMA path: im2col / pointwise tails of the 4<->C channel convolutions at the
+// latent and image boundaries (fp32 NCHW <-> bf16 NHWC), the scheduler update, the time-embedding dense layers and
+// the post_quant 1x1 conv.
 #include "common.h"
 
 namespace {
-
-// ---- conv3x3 pad 1, <= 8 fp32 NCHW input channels (two sources) -> bf16 NHWC ----------------
-// One thread per output pixel, looping over all Cout in groups of 8 (16-byte NHWC stores); the
-// 3x3xCin neighbourhood stays in registers, weights are wave-uniform (scalar loads).
-// Folds torch.cat([rgb_latent, target_latent]) (marigold_depth_pipeline.py:456-458) + conv_in.
-template <int CIN>
-__global__ __launch_bounds__(256) void conv_cin_small_kernel(
-    const float* __restrict__ src0, const float* __restrict__ src1, const float* __restrict__ Wt,
-    const float* __restrict__ bias, bf16_t* __restrict__ out, int B, int H, int W, int C0, int Cout,
-    int bcast0) {
-  const long long hw = (long long)H * W;
-  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= (long long)B * hw) return;
-  const int b = (int)(pix / hw);
-  const int rem = (int)(pix % hw);
-  const int y = rem / W, x = rem % W;
-  float in[9][CIN];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) {
-      float v = 0.f;
-      if (ok) {
-        if (c < C0) v = src0[((long long)(bcast0 ? 0 : b) * C0 + c) * hw + (long long)iy * W + ix];
-        else v = src1[((long long)b * (CIN - C0) + (c - C0)) * hw + (long long)iy * W + ix];
-      }
-      in[t][c] = v;
-    }
-  }
-  bf16_t* o = out + pix * Cout;
-  for (int cg = 0; cg < Cout; cg += 8) {
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bias[cg + j];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float* w = Wt + (long long)(cg + j) * 9 * CIN;
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int c = 0; c < CIN; ++c) acc[j] += in[t][c] * w[t * CIN + c];
-    }
-    uint4 pk;
-    pk.x = pack2bf(acc[0], acc[1]); pk.y = pack2bf(acc[2], acc[3]);
-    pk.z = pack2bf(acc[4], acc[5]); pk.w = pack2bf(acc[6], acc[7]);
-    *(uint4*)(o + cg) = pk;
-  }
-}
-
-// ---- conv3x3 pad 1, bf16 NHWC -> <= 8 fp32 NCHW channels, pipeline tail fused ----------------
-template <int COUT>
-__global__ __launch_bounds__(256) void conv_cout_small_kernel(
-    const bf16_t* __restrict__ x, const float* __restrict__ Wt, const float* __restrict__ bias,
-    float* __restrict__ out, int B, int H, int W, int Cin, int post, float oscale) {
-  const long long hw = (long long)H * W;
-  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= (long long)B * hw) return;
-  const int b = (int)(pix / hw);
-  const int rem = (int)(pix % hw);
-  const int y = rem / W, xx = rem % W;
-  float acc[COUT];
-#pragma unroll
-  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-  for (int t = 0; t < 9; ++t) {
-    const int iy = y + t / 3 - 1, ix = xx + t % 3 - 1;
-    if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
-    const bf16_t* xr = x + ((long long)b * hw + (long long)iy * W + ix) * Cin;
-    for (int c = 0; c < Cin; c += 8) {
-      const uint4 u = *(const uint4*)(xr + c);
-      const float v[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
-#pragma unroll
-      for (int co = 0; co < COUT; ++co) {
-        const float* w = Wt + ((long long)co * 9 + t) * Cin + c;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[co] += v[j] * w[j];
-      }
-    }
-  }
-#pragma unroll
-  for (int co = 0; co < COUT; ++co) acc[co] = (acc[co] + bias[co]) * oscale;
-  const long long p = (long long)rem;
-  if (post == MG_POST_DEPTH) {
-    float m = 0.f;
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) m += acc[co];
-    m = m / (float)COUT;
-    m = fminf(fmaxf(m, -1.f), 1.f);
-    out[(long long)b * hw + p] = (m + 1.0f) * 0.5f;
-  } else if (post == MG_POST_NORMALS) {
-    float n2 = 0.f;
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-      acc[co] = fminf(fmaxf(acc[co], -1.f), 1.f);
-      n2 += acc[co] * acc[co];
-    }
-    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-6f);
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) out[((long long)b * COUT + co) * hw + p] = acc[co] * inv;
-  } else {
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) out[((long long)b * COUT + co) * hw + p] = acc[co];
-  }
-}
-
-__global__ __launch_bounds__(256) void concat_c_kernel(const bf16_t* __restrict__ a,
-                                                       const bf16_t* __restrict__ b,
-                                                       bf16_t* __restrict__ out, long long M, int C1,
-                                                       int C2) {
-  const int v1 = C1 >> 3, v2 = C2 >> 3, vt = v1 + v2;
-  const long long total = M * vt;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
-       i += (long long)gridDim.x * 256) {
-    const long long m = i / vt;
-    const int v = (int)(i % vt);
-    const uint4 u = v < v1 ? *(const uint4*)(a + m * C1 + v * 8)
-                           : *(const uint4*)(b + m * C2 + (v - v1) * 8);
-    *(uint4*)(out + i * 8) = u;
-  }
-}
 
 __global__ __launch_bounds__(256) void sched_step_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ mo,
@@ -224,7 +103,8 @@ __global__ __launch_bounds__(256) void im2col_small_kernel(const float* __restri
 template <int COUT>
 __global__ __launch_bounds__(256) void post_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         long long npix, long long HW, int ldi, int post,
-                                                        float scale) {
+                                                        float scale, const float* __restrict__ noise, float cx, float cm,
+                                                        float cn) {
   for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < npix;
        pix += (long long)gridDim.x * 256) {
     const long long b = pix / HW, p = pix - b * HW;
@@ -254,6 +134,16 @@ __global__ __launch_bounds__(256) void post_nchw_kernel(const float* __restrict_
       const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-6f);
 #pragma unroll
       for (int co = 0; co < COUT; ++co) out[(b * COUT + co) * HW + p] = acc[co] * inv;
+    } else if (post == MG_POST_SCHED) {
+      // the DDIM / LCM update applied to the UNet's output in place of storing it: x <- cx x + cm model_out + cn noise
+      // (same operation order as sched_step_kernel: bit-identical to the two-launch form)
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) {
+        const long long i = (b * COUT + co) * HW + p;
+        float v = cx * out[i] + cm * acc[co];
+        if (noise) v += cn * noise[i];
+        out[i] = v;
+      }
     } else if (post == MG_POST_UNIT) {   // IID: clip to [-1,1], shift to [0,1] (marigold_iid_pipeline.py:523-526)
 #pragma unroll
       for (int co = 0; co < COUT; ++co)
@@ -269,55 +159,6 @@ __global__ __launch_bounds__(256) void post_nchw_kernel(const float* __restrict_
 
 int mg_launch_misc(const mg_op* op, hipStream_t s) {
   switch (op->kind) {
-    case MG_OP_CONV_CIN_SMALL: {
-      const int B = op->i[0], H = op->i[1], W = op->i[2], C0 = op->i[3], C1 = op->i[4], Cout = op->i[5];
-      const int cin = C0 + C1;
-      MG_REQUIRE(Cout % 8 == 0, "conv_cin_small: Cout %d must be a multiple of 8", Cout);
-      MG_REQUIRE(C1 == 0 || op->p[1], "conv_cin_small: src1 missing");
-      const long long npix = (long long)B * H * W;
-      const dim3 grid((unsigned)((npix + 255) / 256));
-#define CIN_CASE(N)                                                                              \
-  case N:                                                                                        \
-    MG_LAUNCH(conv_cin_small_kernel<N>, grid, dim3(256), 0, s, (const float*)op->p[0],  \
-                       (const float*)op->p[1], (const float*)op->p[2], (const float*)op->p[3],   \
-                       (bf16_t*)op->p[4], B, H, W, C0, Cout, op->i[6]);                          \
-    break;
-      switch (cin) {
-        CIN_CASE(3) CIN_CASE(4) CIN_CASE(8)
-        default: MG_REQUIRE(false, "conv_cin_small: unsupported Cin %d (3, 4 or 8)", cin);
-      }
-#undef CIN_CASE
-      break;
-    }
-    case MG_OP_CONV_COUT_SMALL: {
-      const int B = op->i[0], H = op->i[1], W = op->i[2], Cin = op->i[3], Cout = op->i[4];
-      MG_REQUIRE(Cin % 8 == 0, "conv_cout_small: Cin %d must be a multiple of 8", Cin);
-      const long long npix = (long long)B * H * W;
-      const dim3 grid((unsigned)((npix + 255) / 256));
-      const float osc = op->f[0] == 0.f ? 1.f : op->f[0];
-#define COUT_CASE(N)                                                                             \
-  case N:                                                                                        \
-    MG_LAUNCH(conv_cout_small_kernel<N>, grid, dim3(256), 0, s, (const bf16_t*)op->p[0], \
-                       (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], B, H, W, \
-                       Cin, op->i[5], osc);                                                      \
-    break;
-      switch (Cout) {
-        COUT_CASE(3) COUT_CASE(4) COUT_CASE(8)
-        default: MG_REQUIRE(false, "conv_cout_small: unsupported Cout %d (3, 4 or 8)", Cout);
-      }
-#undef COUT_CASE
-      break;
-    }
-    case MG_OP_CONCAT_C: {
-      const long long M = op->i[0];
-      const int C1 = op->i[1], C2 = op->i[2];
-      MG_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0, "concat_c: channel counts must be multiples of 8");
-      const long long total = M * ((C1 + C2) / 8);
-      const int grid = (int)min((total + 255) / 256, (long long)8192);
-      MG_LAUNCH(concat_c_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)op->p[0],
-                         (const bf16_t*)op->p[1], (bf16_t*)op->p[2], M, C1, C2);
-      break;
-    }
     case MG_OP_SCHED_STEP: {
       const long long n = op->l[0];
       const int grid = (int)min((n + 255) / 256, (long long)4096);
@@ -369,11 +210,11 @@ int mg_launch_misc(const mg_op* op, hipStream_t s) {
       const int grid = (int)min((npix + 255) / 256, (long long)8192);
       const float sc = op->f[0] == 0.f ? 1.f : op->f[0];
       switch (Cout) {
-        case 1: MG_LAUNCH(post_nchw_kernel<1>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
-        case 3: MG_LAUNCH(post_nchw_kernel<3>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
-        case 4: MG_LAUNCH(post_nchw_kernel<4>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
-        case 8: MG_LAUNCH(post_nchw_kernel<8>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
-        case 12: MG_LAUNCH(post_nchw_kernel<12>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc); break;
+        case 1: MG_LAUNCH(post_nchw_kernel<1>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc, (const float*)op->p[2], op->f[1], op->f[2], op->f[3]); break;
+        case 3: MG_LAUNCH(post_nchw_kernel<3>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc, (const float*)op->p[2], op->f[1], op->f[2], op->f[3]); break;
+        case 4: MG_LAUNCH(post_nchw_kernel<4>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc, (const float*)op->p[2], op->f[1], op->f[2], op->f[3]); break;
+        case 8: MG_LAUNCH(post_nchw_kernel<8>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc, (const float*)op->p[2], op->f[1], op->f[2], op->f[3]); break;
+        case 12: MG_LAUNCH(post_nchw_kernel<12>, dim3(grid), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1], npix, HW, ldi, post, sc, (const float*)op->p[2], op->f[1], op->f[2], op->f[3]); break;
         default: MG_REQUIRE(false, "post_nchw: unsupported Cout %d (1, 3, 4, 8 or 12)", Cout);
       }
       break;

@@ -95,7 +95,36 @@ void launch_pass(const void* src, void* dst, long long total, int in_len, int ou
 
 }  // namespace
 
+// Colour-mapped depth (marigold/util/image_util.py:38-76 colorize_depth_maps + the pipeline's (x * 255).astype(uint8),
+// marigold_depth_pipeline.py:318-327): matplotlib's listed / segmented colormaps are 256-entry tables indexed by
+// int(x * 256) (x == 1 -> 255); the table arrives as uint8 RGB (built once per colormap on the host from matplotlib
+// itself), the output is the HWC uint8 image PIL takes.
+__global__ __launch_bounds__(256) void colorize_kernel(const float* __restrict__ depth, const uint8_t* __restrict__ lut,
+                                                       uint8_t* __restrict__ out, long long n, float lo, float inv_range) {
+  __shared__ uint8_t tab[768];
+  for (int i = threadIdx.x; i < 768; i += 256) tab[i] = lut[i];
+  __syncthreads();
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float x = (depth[i] - lo) * inv_range;
+    x = fminf(fmaxf(x, 0.f), 1.f);
+    int k = (int)(x * 256.0f);
+    k = k > 255 ? 255 : k;
+    out[3 * i + 0] = tab[3 * k + 0];
+    out[3 * i + 1] = tab[3 * k + 1];
+    out[3 * i + 2] = tab[3 * k + 2];
+  }
+}
+
 int mg_launch_resize(const mg_op* op, hipStream_t s) {
+  if (op->kind == MG_OP_COLORIZE) {
+    const long long n = op->l[0];
+    MG_REQUIRE(n > 0 && op->p[0] && op->p[1] && op->p[2], "colorize: null pointer / empty map");
+    MG_REQUIRE(op->f[1] > op->f[0], "colorize: max_depth must exceed min_depth");
+    MG_LAUNCH(colorize_kernel, dim3((unsigned)min((n + 255) / 256, (long long)4096)), dim3(256), 0, s, (const float*)op->p[0],
+              (const uint8_t*)op->p[1], (uint8_t*)op->p[2], n, op->f[0], 1.0f / (op->f[1] - op->f[0]));
+    if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const long long planes = op->i[0];
   const int Hin = op->i[1], Win = op->i[2], Hout = op->i[3], Wout = op->i[4], mode = op->i[5];
   const int u8 = op->i[6];  // 1: uint8 in and out, 0: fp32

@@ -15,7 +15,6 @@
 void* g_zero_page = nullptr;
 void* g_splitk_ws = nullptr;
 thread_local bool g_dry_run = false;
-int g_igemm_gen = 2;
 static thread_local char g_err[512] = "";
 static std::mutex g_init_mutex;
 static int g_device = -1;
@@ -44,9 +43,6 @@ static int dispatch(const mg_op* op, hipStream_t s) {
     case MG_OP_FLASH_ATTN64:
     case MG_OP_SOFTMAX_ROWS:
     case MG_OP_SOFTMAX_PAIRS: return mg_launch_attention(op, s);
-    case MG_OP_CONV_CIN_SMALL:
-    case MG_OP_CONV_COUT_SMALL:
-    case MG_OP_CONCAT_C:
     case MG_OP_SCHED_STEP:
     case MG_OP_LINEAR_SMALL_M:
     case MG_OP_LATENT_1X1:
@@ -58,7 +54,8 @@ static int dispatch(const mg_op* op, hipStream_t s) {
     case MG_OP_ENS_DEPTH_MEDIAN:
     case MG_OP_ENS_DEPTH_NORM:
     case MG_OP_ENS_NORMALS: return mg_launch_ensemble(op, s);
-    case MG_OP_RESIZE: return mg_launch_resize(op, s);
+    case MG_OP_RESIZE:
+    case MG_OP_COLORIZE: return mg_launch_resize(op, s);
     default: mg_set_error("mg_launch: unknown op kind %d", op->kind); return 2;
   }
 }
@@ -67,17 +64,7 @@ extern "C" {
 
 int mg_abi_version(void) { return MG_ABI_VERSION; }
 
-// GEMM kernel generation in force (2 unless MARIGOLD_IGEMM_GEN=1) and the GEGLU weight-row
-// interleave it expects (the host packs ff.net.0.proj accordingly).
-static void read_gen_env() {
-  static bool done = false;
-  if (done) return;
-  done = true;
-  const char* e = getenv("MARIGOLD_IGEMM_GEN");
-  if (e && e[0] == '1') g_igemm_gen = 1;
-}
-int mg_igemm_generation(void) { read_gen_env(); return g_igemm_gen; }
-int mg_geglu_interleave(void) { read_gen_env(); return g_igemm_gen == 1 ? 16 : 32; }
+int mg_geglu_interleave(void) { return 32; }
 const char* mg_last_error(void) { return g_err; }
 
 int mg_init(int device) {

@@ -99,9 +99,6 @@ class WeightStore:
     def f32mat(self, name):
         return self._memo(("fm", name), lambda: Wm.f32(self.sd[f"{name}.weight"].reshape(self.sd[f"{name}.weight"].shape[0], -1), self.device))
 
-    def small_conv(self, name):
-        return self._memo(("sc", name), lambda: Wm.f32(Wm.pack_small_conv(self.sd[f"{name}.weight"]), self.device))
-
     def small_conv_mfma(self, key, w4, bias):
         """Cout <= 16 conv3x3 as an MFMA GEMM: weights [Cout,Cin,3,3] -> bf16 [8|16][9*Cin] (rows >= Cout
         zero), bias fp32 [8|16]."""
@@ -288,7 +285,7 @@ class Builder:
         self.free(col)
         return out
 
-    def conv_to_nchw(self, x, key, w4, bias, out, cout, post=L.POST_NONE, scale=1.0):
+    def conv_to_nchw(self, x, key, w4, bias, out, cout, post=L.POST_NONE, scale=1.0, sched=None):
         """conv3x3 (pad 1) bf16 NHWC -> <= 4 fp32 NCHW channels on the MFMA path: GEMM into a padded
         fp32 [M][8] buffer, then the pointwise tail (MG_OP_POST_NCHW)."""
         w8, b8 = self.ws.small_conv_mfma(key, w4, bias)
@@ -296,7 +293,12 @@ class Builder:
         tmp = self.raw(x.M * npad * 4)
         self.add(O.igemm(x.t, w8, tmp, B=x.B, H=x.H, W=x.W, Cin=x.C, Ho=x.H, Wo=x.W, N=npad, taps=9, stride=1,
                          pad=1, bias=b8, epi=L.EPI_F32, ldo=npad, n_alg=cout), f"{key}")
-        self.add(O.post_nchw(tmp, out, B=x.B, HW=x.HW, Cout=cout, ldi=npad, post=post, scale=scale), f"{key}.post")
+        if sched is not None:   # (cx, cm, cn, noise): the scheduler update replaces the store of the model output
+            cx, cm, cn, nz = sched
+            self.add(O.post_nchw(tmp, out, B=x.B, HW=x.HW, Cout=cout, ldi=npad, post=L.POST_SCHED, scale=scale, noise=nz,
+                                 cx=cx, cm=cm, cn=cn), f"{key}.post+scheduler.step")
+        else:
+            self.add(O.post_nchw(tmp, out, B=x.B, HW=x.HW, Cout=cout, ldi=npad, post=post, scale=scale), f"{key}.post")
         self.free(tmp)
 
     def dense(self, x, wt, bias, N, *, residual=None, out=None, epi=L.EPI_BF16, label="", K=None, out_dtype_bytes=2,
@@ -412,18 +414,19 @@ class Builder:
         g = self.group_norm(x, f"{name}.group_norm", 1e-6, False)
         wqkv, bqkv = self.ws.qkv(name, True)
         ldp = (T + 63) // 64 * 64
-        qk = self.raw(M * 2 * C * 2)
+        Tn = (T + 7) // 8 * 8           # score columns in whole 8-column store groups: the K rows past the last image's
+        qk = self.raw((M + 8) * 2 * C * 2)   # tokens are slack rows, their columns are never read by the softmax
         vt = self.zeros_persistent(("vvt", B, C, ldp), B * C * ldp * 2)
         self.add(O.igemm(g.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, bias=bqkv,
                          out2=vt, trans_from=2 * C, ldt=ldp), f"{name}.qkv")
         self.free(g)
-        s = self.raw(B * T * T * 4)
-        self.add(O.igemm(qk, qk.data_ptr() + C * 2, s, B=1, H=T, W=1, Cin=C, Ho=T, Wo=1, N=T,
-                         epi=L.EPI_F32, ldo=T, lda=2 * C, ldw=2 * C, batch_z=B,
-                         zstrides=(T * 2 * C, T * 2 * C, T * T, 0), scale=1.0 / math.sqrt(C)), f"{name}.scores")
+        s = self.raw(B * T * ldp * 4)
+        self.add(O.igemm(qk, qk.data_ptr() + C * 2, s, B=1, H=T, W=1, Cin=C, Ho=T, Wo=1, N=Tn,
+                         epi=L.EPI_F32, ldo=ldp, lda=2 * C, ldw=2 * C, batch_z=B, n_alg=T,
+                         zstrides=(T * 2 * C, T * 2 * C, T * ldp, 0), scale=1.0 / math.sqrt(C)), f"{name}.scores")
         self.free(qk)
         p = self.raw(B * T * ldp * 2)
-        self.add(O.softmax_rows(s, p, R=B * T, ncols=T, lds=T, ldp=ldp), f"{name}.softmax")
+        self.add(O.softmax_rows(s, p, R=B * T, ncols=T, lds=ldp, ldp=ldp), f"{name}.softmax")
         self.free(s)
         o = self.new(x.B, x.H, x.W, C)
         self.add(O.igemm(p, vt, o.t, B=1, H=T, W=1, Cin=ldp, Ho=T, Wo=1, N=C, lda=ldp, ldw=ldp, batch_z=B,
@@ -482,9 +485,10 @@ def emit_time_embeddings(bld, cfg, timesteps):
     return table
 
 
-def emit_unet_forward(bld, cfg, ctx, rgb_latent, x_latent, eps_out, temb_table, step, B, h, w):
+def emit_unet_forward(bld, cfg, ctx, rgb_latent, x_latent, eps_out, temb_table, step, B, h, w, sched=None):
     """One UNet forward: eps_out[B,4,h,w] = unet(cat(rgb_latent, x_latent), t_step, ctx).
-    rgb_latent is [1,4,h,w] (shared by all members) or [B,4,h,w]."""
+    rgb_latent is [1,4,h,w] (shared by all members) or [B,4,h,w].  With ``sched`` = (cx, cm, cn, noise) the model
+    output is not stored: the scheduler update x_latent <- cx x_latent + cm out + cn noise is conv_out's tail."""
     ws = bld.ws
     boc = list(cfg.block_out_channels)
     n = len(boc)
@@ -538,7 +542,8 @@ def emit_unet_forward(bld, cfg, ctx, rgb_latent, x_latent, eps_out, temb_table, 
             x = y
     g = bld.group_norm(x, "conv_norm_out", 1e-5, True)
     bld.free(x)
-    bld.conv_to_nchw(g, "conv_out", ws.sd["conv_out.weight"], ws.sd["conv_out.bias"], eps_out, cfg.out_channels)
+    bld.conv_to_nchw(g, "conv_out", ws.sd["conv_out.weight"], ws.sd["conv_out.bias"], x_latent if sched else eps_out,
+                     cfg.out_channels, sched=sched)
     bld.free(g)
 
 

@@ -39,7 +39,18 @@ _SCRATCH_BYTES = 12288
 _FD_STEP = 1.4901161193847656e-08   # scipy's forward-difference step (sqrt(eps)), absolute
 
 
+MAX_ENSEMBLE_SIZE = 32   # members the per-pixel selection kernels keep in registers (csrc/ensemble.hip EMAX)
+
+
+def _check_members(E):
+    """The reference accepts any ensemble size (it warns above 15, marigold_depth_pipeline.py:236-240); the device
+    kernels hold one value per member in registers and stop at 32 - refused here by name instead of by a launch error."""
+    if E > MAX_ENSEMBLE_SIZE:
+        raise ValueError(f"ensemble_size {E} exceeds the {MAX_ENSEMBLE_SIZE} members the HIP ensembling kernels support")
+
+
 def _check_depth_args(depth, reduction, scale_invariant, shift_invariant):
+    _check_members(depth.shape[0])
     if depth.dim() != 4 or depth.shape[1] != 1:
         raise ValueError(f"Expecting 4D tensor of shape [B,1,H,W]; got {depth.shape}.")
     if reduction not in ("mean", "median"):
@@ -222,6 +233,7 @@ def ensemble_normals(normals, output_uncertainty=False, reduction="closest"):
     if reduction not in ("closest", "mean"):
         raise ValueError(f"Unrecognized reduction method: {reduction}.")
     E, _, H, W = normals.shape
+    _check_members(E)
     n = normals.to(torch.float32).contiguous()
     out = torch.empty(3, H * W, dtype=torch.float32, device=n.device)
     unc = torch.empty(H * W, dtype=torch.float32, device=n.device) if output_uncertainty else None
@@ -237,6 +249,7 @@ def ensemble_iid(targets, output_uncertainty=False, reduction="median"):
     if reduction not in ("median", "mean"):
         raise ValueError(f"Unrecognized reduction method: {reduction}.")
     E = targets.shape[0]
+    _check_members(E)
     n = targets[0].numel()
     t = targets.to(torch.float32).contiguous()
     dev = t.device

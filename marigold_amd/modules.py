@@ -129,15 +129,16 @@ class UNet2DConditionModelHIP(_EngineModule):
         n_fwd = 0
         for i in range(len(timesteps)):
             n0 = len(seq)
-            E.emit_unet_forward(bld, self.config, self._ctx, rgb_latent, x, eps, table, i, B, h, w)
-            n_fwd = len(seq) - n0
-            if with_scheduler:
+            sched = None
+            if with_scheduler:   # the scheduler update (reference :466-468) is the tail of conv_out's pointwise pass
                 cx, cm, cn = scheduler.step_coefficients(i)
                 nz = None
                 if scheduler.needs_noise(i):
                     nz = seq.hold(torch.zeros(B, self.config.out_channels, h, w, device=dev))
                     noises.append(nz)
-                seq.add(O.sched_step(x, eps, nz, x, n=x.numel(), cx=cx, cm=cm, cn=cn), f"scheduler.step[{i}]")
+                sched = (cx, cm, cn, nz)
+            E.emit_unet_forward(bld, self.config, self._ctx, rgb_latent, x, eps, table, i, B, h, w, sched=sched)
+            n_fwd = len(seq) - n0
         seq.keep.extend(bld.persist.values())
         prog = DenoiseProgram(seq, rgb_latent, x, eps, noises, n_fwd, n_pro)
         self._programs[key] = prog

@@ -96,19 +96,6 @@ def softmax_pairs(s, p, *, M, pairs, lds, ldp, scale):
     return make_op(L.OP_SOFTMAX_PAIRS, i=[M, pairs, lds, ldp], f=[scale], p=[s, p])
 
 
-def conv_cin_small(src0, src1, w, bias, out, *, B, H, W, C0, C1, Cout, bcast0=False):
-    return make_op(L.OP_CONV_CIN_SMALL, i=[B, H, W, C0, C1, Cout, int(bcast0)],
-                   p=[src0, src1, w, bias, out])
-
-
-def conv_cout_small(x, w, bias, out, *, B, H, W, Cin, Cout, post=L.POST_NONE, scale=1.0):
-    return make_op(L.OP_CONV_COUT_SMALL, i=[B, H, W, Cin, Cout, post], f=[scale], p=[x, w, bias, out])
-
-
-def concat_c(a, b, out, *, M, C1, C2):
-    return make_op(L.OP_CONCAT_C, i=[M, C1, C2], p=[a, b, out])
-
-
 def sched_step(x, model_out, noise, out, *, n, cx, cm, cn=0.0):
     return make_op(L.OP_SCHED_STEP, f=[cx, cm, cn], p=[x, model_out, noise, out], l=[n])
 
@@ -125,8 +112,8 @@ def im2col_small(src0, src1, out, *, B, H, W, C0, C1, Kp, bcast0=False):
     return make_op(L.OP_IM2COL_SMALL, i=[B, H, W, C0, C1, Kp, int(bcast0)], p=[src0, src1, out])
 
 
-def post_nchw(x, out, *, B, HW, Cout, ldi, post=L.POST_NONE, scale=1.0):
-    return make_op(L.OP_POST_NCHW, i=[B, HW, Cout, ldi, post], f=[scale], p=[x, out])
+def post_nchw(x, out, *, B, HW, Cout, ldi, post=L.POST_NONE, scale=1.0, noise=None, cx=0.0, cm=0.0, cn=0.0):
+    return make_op(L.OP_POST_NCHW, i=[B, HW, Cout, ldi, post], f=[scale, cx, cm, cn], p=[x, out, noise])
 
 
 def ens_depth_stats(d, scratch, out, *, E, HW):
@@ -148,6 +135,10 @@ def ens_normals(n, out, unc, *, E, HW, reduction=0):
 
 def resize(src, dst, tmp, *, planes, Hin, Win, Hout, Wout, mode, u8):
     return make_op(L.OP_RESIZE, i=[planes, Hin, Win, Hout, Wout, mode, int(u8)], p=[src, dst, tmp])
+
+
+def colorize(depth, lut, out, *, n, lo=0.0, hi=1.0):
+    return make_op(L.OP_COLORIZE, f=[lo, hi], p=[depth, lut, out], l=[n])
 
 
 def memset(dst, nbytes, value=0):

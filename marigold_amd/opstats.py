@@ -12,10 +12,9 @@ CLASS = {
     L.OP_IGEMM: "igemm_mfma", L.OP_CONV3X3: "conv3x3_patch", L.OP_FLASH_ATTN64: "flash_attn64", L.OP_GN_STATS: "groupnorm",
     L.OP_GN_FINALIZE: "groupnorm", L.OP_GN_APPLY: "groupnorm", L.OP_LAYERNORM: "layernorm",
     L.OP_SOFTMAX_ROWS: "softmax", L.OP_SOFTMAX_PAIRS: "softmax",
-    L.OP_CONV_CIN_SMALL: "boundary_conv", L.OP_CONV_COUT_SMALL: "boundary_conv",
-    L.OP_CONCAT_C: "concat", L.OP_SCHED_STEP: "scheduler_step", L.OP_LINEAR_SMALL_M: "time_embedding",
+    L.OP_SCHED_STEP: "scheduler_step", L.OP_LINEAR_SMALL_M: "time_embedding",
     L.OP_LATENT_1X1: "boundary_conv", L.OP_POST_NCHW: "boundary_conv", L.OP_IM2COL_SMALL: "boundary_conv", L.OP_ENS_DEPTH_STATS: "ensemble", L.OP_ENS_DEPTH_MEDIAN: "ensemble",
-    L.OP_ENS_DEPTH_NORM: "ensemble", L.OP_ENS_NORMALS: "ensemble", L.OP_RESIZE: "resize", L.OP_MEMSET: "memops", L.OP_COPY: "memops",
+    L.OP_ENS_DEPTH_NORM: "ensemble", L.OP_ENS_NORMALS: "ensemble", L.OP_RESIZE: "resize", L.OP_COLORIZE: "resize", L.OP_MEMSET: "memops", L.OP_COPY: "memops",
 }
 BOUND = {"igemm_mfma": "mfma", "conv3x3_patch": "mfma", "flash_attn64": "mfma"}   # everything else is HBM-bound streaming
 
@@ -59,16 +58,6 @@ def op_cost(op):
         byts = i[0] * i[1] * 4 + i[0] * i[3] * 2
     elif k == L.OP_SOFTMAX_PAIRS:
         byts = i[0] * i[2] * 4 + i[0] * i[3] * 2
-    elif k == L.OP_CONV_CIN_SMALL:
-        B, H, W, C0, C1, Cout = (i[j] for j in range(6))
-        flops = 2 * B * H * W * 9 * (C0 + C1) * Cout
-        byts = B * H * W * ((C0 + C1) * 4 + Cout * 2)
-    elif k == L.OP_CONV_COUT_SMALL:
-        B, H, W, Cin, Cout = (i[j] for j in range(5))
-        flops = 2 * B * H * W * 9 * Cin * Cout
-        byts = B * H * W * (Cin * 2 + Cout * 4)
-    elif k == L.OP_CONCAT_C:
-        byts = 2 * i[0] * (i[1] + i[2]) * 2
     elif k == L.OP_SCHED_STEP:
         byts = (4 if op.p[2] else 3) * l[0] * 4
     elif k == L.OP_LINEAR_SMALL_M:
@@ -80,6 +69,8 @@ def op_cost(op):
         byts = i[0] * i[1] * i[2] * ((i[3] + i[4]) * 4 + i[5] * 2)
     elif k == L.OP_POST_NCHW:
         byts = i[0] * i[1] * (i[3] + (1 if i[4] == L.POST_DEPTH else i[2])) * 4
+        if i[4] == L.POST_SCHED:   # reads x_t (and the LCM noise) as well
+            byts += i[0] * i[1] * i[2] * 4 * (2 if op.p[2] else 1)
     elif k in (L.OP_ENS_DEPTH_STATS, L.OP_ENS_DEPTH_MEDIAN):
         byts = i[0] * l[0] * 4
     elif k == L.OP_ENS_DEPTH_NORM:

@@ -25,7 +25,7 @@ from .ensemble import ensemble_depth, ensemble_iid, ensemble_normals
 from .modules import AutoencoderKLHIP, UNet2DConditionModelHIP
 from .schedulers import DDIMScheduler, LCMScheduler
 from .util.batchsize import find_batch_size
-from .util.image_util import (chw2hwc, colorize_depth_maps, get_tv_resample_method, pil_to_tensor,
+from .util.image_util import (chw2hwc, colorize_depth_device, colorize_depth_maps, get_tv_resample_method, pil_to_tensor,
                               resize, resize_max_res)
 
 
@@ -79,7 +79,13 @@ class _MarigoldPipelineBase:
 
     @property
     def dtype(self):
+        """Compute dtype of the engine (bf16 operands, fp32 accumulation)."""
         return self.unet.dtype
+
+    # Tensors at the pipeline boundary - the normalised image, the initial latents, the LCM per-step noise, the
+    # predictions - are fp32 like the reference's default pipeline (script/depth/run.py:203-215 loads fp32 unless
+    # --fp16); the engine's boundary convolutions convert them on the fly, so nothing is rounded to bf16 on the way in.
+    io_dtype = torch.float32
 
     def to(self, device):
         self.unet.to(device)
@@ -144,7 +150,8 @@ class _MarigoldPipelineBase:
     @torch.no_grad()
     def single_infer(self, rgb_in: torch.Tensor, num_inference_steps: int,
                      generator: Union[torch.Generator, None], show_pbar: bool = False,
-                     init_latents: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     init_latents: Optional[torch.Tensor] = None,
+                     step_noises: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One batched prediction (reference :396-477).  rgb_in [B,3,h,w] in [-1,1]; identical
         (expanded) rows are encoded once."""
         device = self.device
@@ -154,7 +161,7 @@ class _MarigoldPipelineBase:
         rgb_latent = self.encode_rgb(rgb_in)                       # [1|B,4,h,w] fp32
         h, w = rgb_latent.shape[-2:]
         if init_latents is None:
-            target_latent = torch.randn((B, self._target_latent_channels, h, w), device=device, dtype=self.dtype,
+            target_latent = torch.randn((B, self._target_latent_channels, h, w), device=device, dtype=self.io_dtype,
                                         generator=generator)
         else:
             target_latent = init_latents.to(device)
@@ -165,8 +172,11 @@ class _MarigoldPipelineBase:
                                          rgb_broadcast=shared)
         prog.rgb_latent.copy_(rgb_latent)
         prog.x.copy_(target_latent)
-        for nz in prog.noises:  # LCM consumes the generator once per non-final step (:466-468)
-            nz.copy_(torch.randn(nz.shape, device=device, dtype=self.dtype, generator=generator))
+        for k, nz in enumerate(prog.noises):  # LCM consumes the generator once per non-final step (:466-468)
+            if step_noises is not None:
+                nz.copy_(step_noises[k])
+            else:
+                nz.copy_(torch.randn(nz.shape, device=device, dtype=self.io_dtype, generator=generator))
         prog.run()
         return self._decode(prog.x)
 
@@ -177,13 +187,22 @@ class _MarigoldPipelineBase:
             ensemble_size=ensemble_size, input_res=max(rgb_norm.shape[1:]), dtype=self.dtype)
         E = ensemble_size
         members = list(range(E))
+        step_noises_all = None
         if self._member_parallel and mdist.world_size(self._member_group) > 1:
             # every rank draws the full [E,4,h,w] noise (same generator state) and keeps its slice,
             # so results do not depend on the number of GPUs
             if init_latents is None:
                 hh, ww = self._latent_hw(rgb_norm.shape[-2:])
-                init_latents = torch.randn((E, self._target_latent_channels, hh, ww), device=self.device, dtype=self.dtype,
+                init_latents = torch.randn((E, self._target_latent_channels, hh, ww), device=self.device, dtype=self.io_dtype,
                                            generator=generator)
+            # the LCM scheduler consumes the generator once per non-final step (:466-468): those draws are made for
+            # all E members on every rank too, in the order a single process holding the E members in one batch makes
+            # them (initial latents, then one [E,...] draw per step), and sliced by member
+            self.scheduler.set_timesteps(denoising_steps)
+            n_noise = sum(bool(self.scheduler.needs_noise(i)) for i in range(denoising_steps))
+            if n_noise:
+                step_noises_all = [torch.randn(tuple(init_latents.shape), device=self.device, dtype=self.io_dtype,
+                                               generator=generator) for _ in range(n_noise)]
             members = mdist.shard_members(E, mdist.world_size(self._member_group),
                                           mdist.rank(self._member_group))
         preds = []
@@ -191,7 +210,8 @@ class _MarigoldPipelineBase:
             idx = members[i:i + _bs]
             lat = None if init_latents is None else init_latents[idx]
             rgb = rgb_norm.expand(len(idx), -1, -1, -1)
-            preds.append(self.single_infer(rgb, denoising_steps, generator, False, lat))
+            nzs = None if step_noises_all is None else [nz[idx] for nz in step_noises_all]
+            preds.append(self.single_infer(rgb, denoising_steps, generator, False, lat, step_noises=nzs))
         local = torch.cat(preds, dim=0) if preds else None
         if self._member_parallel and mdist.world_size(self._member_group) > 1:
             C = self._pred_channels
@@ -225,7 +245,7 @@ class _MarigoldPipelineBase:
                 rgb = rgb.to(self.device)   # resample on the device (csrc/resize.hip)
             rgb = resize_max_res(rgb, max_edge_resolution=processing_res, resample_method=resample_method)
         rgb_norm = rgb / 255.0 * 2.0 - 1.0
-        rgb_norm = rgb_norm.to(self.dtype)
+        rgb_norm = rgb_norm.to(self.io_dtype)
         assert rgb_norm.min() >= -1.0 and rgb_norm.max() <= 1.0
         return rgb_norm, input_size
 
@@ -279,11 +299,17 @@ class MarigoldDepthPipeline(_MarigoldPipelineBase):
             final_pred, pred_uncert = target_preds, None
         if match_input_res:
             final_pred = resize(final_pred, input_size[-2:], interpolation=resample, antialias=True)
+        colored_dev = None
+        if color_map is not None and final_pred.is_cuda:
+            # colour table look-up on the device (clip(0, 1) is part of the kernel); the host gets a uint8 HWC image
+            colored_dev = colorize_depth_device(final_pred.squeeze().float(), 0.0, 1.0, cmap=color_map)
         final_pred = final_pred.squeeze().cpu().numpy()
         if pred_uncert is not None:
             pred_uncert = pred_uncert.squeeze().cpu().numpy()
         final_pred = final_pred.clip(0, 1)
-        if color_map is not None:
+        if colored_dev is not None:
+            depth_colored_img = Image.fromarray(colored_dev.cpu().numpy())
+        elif color_map is not None:
             colored = colorize_depth_maps(final_pred, 0, 1, cmap=color_map).squeeze()
             colored = (colored * 255).astype(np.uint8)
             depth_colored_img = Image.fromarray(chw2hwc(colored))

@@ -108,6 +108,32 @@ def colorize_depth_maps(depth_map, min_depth, max_depth, cmap="Spectral", valid_
     return img
 
 
+_LUT_CACHE = {}
+
+
+def colormap_lut_u8(cmap):
+    """matplotlib's 256-entry table of ``cmap`` as the uint8 RGB values the reference ends up with:
+    (cm(k / 256 + eps)[:3] * 255).astype(uint8) for table entry k."""
+    import matplotlib
+    cm = matplotlib.colormaps[cmap]
+    idx = (np.arange(256, dtype=np.float64) + 0.5) / 256.0          # x with int(x * 256) == k
+    return (cm(idx, bytes=False)[:, 0:3] * 255).astype(np.uint8)
+
+
+def colorize_depth_device(depth: torch.Tensor, min_depth=0.0, max_depth=1.0, cmap="Spectral") -> torch.Tensor:
+    """Device form of ``(colorize_depth_maps(depth, lo, hi, cmap) * 255).astype(uint8)`` in HWC order: fp32 CUDA map
+    [H, W] -> uint8 CUDA image [H, W, 3] (csrc/resize.hip, MG_OP_COLORIZE: one table look-up pass)."""
+    from .. import ops as O
+    assert depth.is_cuda and depth.dtype == torch.float32 and depth.dim() == 2
+    key = (cmap, depth.device)
+    if key not in _LUT_CACHE:
+        _LUT_CACHE[key] = torch.from_numpy(colormap_lut_u8(cmap)).to(depth.device).contiguous()
+    d = depth.contiguous()
+    out = torch.empty(d.shape + (3,), dtype=torch.uint8, device=d.device)
+    O.launch(O.colorize(d, _LUT_CACHE[key], out, n=d.numel(), lo=min_depth, hi=max_depth))
+    return out
+
+
 def chw2hwc(chw):
     assert 3 == len(chw.shape)
     if isinstance(chw, torch.Tensor):

@@ -4,8 +4,7 @@ diffusers state-dict tensors (``arch.py`` key scheme) are re-laid for the HIP ke
   * conv3x3 [Cout,Cin,3,3] -> bf16 [Cout][(ky*3+kx)*Cin + c]   (K-contiguous rows for igemm)
   * Linear / conv1x1        -> bf16 [N][K]
   * GEGLU proj [8C, C]      -> rows interleaved in 32-row groups (16 "u" rows then their 16 gate
-                               rows; 16/8+8 for the generation-1 kernel) so the GEMM epilogue
-                               forms u*gelu(g) in registers
+                               rows) so the GEMM epilogue forms u*gelu(g) in registers
   * cross-attention against the constant 2-token empty-prompt embedding
     (marigold_depth_pipeline.py:381-394) -> Wqk [64-padded 2*heads][C], VO^T [C][64]
   * fused Q|K|V projection  -> [3C][C]
@@ -53,24 +52,16 @@ def pack_conv1x1(w):
     return w.reshape(w.shape[0], w.shape[1]).contiguous()
 
 
-def pack_small_conv(w):
-    """[Cout,Cin,3,3] -> fp32 [Cout][9][Cin] for the direct small-channel conv kernels."""
-    co, ci = w.shape[:2]
-    return w.permute(0, 2, 3, 1).reshape(co, 9, ci).contiguous().float()
-
-
 def pack_geglu(w, b, group=None):
     """proj [8C, C] (rows 0..4C-1 = u, 4C..8C-1 = gate) -> rows interleaved in groups of ``group``:
-    group/2 consecutive u rows followed by their group/2 gate rows.  ``group`` is what the GEMM
-    kernel generation in force expects (32 for generation 2, 16 for generation 1); by default it
-    is asked from the library (mg_geglu_interleave)."""
+    group/2 consecutive u rows followed by their group/2 gate rows.  ``group`` = 32 is what the GEMM
+    epilogue expects (mg_geglu_interleave)."""
     if group is None:
-        from . import _lib as L
-        group = L.load().mg_geglu_interleave()
+        group = 32
     n2 = w.shape[0]
     h = n2 // 2
     g2 = group // 2
-    assert group in (16, 32) and h % g2 == 0
+    assert group == 32 and h % g2 == 0
     idx = torch.arange(n2)
     blk, within = idx // group, idx % group
     src = torch.where(within < g2, blk * g2 + within, h + blk * g2 + (within - g2))

@@ -122,7 +122,7 @@ def _rel(got, ref):
 def _stepwise(prog, n_steps, trace, name):
     """Replay a denoising program one step at a time and report the latent error after every step."""
     seq = prog.seq
-    per_step = prog.n_fwd_ops + 1
+    per_step = prog.n_fwd_ops       # the scheduler update is the tail of conv_out's pointwise pass
     seq.run_range(0, prog.n_prologue_ops)
     errs = []
     for i in range(n_steps):

@@ -50,20 +50,13 @@ def _run(op):
 # --------------------------------------------------------------------------- igemm: conv
 CONV_CASES = [
     # name, B, H, W, Cin, Cout, stride, pad, up, variant
-    ("v1_basic", 2, 12, 20, 64, 128, 1, 1, None, 1),
-    ("v2_basic", 2, 16, 24, 128, 128, 1, 1, None, 2),
-    ("v3_basic", 1, 9, 7, 64, 64, 1, 1, None, 3),
-    ("v4_basic", 2, 12, 20, 64, 192, 1, 1, None, 4),
-    ("v11_regstaged", 2, 12, 20, 64, 128, 1, 1, None, 11),
-    ("v13_regstaged", 1, 9, 7, 64, 64, 1, 1, None, 13),
-    ("n_edge_320", 1, 12, 12, 320, 320, 1, 1, None, 1),
     ("stride2_pad1", 2, 16, 16, 64, 64, 2, 1, None, 0),
     ("stride2_pad0_asym", 1, 16, 24, 128, 128, 2, 0, None, 0),
-    ("stride2_odd", 1, 15, 11, 64, 64, 2, 1, None, 3),
+    ("stride2_odd", 1, 15, 11, 64, 64, 2, 1, None, 23),
     ("up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 0),
     ("up_to_size", 1, 4, 6, 64, 64, 1, 1, (7, 11), 0),
     ("auto_big", 4, 32, 32, 192, 256, 1, 1, None, 0),
-    # generation-2 kernel (LDS ring + counted vmcnt + 16-byte epilogue), every tile variant
+    # every tile variant of the implicit-GEMM kernel (LDS ring + counted vmcnt + 16-byte epilogue)
     ("g2_256x128x3", 2, 16, 24, 128, 128, 1, 1, None, 20),
     ("g2_128x128x2", 2, 12, 20, 64, 128, 1, 1, None, 21),
     ("g2_128x128w8", 2, 12, 20, 64, 192, 1, 1, None, 22),
@@ -213,14 +206,6 @@ def _ref_fused_conv(x, w, bias, ss, silu, temb, res, up2=False):
 
 PATCH_CASES = [
     # name, B, H, W, C0, C1, N, fused-norm, silu, temb, residual, variant
-    ("v1_plain", 2, 16, 16, 64, 0, 256, False, False, False, False, 1),
-    ("v1_edges_fused", 2, 20, 37, 128, 0, 256, True, True, True, True, 1),
-    ("v1_two_source_fused", 1, 32, 48, 128, 64, 512, True, True, True, False, 1),
-    ("v2_plain_n128", 2, 24, 16, 192, 0, 128, False, False, False, True, 2),
-    ("v2_fused_nedge", 1, 17, 33, 64, 64, 192, True, False, True, True, 2),
-    ("v4_fused_2stage", 1, 16, 32, 128, 0, 128, True, True, False, False, 4),
-    ("v3_n320", 2, 24, 32, 320, 0, 320, True, True, True, True, 3),
-    ("v3_two_source_n640", 1, 9, 21, 320, 320, 640, True, True, False, True, 3),
     ("v5_small", 1, 8, 16, 64, 0, 128, True, True, False, False, 5),
     ("auto_n640", 1, 16, 16, 64, 0, 640, False, False, False, False, 0),
     ("deep_k_fused", 1, 16, 16, 1280, 640, 256, True, True, True, True, 1),
@@ -361,7 +346,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = torch.randn(N, generator=g) * 0.1
     ref = x @ w.t() + b
-    for variant in (0, 1, 2, 3, 4, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 46, 50, 51, 52, 53, 60, 61, 62, 63):
+    for variant in (0, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 46, 50, 51, 52, 53, 60, 61, 62, 63):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N,
                         bias=b.to(dev), variant=variant))
@@ -373,7 +358,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     xg = _bf(torch.randn(200, C, generator=g))
     u, gt = (xg @ wg.t() + bg).chunk(2, dim=-1)
     ref = u * F.gelu(gt)
-    for group, variants in ((16, (1, 3)), (32, (20, 23, 24, 27, 34, 53, 60, 62, 0))):
+    for group, variants in ((32, (20, 23, 24, 27, 34, 53, 60, 62, 0)),):
         wp, bp = Wm.pack_geglu(wg, bg, group)
         for variant in variants:
             out = torch.full((200, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
@@ -390,7 +375,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     qk = torch.full((B * T, 3 * C), float("nan"), device=dev, dtype=torch.bfloat16)
     vt = torch.zeros((B, C, ldt), device=dev, dtype=torch.bfloat16)
     refv = refq[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1)
-    for variant in (1, 0, 20, 23, 27, 60, 62):
+    for variant in (0, 20, 23, 27, 60, 62):
         qk.fill_(float("nan"))
         vt.zero_()
         _run(ops.igemm(xq.to(dev, torch.bfloat16), wqkv.to(dev, torch.bfloat16), qk, B=B, H=T, W=1, Cin=C,
@@ -398,7 +383,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
         _close(f"qkv/qk/v{variant}", qk[:, :2 * C], refq[:, :2 * C])
         _close(f"qkv/vt/v{variant}", vt[:, :, :T], refv)
         assert (vt[:, :, T:] == 0).all()
-    # token count not a multiple of 8 (scalar transposed tail) through the generation-2 kernel
+    # token count not a multiple of 8 (scalar transposed tail)
     T2 = 36
     xq2 = xq[:B * T2]
     vt2 = torch.zeros((B, C, 64), device=dev, dtype=torch.bfloat16)
@@ -412,7 +397,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     refS = torch.einsum("ztd,zsd->zts", qkv[..., :D], qkv[..., D:2 * D]) * 0.25
     qd = qkv.to(dev, torch.bfloat16)
     S = torch.full((Z, T, T), float("nan"), device=dev, dtype=torch.float32)
-    for variant in (1, 0, 20, 27, 60):
+    for variant in (0, 20, 27, 60):
         S.fill_(float("nan"))
         _run(ops.igemm(qd, qd[:, :, D:], S, B=1, H=T, W=1, Cin=D, Ho=T, Wo=1, N=T, epi=L.EPI_F32, ldo=T,
                        lda=3 * D, ldw=3 * D, batch_z=Z, zstrides=(T * 3 * D, T * 3 * D, T * T, 0),
@@ -556,66 +541,22 @@ def test_softmax_rows_and_pairs(dev):
     assert (p2[:, 2 * pairs:] == 0).all()
 
 
-# --------------------------------------------------------------------------- boundary convs etc.
-def test_conv_cin_small(dev):
-    from marigold_amd import ops, weights as Wm
-    g = torch.Generator().manual_seed(2)
-    B, H, W, Cout = 3, 10, 14, 64
-    rgb_lat = torch.randn(1, 4, H, W, generator=g)
-    tgt = torch.randn(B, 4, H, W, generator=g)
-    w = torch.randn(Cout, 8, 3, 3, generator=g) / math.sqrt(72)
-    b = torch.randn(Cout, generator=g) * 0.1
-    ref = F.conv2d(torch.cat([rgb_lat.expand(B, -1, -1, -1), tgt], 1), w, b, padding=1)
-    out = torch.full((B, H, W, Cout), float("nan"), device=dev, dtype=torch.bfloat16)
-    _run(ops.conv_cin_small(rgb_lat.to(dev), tgt.to(dev), Wm.pack_small_conv(w).to(dev), b.to(dev), out,
-                            B=B, H=H, W=W, C0=4, C1=4, Cout=Cout, bcast0=True))
-    _close("conv_cin_small/8ch", out.float().permute(0, 3, 1, 2), ref, tol=6e-3)
-    img = torch.rand(2, 3, 12, 9, generator=g) * 2 - 1
-    w3 = torch.randn(128, 3, 3, 3, generator=g) / math.sqrt(27)
-    b3 = torch.randn(128, generator=g) * 0.1
-    out3 = torch.full((2, 12, 9, 128), float("nan"), device=dev, dtype=torch.bfloat16)
-    _run(ops.conv_cin_small(img.to(dev), None, Wm.pack_small_conv(w3).to(dev), b3.to(dev), out3,
-                            B=2, H=12, W=9, C0=3, C1=0, Cout=128))
-    _close("conv_cin_small/3ch", out3.float().permute(0, 3, 1, 2), F.conv2d(img, w3, b3, padding=1), tol=6e-3)
-
-
-def test_conv_cout_small(dev):
-    from marigold_amd import _lib as L, ops, weights as Wm
-    g = torch.Generator().manual_seed(4)
-    B, H, W, Cin = 2, 11, 13, 128
-    x = _bf(torch.randn(B, Cin, H, W, generator=g))
-    xd = _nhwc(x).to(dev, torch.bfloat16)
-    for cout, post in ((3, L.POST_NONE), (3, L.POST_DEPTH), (3, L.POST_NORMALS), (4, L.POST_NONE)):
-        w = torch.randn(cout, Cin, 3, 3, generator=g) * (3.0 / math.sqrt(9 * Cin))
-        b = torch.randn(cout, generator=g) * 0.1
-        y = F.conv2d(x, w, b, padding=1)
-        if post == L.POST_DEPTH:
-            ref = (torch.clip(y.mean(1, keepdim=True), -1, 1) + 1) / 2
-        elif post == L.POST_NORMALS:
-            y = torch.clip(y, -1, 1)
-            ref = y / torch.norm(y, dim=1, keepdim=True).clamp(min=1e-6)
-        else:
-            ref = y
-        out = torch.full(tuple(ref.shape), float("nan"), device=dev)
-        _run(ops.conv_cout_small(xd, Wm.pack_small_conv(w).to(dev), b.to(dev), out, B=B, H=H, W=W,
-                                 Cin=Cin, Cout=cout, post=post))
-        _close(f"conv_cout_small/c{cout}p{post}", out, ref, tol=1e-4)
-
-
 def test_small_ops(dev):
     from marigold_amd import ops
     g = torch.Generator().manual_seed(6)
-    a = torch.randn(50, 64, generator=g).to(torch.bfloat16)
-    b = torch.randn(50, 128, generator=g).to(torch.bfloat16)
-    out = torch.empty(50, 192, device=dev, dtype=torch.bfloat16)
-    _run(ops.concat_c(a.to(dev), b.to(dev), out, M=50, C1=64, C2=128))
-    assert torch.equal(out.cpu(), torch.cat([a, b], 1))
     x, m, nz = (torch.randn(3, 4, 8, 8, generator=g) for _ in range(3))
     o = torch.empty(3, 4, 8, 8, device=dev)
     _run(ops.sched_step(x.to(dev), m.to(dev), nz.to(dev), o, n=x.numel(), cx=0.7, cm=-0.3, cn=0.2))
     _close("sched_step", o, 0.7 * x - 0.3 * m + 0.2 * nz, tol=1e-6)
     _run(ops.sched_step(x.to(dev), m.to(dev), None, o, n=x.numel(), cx=0.5, cm=0.25))
     _close("sched_step/no-noise", o, 0.5 * x + 0.25 * m, tol=1e-6)
+    # the same update as the tail of conv_out's pointwise pass (MG_POST_SCHED): in = [B*HW][8] padded GEMM output
+    from marigold_amd import _lib as L
+    tmp = torch.zeros(3 * 64, 8)
+    tmp[:, :4] = m.permute(0, 2, 3, 1).reshape(-1, 4)
+    xd, nzd = x.to(dev).clone(), nz.to(dev)
+    _run(ops.post_nchw(tmp.to(dev), xd, B=3, HW=64, Cout=4, ldi=8, post=L.POST_SCHED, noise=nzd, cx=0.7, cm=-0.3, cn=0.2))
+    _close("post_nchw/scheduler tail", xd, 0.7 * x - 0.3 * m + 0.2 * nz, tol=1e-6)
     xi = torch.randn(5, 320, generator=g)
     w = torch.randn(100, 320, generator=g) / 18
     bb = torch.randn(100, generator=g)
@@ -806,3 +747,16 @@ def test_resize_vs_torch_cpu(dev, mode):
                 assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-3, (shape, size, int(d.max()))
             else:
                 assert float((got - ref).abs().max()) < 2e-5, (shape, size, float((got - ref).abs().max()))
+
+
+@pytest.mark.parametrize("cmap", ["Spectral", "viridis"])
+def test_colorize_lut_matches_reference_chain(dev, cmap):
+    """MG_OP_COLORIZE vs the reference's colorize_depth_maps + (x * 255).astype(uint8) (marigold/util/image_util.py:38-76,
+    marigold_depth_pipeline.py:318-327) restated on matplotlib: bit-exact uint8 image."""
+    from marigold_amd.util import image_util as iu
+    g = torch.Generator().manual_seed(3)
+    d = torch.rand(37, 53, generator=g)
+    d[0, 0], d[0, 1], d[0, 2] = 1.0, 0.0, 1.5    # ends of the table and a value the clip must catch
+    ref = (iu.colorize_depth_maps(d.numpy(), 0, 1, cmap=cmap).squeeze() * 255).astype(np.uint8)   # [3,H,W]
+    got = iu.colorize_depth_device(d.to(dev), 0.0, 1.0, cmap=cmap).cpu().numpy()                  # [H,W,3]
+    assert got.shape == (37, 53, 3) and np.array_equal(np.moveaxis(got, -1, 0), ref)

@@ -66,10 +66,10 @@ def test_scheduler_coefficients_match_oracle_step(kind, kw, n):
         x = ref
 
 
-@pytest.mark.parametrize("group", [16, 32])
+@pytest.mark.parametrize("group", [32])
 def test_geglu_interleave_is_a_permutation_with_paired_rows(group):
     from marigold_amd import _lib as L, weights as Wm
-    assert L.load().mg_geglu_interleave() in (16, 32)
+    assert L.load().mg_geglu_interleave() == 32
     C = 16
     w = torch.arange(8 * C * 3, dtype=torch.float32).reshape(8 * C, 3)
     b = torch.arange(8 * C, dtype=torch.float32)
@@ -201,6 +201,11 @@ def test_ensemble_argument_validation_without_gpu():
         ens.ensemble_normals(torch.rand(3, 2, 8, 8))
     with pytest.raises(ValueError):
         ens.ensemble_normals(torch.rand(3, 3, 8, 8), reduction="median")
+    # the device kernels hold <= 32 members in registers: larger ensembles are refused by name
+    with pytest.raises(ValueError, match="exceeds the 32 members"):
+        ens.ensemble_depth(torch.rand(33, 1, 8, 8), True, True)
+    with pytest.raises(ValueError, match="exceeds the 32 members"):
+        ens.ensemble_normals(torch.rand(40, 3, 8, 8))
 
 
 def _gloo_worker(rank, world, port, E, q):
@@ -433,6 +438,96 @@ def test_from_pretrained_without_checkpoint_fails_clearly():
     import marigold_amd as M
     with pytest.raises(FileNotFoundError, match="neither a local folder nor in the local Hugging Face cache"):
         M.MarigoldDepthPipeline.from_pretrained("prs-eth/marigold-depth-v1-1")
+
+
+def _tiny_checkpoint(tmp_path, with_text_encoder):
+    """A checkpoint folder in the diffusers layout with the tiny architecture and the FULL published config key
+    sets; optionally with a real (tiny, random) CLIP text encoder + tokenizer instead of the precomputed embedding."""
+    import json
+    from marigold_amd import checkpoint as ck, synthetic as syn
+    from marigold_amd.arch import TINY_UNET, TINY_VAE
+    from marigold_amd.schedulers import DDIMScheduler
+    path = str(tmp_path / "ckpt")
+    ck.save_synthetic_checkpoint(path, "MarigoldDepthPipeline", syn.synthetic_unet_state_dict(TINY_UNET),
+                                 syn.synthetic_vae_state_dict(TINY_VAE), TINY_UNET, TINY_VAE, DDIMScheduler(),
+                                 syn.synthetic_text_embedding(TINY_UNET.cross_attention_dim), scale_invariant=True,
+                                 shift_invariant=True, default_denoising_steps=4, default_processing_resolution=768)
+    if with_text_encoder:
+        from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+        os.remove(os.path.join(path, "empty_text_embed.safetensors"))
+        vocab = {"<|startoftext|>": 0, "<|endoftext|>": 1, "a</w>": 2, "b</w>": 3}
+        json.dump(vocab, open(os.path.join(path, "vocab.json"), "w"))
+        open(os.path.join(path, "merges.txt"), "w").write("#version: 0.2\n")
+        tok = CLIPTokenizer(os.path.join(path, "vocab.json"), os.path.join(path, "merges.txt"), model_max_length=77)
+        tok.save_pretrained(os.path.join(path, "tokenizer"))
+        torch.manual_seed(0)
+        cfg = CLIPTextConfig(vocab_size=4, hidden_size=TINY_UNET.cross_attention_dim, intermediate_size=128, num_hidden_layers=2,
+                             num_attention_heads=2, max_position_embeddings=77, bos_token_id=0, eos_token_id=1, pad_token_id=1)
+        CLIPTextModel(cfg).eval().save_pretrained(os.path.join(path, "text_encoder"))
+    return path
+
+
+def test_encode_empty_text_with_a_real_text_encoder(tmp_path):
+    """A9 (marigold_depth_pipeline.py:381-394): the checkpoint's CLIP text encoder + tokenizer are loaded, "" is
+    tokenised with padding="do_not_pad" -> exactly the two tokens [bos, eos], and the [1, 2, D] embedding becomes the
+    UNet's 2-token context (the collapse of every cross-attention rests on that length)."""
+    import marigold_amd as M
+    path = _tiny_checkpoint(tmp_path, with_text_encoder=True)
+    pipe = M.MarigoldDepthPipeline.from_pretrained(path)
+    assert pipe.empty_text_embed is None and pipe.text_encoder is not None and pipe.tokenizer is not None
+    ids = pipe.tokenizer("", padding="do_not_pad", max_length=pipe.tokenizer.model_max_length, truncation=True,
+                         return_tensors="pt").input_ids
+    assert ids.tolist() == [[0, 1]]
+    pipe.encode_empty_text()
+    emb = pipe.empty_text_embed
+    assert tuple(emb.shape) == (1, 2, 64) and torch.isfinite(emb.float()).all()
+    with torch.no_grad():
+        want = pipe.text_encoder(ids)[0]
+    torch.testing.assert_close(emb.float(), want.to(emb.dtype).float())
+    pipe.unet.set_context(emb)            # accepted as the 2-token context; any other length is refused
+    with pytest.raises(ValueError, match="2-token context"):
+        pipe.unet.set_context(torch.zeros(1, 77, 64))
+
+
+def test_checkpoint_configs_are_validated_strictly(tmp_path):
+    """Every field of unet/config.json, vae/config.json and scheduler_config.json is checked: the published SD-v2 key
+    sets load, any value the engine does not implement (or any unknown field) raises instead of being ignored."""
+    import json
+    import marigold_amd as M
+    from marigold_amd import config_check as CC
+    # the published full-size configs pass as they are
+    assert CC.unet_config_from_json(CC.SD2_UNET_CONFIG).block_out_channels == (320, 640, 1280, 1280)
+    assert CC.vae_config_from_json(CC.SD2_VAE_CONFIG).latent_channels == 4
+    path = _tiny_checkpoint(tmp_path, with_text_encoder=False)
+    M.MarigoldDepthPipeline.from_pretrained(path)                      # full key sets, tiny sizes: loads
+
+    def reload_with(sub, fname, **changes):
+        f = os.path.join(path, sub, fname)
+        orig = json.load(open(f))
+        json.dump(dict(orig, **changes), open(f, "w"))
+        try:
+            M.MarigoldDepthPipeline.from_pretrained(path)
+        finally:
+            json.dump(orig, open(f, "w"))
+
+    bad_unet = [dict(use_linear_projection=False), dict(attention_head_dim=8), dict(norm_eps=1e-6), dict(act_fn="gelu"),
+                dict(only_cross_attention=True), dict(num_attention_heads=8), dict(class_embed_type="timestep"),
+                dict(resnet_time_scale_shift="scale_shift"), dict(transformer_layers_per_block=2), dict(layers_per_block=3),
+                dict(attention_head_dim=[2, 2, 2, 2]), dict(some_future_field=1), dict(time_embedding_type="fourier"),
+                dict(dual_cross_attention=True), dict(mid_block_type="UNetMidBlock2D"), dict(addition_embed_type="text")]
+    for ch in bad_unet:
+        with pytest.raises(CC.UnsupportedConfigError, match=next(iter(ch))):
+            reload_with("unet", "config.json", **ch)
+    for ch in (dict(scaling_factor=0.13025), dict(act_fn="relu"), dict(latent_channels=16), dict(use_quant_conv=False),
+               dict(mid_block_add_attention=False), dict(new_vae_field=True)):
+        with pytest.raises(CC.UnsupportedConfigError, match=next(iter(ch))):
+            reload_with("vae", "config.json", **ch)
+    for ch in (dict(thresholding=True), dict(trained_betas=[0.1]), dict(unknown_sched_field=3)):
+        with pytest.raises(CC.UnsupportedConfigError, match=next(iter(ch))):
+            reload_with("scheduler", "scheduler_config.json", **ch)
+    with pytest.raises(ValueError, match="clip_sample"):
+        reload_with("scheduler", "scheduler_config.json", clip_sample=True)
+    reload_with("unet", "config.json", upcast_attention=False, sample_size=64, dropout=0.1)   # informational fields
 
 
 def test_iid_output_container_and_pipeline_contract():
