@@ -318,6 +318,40 @@ def main():
             log(f"[bench] per-kernel profile failed: {type(e).__name__}: {e}")
             kernels, roof, stages, flops_per_map = {}, None, {}, 0
 
+    # ---- the parts of a map that are not native programs: test-time ensembling (host BFGS driving two fused kernels
+    # per cost evaluation) and, with several ranks, the single gather of the members -------------------------------
+    if not args.no_profile and args.ensemble > 1:
+        try:
+            import marigold_amd.dist as mdist
+            from marigold_amd import ensemble as ens
+            C = {"depth": 1, "normals": 3, "iid": 6}[args.kind]
+            local_n = len(mdist.shard_members(args.ensemble, world, rank)) if world > 1 else args.ensemble
+            if world > 1:
+                buf = torch.rand(local_n, C, args.res, args.res, device=dev)
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    mdist.gather_members(buf, args.ensemble, (C, args.res, args.res), dev, None, 0)
+                barrier()
+                if rank == 0:
+                    stages["gather"] = {"ms": round((time.perf_counter() - t1) / 3 * 1e3, 3),
+                                        "bytes_to_root": (args.ensemble - local_n) * C * args.res * args.res * 4}
+            if rank == 0 and args.kind == "depth":
+                rgbn = (img.float() / 255.0 * 2.0 - 1.0).expand(max(1, local_n), -1, -1, -1)   # a batch size whose programs exist
+                members = pipe.single_infer(rgbn, args.denoise, None)
+                if members.shape[0] < args.ensemble:
+                    members = members.repeat(-(-args.ensemble // members.shape[0]), 1, 1, 1)[:args.ensemble]
+                _, _, info = ens.ensemble_depth(members, True, True, return_info=True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    ens.ensemble_depth(members, True, True)
+                torch.cuda.synchronize()
+                stages["ensemble"] = {"ms": round((time.perf_counter() - t1) / 3 * 1e3, 3), "cost_evaluations": int(info["n_eval"]),
+                                      "bfgs_iterations": int(info["n_iter"])}
+        except Exception as e:  # noqa: BLE001 - reporting only
+            log(f"[bench] ensemble / gather timing skipped: {type(e).__name__}: {e}")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the oracle runs in a child process under a hard timeout: it is a reported baseline and must

@@ -50,11 +50,14 @@ enum mg_op_kind {
   MG_OP_IGEMM = 1,
   /* GroupNorm, 3 launches (stats partials -> per-(b,c) scale/shift -> apply [+SiLU]).
    * Replaces torch group_norm + silu in every ResNet block / Transformer2D input norm.
-   *  STATS:    p[0] x bf16 [B][HW][C]  p[1] partials f32 [B][chunks][Ctot][2]; i: B,HW,C,chunks, Ctot (0 = C),
-   *            coff - x holds channels [coff, coff+C) of a Ctot-channel norm (the UNet's skip concat
-   *            torch.cat([hidden, skip]) is normalised source by source, never materialised)
+   *  STATS:    p[0] x bf16 [B][HW][C]  p[1] partials f32 [B][slots][groups][2] ; i: B,HW,C,chunks, Ctot (0 = C), coff,
+   *            groups, slot0, slots (0 = chunks) - x holds channels [coff, coff+C) of a Ctot-channel norm (the UNet's skip
+   *            concat torch.cat([hidden, skip]) is normalised source by source, never materialised); block (chunk, b)
+   *            writes slot slot0 + chunk.  With p[4] != NULL the image's last-arriving block also does FINALIZE's job
+   *            (no finalize launch): p[2] gamma p[3] beta p[4] scale_shift [B][2][Ctot] p[5] uint32 [B] arrival counters
+   *            (zero before the first use; left zero) ; f[0] eps
    *  FINALIZE: p[0] partials p[1] gamma f32 p[2] beta f32 p[3] scale_shift f32 [B][2][C];
-   *            i: B,C,groups,chunks,HW ; f[0] eps
+   *            i: B,C,groups,slots,HW ; f[0] eps
    *  APPLY:    p[0] x  p[1] scale_shift  p[2] out bf16 [B][HW][C]  p[3] x1 | NULL ; i: B,HW,C,silu, C0 - with x1 the
    *            output channels [0,C0) come from x ([B][HW][C0]) and [C0,C) from x1 ([B][HW][C-C0]) */
   MG_OP_GN_STATS = 2,

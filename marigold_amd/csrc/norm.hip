@@ -10,14 +10,62 @@ namespace {
 
 constexpr int GN_NV = 4;  // channel vectors per thread: supports C <= 256*8*GN_NV
 
-// grid (chunks, B); block 256.  partials[b][chunk][c][2] = (sum, sumsq) over the chunk's rows.
-// Threads are laid out txn (channel vectors) x tyn (row lanes); every thread keeps fp32 partials
-// of its rows in registers (4 rows in flight), then the row lanes are combined through LDS in a
-// FIXED order - bit-reproducible, no atomics.
+// grid (chunks, B); block 256.  partials[b][slot][group][2] = (sum, sumsq) of the group's channels THAT THIS SOURCE HOLDS
+// over the chunk's rows, slot = source * chunks + chunk (a norm over the un-materialised concat of two tensors gets one
+// statistics launch per source; a group that straddles the two gets a contribution from each).
+// Threads are laid out txn (channel vectors) x tyn (row lanes); every thread keeps fp32 partials of its rows in
+// registers (4 rows in flight), the row lanes and then the channels of a group are combined through LDS in a FIXED
+// order - bit-reproducible, no floating-point atomics.
+// With ss != nullptr the image's last block to arrive also reduces the table to scale / shift (no finalize launch).
+template <bool SC1>   // SC1: the table was written by other workgroups of this launch with sc1 stores - read it past the L1
+__device__ __forceinline__ void gn_finalize_image(const float* __restrict__ partials, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ ss, int b, int C,
+                                                  int groups, int slots, int HW, float eps, int tid, int nthreads) {
+  // 8 threads per group: thread (g, sub) sums slots sub, sub + 8, ... in fp64, then the 8 are combined by shuffles
+  const int cpg = C / groups;
+  for (int g0 = 0; g0 < groups; g0 += nthreads / 8) {
+    const int g = g0 + tid / 8, sub = tid & 7;
+    double sd = 0.0, qd = 0.0;
+    if (g < groups) {
+      const float* p = partials + ((long long)b * slots * groups + g) * 2;
+      for (int sl = sub; sl < slots; sl += 8) {
+        if constexpr (SC1) {
+          sd += (double)__hip_atomic_load(p + (long long)sl * groups * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          qd += (double)__hip_atomic_load(p + (long long)sl * groups * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          sd += (double)p[(long long)sl * groups * 2];
+          qd += (double)p[(long long)sl * groups * 2 + 1];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      sd += __shfl_xor(sd, o);
+      qd += __shfl_xor(qd, o);
+    }
+    if (g < groups) {
+      const double cnt = (double)HW * cpg;
+      const double mean = sd / cnt;
+      double var = qd / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+      for (int i = sub; i < cpg; i += 8) {
+        const int c = g * cpg + i;
+        const float sc = rstd * gamma[c];
+        ss[((long long)b * 2 + 0) * C + c] = sc;
+        ss[((long long)b * 2 + 1) * C + c] = beta[c] - (float)mean * sc;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x,
                                                        float* __restrict__ partials, int HW, int C,
-                                                       int chunks, int Ctot, int coff) {
-  extern __shared__ float lds[];  // [tyn][C][2]
+                                                       int chunks, int Ctot, int coff, int slot0, int slots,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ ss,
+                                                       unsigned* __restrict__ counters, int groups, float eps) {
+  extern __shared__ float lds[];  // [tyn][C][2] row-lane partials, then [C][2] channel totals
   const int cv = C >> 3;
   const int txn = cv < 256 ? cv : 256;
   const int tyn = 256 / txn;
@@ -69,55 +117,53 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     }
   }
   __syncthreads();
-  // channels [coff, coff + C) of a Ctot-channel norm: the skip concat of the UNet's up blocks is normalised without
-  // being materialised, each source contributes its own channels' partial sums
-  float* out = partials + (((long long)b * chunks + chunk) * Ctot + coff) * 2;
+  float* tot = lds + (long long)tyn * 2 * C;
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     float t = 0.f;
     for (int y = 0; y < tyn; ++y) t += lds[(long long)y * 2 * C + i];
-    out[i] = t;
+    tot[i] = t;
   }
+  __syncthreads();
+  const int cpg = Ctot / groups;
+  float* out = partials + (((long long)b * slots + slot0 + chunk) * groups) * 2;
+  for (int g = threadIdx.x; g < groups; g += 256) {   // this source's share of every group (zero where it has none)
+    const int lo = max(g * cpg, coff) - coff, hi = min((g + 1) * cpg, coff + C) - coff;
+    float sg = 0.f, qg = 0.f;
+    for (int c = lo; c < hi; ++c) { sg += tot[2 * c]; qg += tot[2 * c + 1]; }
+    if (ss) {   // write-through (sc1) stores: visible at agent scope without a per-block L2 write-back fence
+      __hip_atomic_store(&out[2 * g], sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&out[2 * g + 1], qg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      out[2 * g] = sg;
+      out[2 * g + 1] = qg;
+    }
+  }
+  if (!ss) return;
+  // ---- the image's last block to arrive turns the partial table into scale / shift ----
+  // hand-off per cdna_hip_programming.md Guideline 16 (write-through form): sc1 stores of the block's row -> every wave
+  // drains them -> barrier -> one relaxed agent-scope ticket; the block that draws the last ticket reads the table with
+  // agent-scope loads.
+  // The reduction order is fixed by the thread index, not by which block happens to be last: bit-reproducible.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(&counters[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = ticket == (unsigned)(slots - 1);
+    lds[0] = last ? 1.f : 0.f;
+    if (last) __hip_atomic_store(&counters[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (lds[0] == 0.f) return;
+  gn_finalize_image<true>(partials, gamma, beta, ss, b, Ctot, groups, slots, HW, eps, threadIdx.x, 256);
 }
 
-// one workgroup per (b, group): fixed-order tree over the chunk partials (fp64), then
-// ss[b][0][c] = scale = rstd * gamma, ss[b][1][c] = shift = beta - mean * scale
+// one workgroup per image (the stand-alone form of the reduction above)
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           float* __restrict__ ss, int B, int C,
-                                                          int groups, int chunks, int HW, float eps) {
-  __shared__ double red[2][4];
-  const int b = blockIdx.x / groups, g = blockIdx.x % groups;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cpg = C / groups;
-  double s = 0.0, q = 0.0;
-  const int n = chunks * cpg;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int ch = i / cpg, c = g * cpg + (i % cpg);
-    const float* p = partials + (((long long)b * chunks + ch) * C + c) * 2;
-    s += (double)p[0];
-    q += (double)p[1];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o);
-    q += __shfl_xor(q, o);
-  }
-  if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
-  __syncthreads();
-  s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-  q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-  const double cnt = (double)HW * cpg;
-  const double mean = s / cnt;
-  double var = q / cnt - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  for (int i = threadIdx.x; i < cpg; i += 256) {
-    const int c = g * cpg + i;
-    const float sc = rstd * gamma[c];
-    ss[((long long)b * 2 + 0) * C + c] = sc;
-    ss[((long long)b * 2 + 1) * C + c] = beta[c] - (float)mean * sc;
-  }
+                                                          int groups, int slots, int HW, float eps) {
+  gn_finalize_image<false>(partials, gamma, beta, ss, blockIdx.x, C, groups, slots, HW, eps, threadIdx.x, 256);
 }
 
 // grid (row chunks, B); threads laid out like gn_stats: txn channel vectors x tyn row lanes.  A thread
@@ -262,17 +308,24 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
       MG_REQUIRE(B > 0 && HW > 0 && chunks > 0 && chunks <= HW, "gn_stats: bad dims");
       const int cvv = C / 8, tynn = 256 / (cvv < 256 ? cvv : 256);
       const int Ctot = op->i[4] > 0 ? op->i[4] : C, coff = op->i[5];
+      const int groups = op->i[6], slot0 = op->i[7], slots = op->i[8] > 0 ? op->i[8] : chunks;
       MG_REQUIRE(coff >= 0 && coff + C <= Ctot && coff % 8 == 0, "gn_stats: channel window [%d,+%d) outside %d", coff, C, Ctot);
-      MG_LAUNCH(gn_stats_kernel, dim3(chunks, B), dim3(256), (size_t)tynn * 2 * C * sizeof(float), s,
-                         (const bf16_t*)op->p[0], (float*)op->p[1], HW, C, chunks, Ctot, coff);
+      MG_REQUIRE(groups > 0 && Ctot % groups == 0, "gn_stats: %d channels not divisible into %d groups", Ctot, groups);
+      MG_REQUIRE(slot0 >= 0 && slot0 + chunks <= slots, "gn_stats: slots [%d,+%d) outside %d", slot0, chunks, slots);
+      // optional fused finalize: p[2] gamma p[3] beta p[4] scale_shift [B][2][Ctot] p[5] per-image arrival counters
+      float* ssout = (float*)op->p[4];
+      if (ssout) MG_REQUIRE(op->p[2] && op->p[3] && op->p[5], "gn_stats: fused finalize needs gamma, beta and counters");
+      MG_LAUNCH(gn_stats_kernel, dim3(chunks, B), dim3(256), (size_t)(tynn + 1) * 2 * C * sizeof(float), s,
+                         (const bf16_t*)op->p[0], (float*)op->p[1], HW, C, chunks, Ctot, coff, slot0, slots,
+                         (const float*)op->p[2], (const float*)op->p[3], ssout, (unsigned*)op->p[5], groups, op->f[0]);
       break;
     }
     case MG_OP_GN_FINALIZE: {
-      const int B = op->i[0], C = op->i[1], groups = op->i[2], chunks = op->i[3], HW = op->i[4];
-      MG_REQUIRE(C % groups == 0, "gn_finalize: C %d not divisible by groups %d", C, groups);
-      MG_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, s,
+      const int B = op->i[0], C = op->i[1], groups = op->i[2], slots = op->i[3], HW = op->i[4];
+      MG_REQUIRE(groups > 0 && C % groups == 0, "gn_finalize: C %d not divisible by groups %d", C, groups);
+      MG_LAUNCH(gn_finalize_kernel, dim3(B), dim3(256), 0, s,
                          (const float*)op->p[0], (const float*)op->p[1], (const float*)op->p[2],
-                         (float*)op->p[3], B, C, groups, chunks, HW, op->f[0]);
+                         (float*)op->p[3], B, C, groups, slots, HW, op->f[0]);
       break;
     }
     case MG_OP_GN_APPLY: {

@@ -187,15 +187,18 @@ class Builder:
         # ~768 (chunk, image) blocks: covers the 256 CUs three times over while keeping the
         # second-level reduction (gn_finalize) short; >= 32 rows per chunk
         chunks = max(1, min(HW // 32, max(16, 768 // B)))
-        part = self.raw(B * chunks * C * 2 * 4)
+        slots = chunks * len(srcs)
+        part = self.raw(B * slots * self.groups * 2 * 4)
         ss = self.raw(B * 2 * C * 4)
         coff = 0
+        counters = self.zeros_persistent("gn_counters", 4 * max(B, 1024))   # stream-ordered reuse; left zero by every use
         for k, x in enumerate(srcs):
-            self.add(O.gn_stats(x.t, part, B=B, HW=HW, C=x.C, chunks=chunks, Ctot=C, coff=coff),
+            # the image's last-arriving statistics block turns the partial table into scale / shift (no finalize launch)
+            self.add(O.gn_stats(x.t, part, B=B, HW=HW, C=x.C, chunks=chunks, groups=self.groups, Ctot=C, coff=coff,
+                                slot0=k * chunks, slots=slots, gamma=self.ws.vec(f"{name}.weight"),
+                                beta=self.ws.vec(f"{name}.bias"), ss=ss, counters=counters, eps=eps),
                      f"{name}.stats" + (f"{k}" if len(srcs) > 1 else ""))
             coff += x.C
-        self.add(O.gn_finalize(part, self.ws.vec(f"{name}.weight"), self.ws.vec(f"{name}.bias"), ss, B=B,
-                               C=C, groups=self.groups, chunks=chunks, HW=HW, eps=eps), f"{name}.finalize")
         self.free(part)
         return ss
 
@@ -216,10 +219,22 @@ class Builder:
 
     # ---- patch-resident conv3x3 (MG_OP_CONV3X3) ------------------------------------------------------
     @staticmethod
-    def patch_eligible(H, W):
+    def patch_eligible(H, W, B=None, N=None, subpix=False):
         """16-pixel-wide tiles: maps that waste little of them (the 24x24 / 12x12 levels stay on the implicit GEMM,
-        whose split-K also fills the chip there)."""
-        return (H >= 32 and W >= 32) or (H % 16 == 0 and W % 16 == 0)
+        whose split-K also fills the chip there) and - when the batch and width are given - enough workgroups for the
+        256 CUs (a single member at 96x96 has 36-72 spatial tiles: the implicit GEMM's smaller tiles fill the chip)."""
+        if not ((H >= 32 and W >= 32) or (H % 16 == 0 and W % 16 == 0)):
+            return False
+        if B is None:
+            return True
+        if N % 256 == 0:
+            th, bn = 16, 256
+        elif N == 320 or (subpix and N % 320 == 0):
+            th, bn = 8, 320
+        else:
+            th, bn = 16, 128
+        grid = B * -(-H // th) * -(-W // 16) * -(-N // bn) * (4 if subpix else 1)
+        return grid >= 240
 
     def fuse_norm_into_conv(self, B, H, W, Cin, N):
         """Apply the GroupNorm affine + SiLU inside the convolution's operand staging?  The fix-up runs once per
@@ -256,7 +271,7 @@ class Builder:
             Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
         if out is None:
             out = self.new(x.B, Ho, Wo, cout)
-        if USE_PATCH and stride == 1 and pad == 1 and self.patch_eligible(x.H, x.W):
+        if USE_PATCH and stride == 1 and pad == 1 and self.patch_eligible(x.H, x.W, x.B, cout, up is not None):
             if up is None:
                 return self.conv3x3p([x], name, cout, rowvec=rowvec, residual=residual, out=out)
             if up == (2 * x.H, 2 * x.W) and rowvec is None and residual is None:
@@ -326,7 +341,7 @@ class Builder:
         ``fuse_norm_into_conv`` says it pays, else by one pass that also performs the concat."""
         srcs = [x] + ([skip] if skip is not None else [])
         Cin = sum(y.C for y in srcs)
-        patch = USE_PATCH and self.patch_eligible(x.H, x.W)
+        patch = USE_PATCH and self.patch_eligible(x.H, x.W, x.B, cout)
 
         def norm_conv(inputs, norm, conv, rowvec=None, residual=None, out=None):
             ss = self.gn_scale_shift(inputs, norm, eps)

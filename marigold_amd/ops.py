@@ -67,12 +67,15 @@ def linear(x, w, out, *, M, K, N, **kw):
     return igemm(x, w, out, B=1, H=M, W=1, Cin=K, Ho=M, Wo=1, N=N, taps=1, **kw)
 
 
-def gn_stats(x, partials, *, B, HW, C, chunks, Ctot=0, coff=0):
-    return make_op(L.OP_GN_STATS, i=[B, HW, C, chunks, Ctot, coff], p=[x, partials])
+def gn_stats(x, partials, *, B, HW, C, chunks, groups, Ctot=0, coff=0, slot0=0, slots=0, gamma=None, beta=None, ss=None,
+             counters=None, eps=0.0):
+    """Partials [B][slots][groups][2]; with ``ss`` the image's last-arriving block also finalizes (MG_OP_GN_STATS)."""
+    return make_op(L.OP_GN_STATS, i=[B, HW, C, chunks, Ctot, coff, groups, slot0, slots], f=[eps],
+                   p=[x, partials, gamma, beta, ss, counters])
 
 
-def gn_finalize(partials, gamma, beta, ss, *, B, C, groups, chunks, HW, eps):
-    return make_op(L.OP_GN_FINALIZE, i=[B, C, groups, chunks, HW], f=[eps], p=[partials, gamma, beta, ss])
+def gn_finalize(partials, gamma, beta, ss, *, B, C, groups, slots, HW, eps):
+    return make_op(L.OP_GN_FINALIZE, i=[B, C, groups, slots, HW], f=[eps], p=[partials, gamma, beta, ss])
 
 
 def gn_apply(x, ss, out, *, B, HW, C, silu, x1=None, C0=0):

@@ -308,15 +308,30 @@ def test_igemm_two_sources_and_gn_channel_windows(dev):
     # GroupNorm over the concat: statistics per source into one partial table, finalize, two-source apply
     groups, chunks, eps = 32, 4, 1e-5
     gamma, beta = (1.0 + 0.1 * torch.randn(Cin, generator=g)), 0.1 * torch.randn(Cin, generator=g)
-    part = torch.zeros(B * chunks * Cin * 2, device=dev)
+    part = torch.zeros(B * 2 * chunks * groups * 2, device=dev)
     ss = torch.zeros(B, 2, Cin, device=dev)
-    _run(ops.gn_stats(a0, part, B=B, HW=H * W, C=C0, chunks=chunks, Ctot=Cin, coff=0))
-    _run(ops.gn_stats(a1, part, B=B, HW=H * W, C=C1, chunks=chunks, Ctot=Cin, coff=C0))
-    _run(ops.gn_finalize(part, gamma.to(dev), beta.to(dev), ss, B=B, C=Cin, groups=groups, chunks=chunks, HW=H * W, eps=eps))
+    _run(ops.gn_stats(a0, part, B=B, HW=H * W, C=C0, chunks=chunks, groups=groups, Ctot=Cin, coff=0, slot0=0, slots=2 * chunks))
+    _run(ops.gn_stats(a1, part, B=B, HW=H * W, C=C1, chunks=chunks, groups=groups, Ctot=Cin, coff=C0, slot0=chunks, slots=2 * chunks))
+    _run(ops.gn_finalize(part, gamma.to(dev), beta.to(dev), ss, B=B, C=Cin, groups=groups, slots=2 * chunks, HW=H * W, eps=eps))
     out = torch.full((B, H, W, Cin), float("nan"), device=dev, dtype=torch.bfloat16)
     _run(ops.gn_apply(a0, ss, out, B=B, HW=H * W, C=Cin, silu=True, x1=a1, C0=C0))
     ref = F.silu(F.group_norm(x, groups, gamma, beta, eps))
     _close("groupnorm over two sources", out.float().permute(0, 3, 1, 2), ref)
+    # the same table finalized by the last-arriving statistics block (no finalize launch): same scale / shift up to
+    # the summation order of the fp64 reduction, identical bits from launch to launch, counters left at zero
+    gd, bd = gamma.to(dev), beta.to(dev)
+    cnt = torch.zeros(1024, dtype=torch.int32, device=dev)
+    runs = []
+    for _ in range(3):
+        part.fill_(float("nan"))
+        ss2 = torch.full((B, 2, Cin), float("nan"), device=dev)
+        for k, (src, C, coff) in enumerate(((a0, C0, 0), (a1, C1, C0))):
+            _run(ops.gn_stats(src, part, B=B, HW=H * W, C=C, chunks=chunks, groups=groups, Ctot=Cin, coff=coff, slot0=k * chunks,
+                              slots=2 * chunks, gamma=gd, beta=bd, ss=ss2, counters=cnt, eps=eps))
+        runs.append(ss2.clone())
+        assert int(cnt.abs().sum()) == 0
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    _close("groupnorm fused finalize vs finalize launch", runs[0], ss, tol=1e-5)
 
 
 def test_flash_attn64_benchmark_shape(dev):
@@ -459,9 +474,9 @@ def test_groupnorm(dev, B, H, W, C, silu, eps):
     part = torch.empty(B, chunks, C, 2, device=dev)
     ss = torch.empty(B, 2, C, device=dev)
     out = torch.full_like(xd, float("nan"))
-    for op in (ops.gn_stats(xd, part, B=B, HW=HW, C=C, chunks=chunks),
+    for op in (ops.gn_stats(xd, part, B=B, HW=HW, C=C, chunks=chunks, groups=32),
                ops.gn_finalize(part, gamma.to(dev), beta.to(dev), ss, B=B, C=C, groups=32,
-                               chunks=chunks, HW=HW, eps=eps),
+                               slots=chunks, HW=HW, eps=eps),
                ops.gn_apply(xd, ss, out, B=B, HW=HW, C=C, silu=silu)):
         _run(op)
     _close(f"groupnorm/C{C}", out.float().permute(0, 3, 1, 2), ref)
@@ -649,8 +664,8 @@ def test_program_and_graph_replay(dev):
     out = torch.zeros_like(x)
     gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     seq = ops.OpSeq("gn")
-    seq.add(ops.gn_stats(x, part, B=B, HW=HW, C=C, chunks=4))
-    seq.add(ops.gn_finalize(part, gamma, beta, ss, B=B, C=C, groups=32, chunks=4, HW=HW, eps=1e-5))
+    seq.add(ops.gn_stats(x, part, B=B, HW=HW, C=C, chunks=4, groups=32))
+    seq.add(ops.gn_finalize(part, gamma, beta, ss, B=B, C=C, groups=32, slots=4, HW=HW, eps=1e-5))
     seq.add(ops.gn_apply(x, ss, out, B=B, HW=HW, C=C, silu=True))
     seq.run()
     torch.cuda.synchronize()

@@ -265,6 +265,7 @@ def test_ensemble_depth_on_device_vs_reference_golden(golden_dir):
         print(f"[parity] ensemble_depth/{name}: cost ours {c_ours:.5f} <= reference {c_ref:.5f}; {info['n_eval']} "
               f"evals / {info['n_iter']} its; |out-ref| max {float(diff.max()):.4f} mean {float(diff.mean()):.5f}; {m}")
         assert float(diff.max()) < tol_max and float(diff.mean()) < tol_mean
+        assert m["rmse"] < 2.5 * tol_mean and m["delta1"] > 0.96, (name, m)   # the reference's own metrics, asserted
         assert u.shape == d.shape and torch.isfinite(u).all()
     x = torch.from_numpy(gold["d_scale_mean_in"])
     d, u = ens.ensemble_depth(x.cuda(), True, False, output_uncertainty=True, reduction="mean")
@@ -319,6 +320,37 @@ def test_graph_capture_matches_eager(tiny):
         prog.run()
     torch.cuda.synchronize()
     assert torch.equal(prog.x, ref)
+
+
+def test_ensemble_depth_metric_config_vs_reference(golden_dir):
+    """A11 at the metric configuration: E = 10 members at 768 x 768 against the output of the REFERENCE's own
+    ensemble_depth on the same (seeded, regenerated) members (tests/golden/ensemble_ref_768.npz, 92 s of CPU there).
+    Asserted in the reference's affine-invariant metrics (src/util/alignment.py:35-82, src/util/metric.py:64-104) and in
+    raw differences; reports cost evaluations and milliseconds per call."""
+    import time
+    from marigold_amd import ensemble as ens
+    from oracle import metrics as omet
+    from oracle.make_golden import synth_realistic_depth_members
+    gold = np.load(os.path.join(golden_dir, "ensemble_ref_768.npz"))
+    x = synth_realistic_depth_members(10, 768, 768, 51).cuda()
+    d, u, info = ens.ensemble_depth(x, True, True, output_uncertainty=True, return_info=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ens.ensemble_depth(x, True, True, output_uncertainty=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    ref = gold["d_real_e10_768_out"]
+    got = d[0, 0].cpu().numpy()
+    diff = np.abs(got - ref)
+    m = omet.affine_invariant_depth_errors(ref, got)
+    du = np.abs(u[0, 0].cpu().numpy() - gold["d_real_e10_768_unc"].astype(np.float32))
+    print(f"[parity] ensemble_depth E=10 768x768 vs the reference's own output: |out-ref| max {diff.max():.4f} mean {diff.mean():.5f}; "
+          f"{m}; uncertainty |diff| max {du.max():.4f}; {info['n_eval']} cost evaluations / {info['n_iter']} iterations, "
+          f"{ms:.1f} ms per call on the MI355X (reference: {float(gold['seconds_reference_cpu']):.0f} s on {int(gold['threads'])} CPU threads)")
+    assert m["rmse"] < 6e-3 and m["delta1"] > 0.995 and m["abs_rel"] < 1.5e-2
+    assert diff.mean() < 1e-2 and diff.max() < 5e-2
+    assert du.max() < 3e-2
 
 
 def _mp_worker(rank, world, port, q):
