@@ -41,6 +41,16 @@ struct Igemm2Args {
   float* ws;           // fp32 [splits][M][N] (scale / bias / residual are applied by the reduce kernel)
   long long sA, sW, sO, sR;
   float scale;
+  // LayerNorm folded into this GEMM (Linear layers that consume LN(x)): A = the RAW rows x, weights = W * gamma, and
+  //   out = rstd[m] * (acc - mean[m] * ln_g[n]) + ln_c[n],  ln_g[n] = sum_k (W gamma)[n][k],  ln_c[n] = sum_k beta[k] W[n][k] + bias[n]
+  // with (mean, rstd) of row m taken from ln_in: [M][ln_slots] (sum, sum of squares) over 32-column slots, written by the
+  // epilogue of the GEMM that produced x (ln_out of that launch: one slot per 32 output columns).
+  const float2* ln_in;
+  const float* ln_g;
+  const float* ln_c;
+  float2* ln_out;
+  int ln_slots;
+  float ln_eps;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -222,6 +232,27 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  // folded LayerNorm: (mean, rstd) of the tile's BM rows, kept in LDS behind the ring for the epilogue (the K loop's
+  // barriers publish them)
+  float2* const lnst = (float2*)(smem + NSTAGE * STAGE);
+  if (a.ln_in) {
+    for (int r = tid; r < BM; r += NT) {
+      const int m = m0 + r;
+      float2 st = make_float2(0.f, 1.f);
+      if (m < a.M) {
+        const float2* p = a.ln_in + (long long)m * a.ln_slots;
+        double sd = 0.0, qd = 0.0;
+        for (int sl = 0; sl < a.ln_slots; ++sl) { const float2 v = p[sl]; sd += (double)v.x; qd += (double)v.y; }
+        const double mean = sd / (double)a.Cin;
+        double var = qd / (double)a.Cin - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)a.ln_eps)));
+      }
+      lnst[r] = st;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
 
   int rowA[MI], rowB[NI];
 #pragma unroll
@@ -506,6 +537,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wm * TM + mi * 32 + l31;
+        const float2 lst = a.ln_in ? lnst[wm * TM + mi * 32 + l31] : make_float2(0.f, 1.f);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int nb = n0 + wn * TN + ni * 32;
@@ -516,6 +548,12 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
             const int nu = nb + 4 * half + j;
             float u0 = acc[ni][mi][j] * scale, u1 = acc[ni][mi][4 + j] * scale;
             float t0 = acc[ni][mi][8 + j] * scale, t1 = acc[ni][mi][12 + j] * scale;
+            if (a.ln_in && nok) {
+              u0 = lst.y * (u0 - lst.x * a.ln_g[nu]) + a.ln_c[nu];
+              u1 = lst.y * (u1 - lst.x * a.ln_g[nu + 8]) + a.ln_c[nu + 8];
+              t0 = lst.y * (t0 - lst.x * a.ln_g[nu + 16]) + a.ln_c[nu + 16];
+              t1 = lst.y * (t1 - lst.x * a.ln_g[nu + 24]) + a.ln_c[nu + 24];
+            }
             if (a.bias && nok) {
               u0 += a.bias[nu]; u1 += a.bias[nu + 8]; t0 += a.bias[nu + 16]; t1 += a.bias[nu + 24];
             }
@@ -542,6 +580,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int mb = m0 + wm * TM + mi * 32, nb = n0 + wn * TN + ni * 32;
+      float ps = 0.f, pq = 0.f;   // ln_out: this lane's share of (sum, sum of squares) of row mb + l31 over columns [nb, nb + 32)
 #pragma unroll
       for (int gp = 0; gp < 2; ++gp) {
         float v[8];
@@ -568,6 +607,15 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
               *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
           } else if (m < a.M && n < a.n_end) {
+            if (a.ln_in) {
+              const float2 lst = lnst[wm * TM + mi * 32 + l31];
+              const float4 g0 = *(const float4*)(a.ln_g + n), g1 = *(const float4*)(a.ln_g + n + 4);
+              const float4 c0 = *(const float4*)(a.ln_c + n), c1 = *(const float4*)(a.ln_c + n + 4);
+              const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+              const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = lst.y * (v[j] - lst.x * gg[j]) + cc[j];
+            }
             if (a.bias) {
               const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
               v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
@@ -589,6 +637,10 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
                 v[0] += bflo(r4.x); v[1] += bfhi(r4.x); v[2] += bflo(r4.y); v[3] += bfhi(r4.y);
                 v[4] += bflo(r4.z); v[5] += bfhi(r4.z); v[6] += bflo(r4.w); v[7] += bfhi(r4.w);
               }
+              if (a.ln_out) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ps += v[j]; pq = __builtin_fmaf(v[j], v[j], pq); }
+              }
               uint4 pk;
               pk.x = cvt_pk_bf16(v[0], v[1]); pk.y = cvt_pk_bf16(v[2], v[3]);
               pk.z = cvt_pk_bf16(v[4], v[5]); pk.w = cvt_pk_bf16(v[6], v[7]);
@@ -599,6 +651,14 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
           // transposed store: out[z][img][n][tok], 8 consecutive tokens per lane
           const int n = nb + l31, m = mb + 16 * gp + 8 * half;
           if (n < a.n_end && m < a.M) {
+            if (a.ln_in) {
+              const float gn = a.ln_g[n], cn = a.ln_c[n];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float2 lst = lnst[m - m0 + j];
+                v[j] = lst.y * (v[j] - lst.x * gn) + cn;
+              }
+            }
             const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += bv;
@@ -622,6 +682,14 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
               }
             }
           }
+        }
+      }
+      if constexpr (!TRANS) {
+        if (a.ln_out) {   // both halves of the lane pair hold 16 of the row's 32 columns
+          ps += __shfl_xor(ps, 32);
+          pq += __shfl_xor(pq, 32);
+          const int m = mb + l31;
+          if (half == 0 && m < a.M && nb < a.n_end) a.ln_out[(long long)m * (a.N >> 5) + (nb >> 5)] = make_float2(ps, pq);
         }
       }
     }
@@ -685,7 +753,7 @@ template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT =
           int BK = 64, int PPOPT = -1>
 int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   constexpr int NT = WGM * WGN * 64;
-  constexpr int LDS = NSTAGE * (BM + BN) * BK * 2;
+  constexpr int LDS = NSTAGE * (BM + BN) * BK * 2 + BM * 8;   // ring + (mean, rstd) of the tile's rows (folded LayerNorm)
   static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
   static bool attr_set = false;
   void (*kern)(const Igemm2Args);
@@ -818,6 +886,23 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.tw = a.taps == 9 ? 3 : (a.taps == 4 ? 2 : 1);
   a.subpix = a.taps == 4;
   a.splits = variant ? -1 : 0;   // split-K only under the automatic tile choice
+  a.ln_out = (float2*)op->p[8];
+  a.ln_in = (const float2*)op->p[9];
+  a.ln_g = (const float*)op->p[10];
+  a.ln_c = (const float*)op->p[11];
+  a.ln_slots = op->i[26];
+  a.ln_eps = op->f[1];
+  if (a.ln_out) {
+    MG_REQUIRE(a.epi == MG_EPI_BF16 && trans_from < 0 && a.N % 32 == 0 && batch_z == 1 && (uintptr_t)a.ln_out % 8 == 0,
+               "igemm: row statistics (ln_out) need the bf16 epilogue, N %% 32 == 0, no transposed section / batching");
+    a.splits = -1;   // the statistics are taken in the tile epilogue, not in the split-K reduction
+  }
+  if (a.ln_in) {
+    MG_REQUIRE(a.taps == 1 && batch_z == 1 && !a.A1 && a.ln_g && a.ln_c && a.ln_slots * 32 == a.Cin && (uintptr_t)a.ln_in % 8 == 0 &&
+               (uintptr_t)a.ln_g % 16 == 0 && (uintptr_t)a.ln_c % 16 == 0,
+               "igemm: folded LayerNorm needs a Linear layer (taps 1), ln_g / ln_c and one statistics slot per 32 input columns");
+    a.splits = -1;
+  }
   a.kps = 0;
   a.ws = nullptr;
   a.ctr = 0;
@@ -865,6 +950,9 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
     tns.out = out2;
     tns.Wt = a.Wt + (long long)trans_from * a.ldw;
     tns.bias = a.bias ? a.bias + trans_from : nullptr;
+    tns.ln_g = a.ln_g ? a.ln_g + trans_from : nullptr;
+    tns.ln_c = a.ln_c ? a.ln_c + trans_from : nullptr;
+    tns.ln_out = nullptr;
     tns.N = a.N - trans_from;
     tns.n_begin = 0;
     tns.n_end = tns.N;

@@ -23,6 +23,7 @@ LATENT_SCALE = 0.18215  # marigold_depth_pipeline.py:118
 # A/B switches for tuning runs (defaults are the product configuration)
 USE_PATCH = os.environ.get("MARIGOLD_PATCH_CONV", "1") != "0"      # patch-resident conv3x3 kernel where eligible
 FUSE_GN = os.environ.get("MARIGOLD_FUSE_GN", "auto")               # auto | all | none: GroupNorm apply inside the conv
+FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"           # LayerNorms folded into the Linear layers that consume them
 
 
 class Act:
@@ -138,6 +139,33 @@ class WeightStore:
                 b = Wm.f32(torch.cat([self.sd[f"{prefix}.{q}.bias"].float() for q in ("to_q", "to_k", "to_v")]), self.device)
             return Wm.bf16(w, self.device), b
         return self._memo(("qkv", prefix), f)
+
+    # ---- Linear layers with the preceding LayerNorm folded in (weights.fold_layernorm) ----
+    def _ln(self, norm):
+        return self.sd[f"{norm}.weight"].float(), self.sd[f"{norm}.bias"].float()
+
+    def qkv_ln(self, prefix, norm):
+        def f():
+            w = Wm.pack_qkv(*(self.sd[f"{prefix}.{q}.weight"].float() for q in ("to_q", "to_k", "to_v")))
+            wp, g, c = Wm.fold_layernorm(w, None, *self._ln(norm))
+            return wp.to(self.device), Wm.f32(g, self.device), Wm.f32(c, self.device)
+        return self._memo(("qkv_ln", prefix), f)
+
+    def geglu_ln(self, name, norm):
+        def f():
+            w, b = Wm.pack_geglu(self.sd[f"{name}.weight"].float(), self.sd[f"{name}.bias"].float())
+            wp, g, c = Wm.fold_layernorm(w, b, *self._ln(norm))
+            return wp.to(self.device), Wm.f32(g, self.device), Wm.f32(c, self.device)
+        return self._memo(("gg_ln", name), f)
+
+    def cross_ln(self, prefix, ctx, heads, norm):
+        def f():
+            wqk, vot, npad = Wm.cross_attention_tables(
+                self.sd[f"{prefix}.to_q.weight"], self.sd[f"{prefix}.to_k.weight"],
+                self.sd[f"{prefix}.to_v.weight"], self.sd[f"{prefix}.to_out.0.weight"], ctx, heads)
+            wp, g, c = Wm.fold_layernorm(wqk, None, *self._ln(norm))
+            return wp.to(self.device), Wm.f32(g, self.device), Wm.f32(c, self.device), Wm.bf16(vot, self.device), npad
+        return self._memo(("x_ln", prefix), f)
 
     def cross(self, prefix, ctx, heads):
         def f():
@@ -317,15 +345,19 @@ class Builder:
         self.free(tmp)
 
     def dense(self, x, wt, bias, N, *, residual=None, out=None, epi=L.EPI_BF16, label="", K=None, out_dtype_bytes=2,
-              skip=None):
-        """x: Act viewed as [M][C]; wt: [N][K] bf16.  ``skip``: second channel source (K = x.C + skip.C)."""
+              skip=None, ln_out=None, ln=None):
+        """x: Act viewed as [M][C]; wt: [N][K] bf16.  ``skip``: second channel source (K = x.C + skip.C).  ``ln_out``:
+        buffer for the row statistics of the OUTPUT (the next LayerNorm's input); ``ln`` = (stats, g, c): the LayerNorm
+        of the INPUT is folded into this layer (x holds the raw rows)."""
         M, K = x.M, (K or x.C + (skip.C if skip is not None else 0))
         n_out = N // 2 if epi == L.EPI_GEGLU else N
         if out is None:
             out = Act(self.pool.get(M * n_out * out_dtype_bytes), x.B, x.H, x.W, n_out)
         self.add(O.linear(x.t, wt, out.t, M=M, K=K, N=N, bias=bias, epi=epi,
                           residual=None if residual is None else residual.t,
-                          a1=None if skip is None else skip.t, C0=x.C if skip is not None else 0), label)
+                          a1=None if skip is None else skip.t, C0=x.C if skip is not None else 0, ln_out=ln_out,
+                          ln_in=None if ln is None else ln[0], ln_g=None if ln is None else ln[1],
+                          ln_c=None if ln is None else ln[2]), label)
         return out
 
     def layer_norm(self, x, name):
@@ -366,54 +398,74 @@ class Builder:
         self.free(h1)
         return out
 
-    def self_attention(self, h, y, prefix, heads):
-        """h += to_out(attn(y)); y = LN(h) already computed.  Head dim 64."""
+    def self_attention(self, h, st, prefix, norm, heads, st_out):
+        """h += to_out(attn(LN(h))) with the LayerNorm folded into the fused QKV projection (``st`` = row statistics of
+        h from its producer); the to_out epilogue writes the statistics of the new h into ``st_out``.  Head dim 64."""
         C, B, T, M = h.C, h.B, h.HW, h.M
-        wqkv, _ = self.ws.qkv(prefix, False)
         ldvt = (T + 63) // 64 * 64
         qk = self.raw(M * 2 * C * 2)
         vt = self.zeros_persistent(("vt", B, C, ldvt), B * C * ldvt * 2)
-        self.add(O.igemm(y.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, out2=vt,
-                         trans_from=2 * C, ldt=ldvt), f"{prefix}.qkv")
+        if st is not None:
+            wqkv, g, c = self.ws.qkv_ln(prefix, norm)
+            self.add(O.igemm(h.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, out2=vt,
+                             trans_from=2 * C, ldt=ldvt, ln_in=st, ln_g=g, ln_c=c), f"{prefix}.qkv")
+        else:   # A/B form: the LayerNorm as its own pass
+            y = self.layer_norm(h, norm)
+            self.add(O.igemm(y.t, self.ws.qkv(prefix, False)[0], qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C,
+                             out2=vt, trans_from=2 * C, ldt=ldvt), f"{prefix}.qkv")
+            self.free(y)
         o = self.new(h.B, h.H, h.W, C)
         self.add(O.flash_attn64(qk, qk.data_ptr() + C * 2, vt, o.t, B=B, heads=heads, Ntok=T, ldq=2 * C,
                                 ldo=C, ldvt=ldvt, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C,
                                 scale=1.0 / math.sqrt(C // heads)), f"{prefix}.flash")
         self.free(qk)
         self.dense(o, self.ws.mat(f"{prefix}.to_out.0"), self.ws.bias(f"{prefix}.to_out.0"), C,
-                   residual=h, out=h, label=f"{prefix}.to_out")
+                   residual=h, out=h, label=f"{prefix}.to_out", ln_out=st_out)
         self.free(o)
 
-    def cross_attention2(self, h, y, prefix, heads, ctx):
-        """h += attn2(y, ctx) with the 2-token context collapsed into two thin GEMMs."""
+    def cross_attention2(self, h, st, prefix, norm, heads, ctx, st_out):
+        """h += attn2(LN(h), ctx) with the 2-token context collapsed into two thin GEMMs and the LayerNorm folded into
+        the first one."""
         C, M = h.C, h.M
-        wqk, vot, npad = self.ws.cross(prefix, ctx, heads)
-        s = self.raw(M * npad * 4)
-        self.add(O.linear(y.t, wqk, s, M=M, K=C, N=npad, epi=L.EPI_F32), f"{prefix}.scores")
+        if st is not None:
+            wqk, g, c, vot, npad = self.ws.cross_ln(prefix, ctx, heads, norm)
+            s = self.raw(M * npad * 4)
+            self.add(O.linear(h.t, wqk, s, M=M, K=C, N=npad, epi=L.EPI_F32, ln_in=st, ln_g=g, ln_c=c), f"{prefix}.scores")
+        else:
+            wqk, vot, npad = self.ws.cross(prefix, ctx, heads)
+            s = self.raw(M * npad * 4)
+            y = self.layer_norm(h, norm)
+            self.add(O.linear(y.t, wqk, s, M=M, K=C, N=npad, epi=L.EPI_F32), f"{prefix}.scores")
+            self.free(y)
         p = self.raw(M * npad * 2)
         self.add(O.softmax_pairs(s, p, M=M, pairs=heads, lds=npad, ldp=npad,
                                  scale=1.0 / math.sqrt(C // heads)), f"{prefix}.softmax2")
         self.add(O.linear(p, vot, h.t, M=M, K=npad, N=C, bias=self.ws.bias(f"{prefix}.to_out.0"),
-                          residual=h.t), f"{prefix}.blend")
+                          residual=h.t, ln_out=st_out), f"{prefix}.blend")
         self.free(s, p)
 
     def transformer(self, x, name, heads, ctx):
+        """diffusers Transformer2DModel / BasicTransformerBlock.  The three LayerNorms never run as passes: each Linear
+        that consumes one takes the raw residual stream and corrects in its epilogue (MG_OP_IGEMM ln_in), with the row
+        statistics written by the epilogue of the GEMM that produced the stream (ln_out)."""
         C = x.C
         g = self.group_norm(x, f"{name}.norm", 1e-6, False)
+        st = [self.raw(x.M * (C // 32) * 8) if FOLD_LN else None for _ in range(3)]
         h = self.dense(g, self.ws.mat(f"{name}.proj_in"), self.ws.bias(f"{name}.proj_in"), C,
-                       label=f"{name}.proj_in")
+                       label=f"{name}.proj_in", ln_out=st[0])
         self.free(g)
         b = f"{name}.transformer_blocks.0"
-        y = self.layer_norm(h, f"{b}.norm1")
-        self.self_attention(h, y, f"{b}.attn1", heads)
-        self.free(y)
-        y = self.layer_norm(h, f"{b}.norm2")
-        self.cross_attention2(h, y, f"{b}.attn2", heads, ctx)
-        self.free(y)
-        y = self.layer_norm(h, f"{b}.norm3")
-        wg, bg = self.ws.geglu(f"{b}.ff.net.0.proj")
-        ff = self.dense(y, wg, bg, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu")
-        self.free(y)
+        self.self_attention(h, st[0], f"{b}.attn1", f"{b}.norm1", heads, st[1])
+        self.cross_attention2(h, st[1], f"{b}.attn2", f"{b}.norm2", heads, ctx, st[2])
+        if FOLD_LN:
+            wg, gg, cg = self.ws.geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3")
+            ff = self.dense(h, wg, None, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu", ln=(st[2], gg, cg))
+        else:
+            y = self.layer_norm(h, f"{b}.norm3")
+            wg, bg = self.ws.geglu(f"{b}.ff.net.0.proj")
+            ff = self.dense(y, wg, bg, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu")
+            self.free(y)
+        self.free(*st)
         self.dense(ff, self.ws.mat(f"{b}.ff.net.2"), self.ws.bias(f"{b}.ff.net.2"), C, residual=h, out=h,
                    label=f"{b}.ff.out")
         self.free(ff)

@@ -93,3 +93,16 @@ def cross_attention_tables(wq, wk, wv, wo, ctx, heads):
             wqk[2 * h + j] = k[j, sl] @ wq[sl, :]          # (Wq_h^T k_jh)[c] = sum_d Wq[hd,c] k[j,hd]
             vot[:, 2 * h + j] = wo[:, sl] @ v[j, sl]
     return wqk.float(), vot.float(), npad
+
+
+def fold_layernorm(w, bias, gamma, beta):
+    """LayerNorm folded into the Linear layer that consumes it (MG_OP_IGEMM ln_in): y = LN(x) W^T + b
+    = rstd * (x (W gamma)^T - mean * g) + c  with  g[n] = sum_k (W gamma)[n][k],  c[n] = sum_k beta[k] W[n][k] + b[n].
+    ``w`` [N][K] fp32 (rows already in the kernel's order), ``bias`` [N] | None.  Returns (W gamma as bf16, g, c); g sums
+    the ROUNDED weights, so a constant row x = a gives exactly c (the kernel's x (W gamma)^T - mean g cancels)."""
+    wp = (w.double() * gamma.double()[None, :]).float().to(torch.bfloat16)
+    g = wp.double().sum(dim=1).float()
+    c = w.double() @ beta.double()
+    if bias is not None:
+        c = c + bias.double()
+    return wp.contiguous(), g.contiguous(), c.float().contiguous()

@@ -420,6 +420,72 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
         _close(f"scores_f32/v{variant}", S, refS, tol=2e-3)
 
 
+def test_igemm_layernorm_fold(dev):
+    """LayerNorm folded into the Linear that consumes it (MG_OP_IGEMM ln_in) and the row statistics taken in the
+    producer's epilogue (ln_out), against torch layer_norm + linear in fp32: bf16 / fp32 / GEGLU epilogues, the
+    transposed (V^T) section and several tiles."""
+    from marigold_amd import _lib as L, ops, weights as Wm
+    g = torch.Generator().manual_seed(21)
+    M, C = 700, 320
+    x = _bf(torch.randn(M, C, generator=g) * 1.3 + 0.4 * torch.randn(M, 1, generator=g))    # rows with their own means
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    xd = x.to(dev, torch.bfloat16)
+    # --- producer: out = a @ w^T + b + res, ln_out = per-row (sum, sum of squares) over 32-column slots
+    K0 = 192
+    a = _bf(torch.randn(M, K0, generator=g))
+    w0 = _bf(torch.randn(C, K0, generator=g) / math.sqrt(K0))
+    b0 = torch.randn(C, generator=g) * 0.1
+    res = _bf(torch.randn(M, C, generator=g))
+    ref0 = a @ w0.t() + b0 + res
+    for variant in (0, 46, 53, 35, 62):
+        out = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        st = torch.full((M, C // 32, 2), float("nan"), device=dev)
+        _run(ops.linear(a.to(dev, torch.bfloat16), w0.to(dev, torch.bfloat16), out, M=M, K=K0, N=C, bias=b0.to(dev),
+                        residual=res.to(dev, torch.bfloat16), ln_out=st, variant=variant))
+        want = torch.stack([ref0.reshape(M, C // 32, 32).sum(-1), (ref0 ** 2).reshape(M, C // 32, 32).sum(-1)], dim=-1)
+        _close(f"ln_out/v{variant}", st, want, tol=2e-4)
+    # statistics of x itself for the consumers (what a producer would have written)
+    stx = torch.stack([x.reshape(M, C // 32, 32).sum(-1), (x ** 2).reshape(M, C // 32, 32).sum(-1)], dim=-1).to(dev).contiguous()
+    # --- consumer, bf16 and fp32 epilogues
+    N = 640
+    w = torch.randn(N, C, generator=g) / math.sqrt(C)
+    b = torch.randn(N, generator=g) * 0.1
+    wp, gv, cv = Wm.fold_layernorm(w, b, gamma, beta)
+    ref = y @ w.t() + b
+    for variant in (0, 20, 46, 53, 62):
+        out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.linear(xd, wp.to(dev), out, M=M, K=C, N=N, ln_in=stx, ln_g=gv.to(dev), ln_c=cv.to(dev), variant=variant))
+        _close(f"ln_fold/bf16/v{variant}", out, ref, tol=2e-2)
+    outf = torch.full((M, N), float("nan"), device=dev)
+    _run(ops.linear(xd, wp.to(dev), outf, M=M, K=C, N=N, epi=L.EPI_F32, ln_in=stx, ln_g=gv.to(dev), ln_c=cv.to(dev)))
+    _close("ln_fold/f32", outf, ref, tol=1.5e-2)
+    # --- GEGLU epilogue
+    wg = torch.randn(8 * C, C, generator=g) / math.sqrt(C)
+    bg = torch.randn(8 * C, generator=g) * 0.1
+    u, gt = (y @ wg.t() + bg).chunk(2, dim=-1)
+    refg = u * F.gelu(gt)
+    wpk, bpk = Wm.pack_geglu(wg, bg)
+    wpg, gg, cg = Wm.fold_layernorm(wpk, bpk, gamma, beta)
+    for variant in (0, 53, 62):
+        og = torch.full((M, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.linear(xd, wpg.to(dev), og, M=M, K=C, N=8 * C, epi=L.EPI_GEGLU, ln_in=stx, ln_g=gg.to(dev), ln_c=cg.to(dev),
+                        variant=variant))
+        _close(f"ln_fold/geglu/v{variant}", og, refg, tol=2e-2)
+    # --- fused QKV with the transposed V section (B images x T tokens)
+    B, T = 2, 350
+    wq = torch.randn(3 * C, C, generator=g) / math.sqrt(C)
+    wpq, gq, cq = Wm.fold_layernorm(wq, None, gamma, beta)
+    refq = y @ wq.t()
+    ldt = 384
+    qk = torch.full((M, 2 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+    vt = torch.zeros((B, C, ldt), device=dev, dtype=torch.bfloat16)
+    _run(ops.igemm(xd, wpq.to(dev), qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, out2=vt, trans_from=2 * C, ldt=ldt,
+                   ln_in=stx, ln_g=gq.to(dev), ln_c=cq.to(dev)))
+    _close("ln_fold/qkv/qk", qk, refq[:, :2 * C], tol=2e-2)
+    _close("ln_fold/qkv/vt", vt[:, :, :T], refq[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1), tol=2e-2)
+
+
 def test_igemm_pingpong_short_k_and_repeatability(dev):
     """Tile variant 60 (two wave groups one barrier apart, four phases per K tile): the one- and two-tile K loops
     (prologue / drain only), and a many-tile problem launched repeatedly - every launch must give the same bits
