@@ -233,26 +233,55 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-  // folded LayerNorm: (mean, rstd) of the tile's BM rows, kept in LDS behind the ring for the epilogue (the K loop's
-  // barriers publish them)
+  // folded LayerNorm: (mean, rstd) of the tile's BM rows, kept in LDS behind the ring for the epilogue.  NT / BM threads
+  // share a row (fixed slot -> thread assignment, fp64 sums: reproducible).  The slot loads are issued HERE, ahead of the
+  // first LDS-DMA stage, into registers and only consumed after the K loop: their latency hides under tile 0's, and no
+  // compiler-inserted vmcnt(0) sits between the DMA prologue and the first K step (rows wider than LNR * TS slots -
+  // the 1280-channel levels - take the slots after the loop instead).
   float2* const lnst = (float2*)(smem + NSTAGE * STAGE);
-  if (a.ln_in) {
-    for (int r = tid; r < BM; r += NT) {
-      const int m = m0 + r;
-      float2 st = make_float2(0.f, 1.f);
-      if (m < a.M) {
-        const float2* p = a.ln_in + (long long)m * a.ln_slots;
-        double sd = 0.0, qd = 0.0;
-        for (int sl = 0; sl < a.ln_slots; ++sl) { const float2 v = p[sl]; sd += (double)v.x; qd += (double)v.y; }
-        const double mean = sd / (double)a.Cin;
-        double var = qd / (double)a.Cin - mean * mean;
-        if (var < 0.0) var = 0.0;
-        st = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)a.ln_eps)));
-      }
-      lnst[r] = st;
+  constexpr int LN_TS = NT >= BM ? (NT / BM >= 4 ? 4 : NT / BM) : 1;   // threads per row (a power of two <= 4)
+  constexpr int LNR = MI * NI * 16 >= 128 ? 1 : 8;   // the 128-accumulator tiles have no registers to spare (slots after the loop)
+  static_assert(BM * LN_TS <= NT || LN_TS == 1, "one row per thread");
+  const int ln_r = tid / LN_TS, ln_sub = tid % LN_TS;
+  const bool ln_row = a.ln_in && ln_r < BM && m0 + ln_r < a.M;
+  const bool ln_regs = a.ln_in && LNR > 1 && a.ln_slots <= LNR * LN_TS;
+  float2 lnreg[LNR];
+  if (ln_regs) {
+    const float2* p = a.ln_in + (long long)(m0 + ln_r) * a.ln_slots;
+#pragma unroll
+    for (int i = 0; i < LNR; ++i) {
+      const int sl = ln_sub + i * LN_TS;
+      lnreg[i] = (ln_row && sl < a.ln_slots) ? p[sl] : make_float2(0.f, 0.f);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  auto ln_finish = [&]() {   // after the K loop: reduce the slots, publish (mean, rstd) of the tile's rows
+    if (!a.ln_in) return;
+    for (int r0 = 0; r0 < BM; r0 += NT / LN_TS) {   // one pass unless NT < BM
+      const int r = r0 + ln_r;
+      const int m = m0 + r;
+      double sd = 0.0, qd = 0.0;
+      if (ln_regs) {
+#pragma unroll
+        for (int i = 0; i < LNR; ++i) { sd += (double)lnreg[i].x; qd += (double)lnreg[i].y; }
+      } else if (r < BM && m < a.M) {
+        const float2* p = a.ln_in + (long long)m * a.ln_slots;
+        for (int sl = ln_sub; sl < a.ln_slots; sl += LN_TS) { const float2 v = p[sl]; sd += (double)v.x; qd += (double)v.y; }
+      }
+#pragma unroll
+      for (int o = LN_TS / 2; o > 0; o >>= 1) { sd += __shfl_xor(sd, o); qd += __shfl_xor(qd, o); }
+      if (r < BM && ln_sub == 0) {
+        float2 st = make_float2(0.f, 1.f);
+        if (m < a.M) {
+          const double mean = sd / (double)a.Cin;
+          double var = qd / (double)a.Cin - mean * mean;
+          if (var < 0.0) var = 0.0;
+          st = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)a.ln_eps)));
+        }
+        lnst[r] = st;
+      }
+    }
+    __syncthreads();
+  };
 
   int rowA[MI], rowB[NI];
 #pragma unroll
@@ -527,6 +556,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   }
 
   // ---------------- epilogue ----------------
+  ln_finish();
   const float scale = a.scale;
   if constexpr (!TRANS) {
     if (a.epi == MG_EPI_GEGLU) {
@@ -543,20 +573,27 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
           const int nb = n0 + wn * TN + ni * 32;
           const bool nok = nb < a.n_end;
           float r[8];
+          // per-column vectors of this lane's four 4-column groups (u: +0, +8; gates: +16, +24), 16-byte loads
+          const int nu0 = nb + 4 * half;
+          float bq[4][4], gq[4][4], cq[4][4];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 bv = (a.bias && nok) ? *(const float4*)(a.bias + nu0 + 8 * q4) : z4;
+            const float4 gv = (a.ln_in && nok) ? *(const float4*)(a.ln_g + nu0 + 8 * q4) : z4;
+            const float4 cv = (a.ln_in && nok) ? *(const float4*)(a.ln_c + nu0 + 8 * q4) : z4;
+            bq[q4][0] = bv.x; bq[q4][1] = bv.y; bq[q4][2] = bv.z; bq[q4][3] = bv.w;
+            gq[q4][0] = gv.x; gq[q4][1] = gv.y; gq[q4][2] = gv.z; gq[q4][3] = gv.w;
+            cq[q4][0] = cv.x; cq[q4][1] = cv.y; cq[q4][2] = cv.z; cq[q4][3] = cv.w;
+          }
+          const float lsc = a.ln_in ? lst.y : 1.f, lmr = a.ln_in ? lst.y * lst.x : 0.f;   // rstd, mean * rstd
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int nu = nb + 4 * half + j;
-            float u0 = acc[ni][mi][j] * scale, u1 = acc[ni][mi][4 + j] * scale;
-            float t0 = acc[ni][mi][8 + j] * scale, t1 = acc[ni][mi][12 + j] * scale;
-            if (a.ln_in && nok) {
-              u0 = lst.y * (u0 - lst.x * a.ln_g[nu]) + a.ln_c[nu];
-              u1 = lst.y * (u1 - lst.x * a.ln_g[nu + 8]) + a.ln_c[nu + 8];
-              t0 = lst.y * (t0 - lst.x * a.ln_g[nu + 16]) + a.ln_c[nu + 16];
-              t1 = lst.y * (t1 - lst.x * a.ln_g[nu + 24]) + a.ln_c[nu + 24];
-            }
-            if (a.bias && nok) {
-              u0 += a.bias[nu]; u1 += a.bias[nu + 8]; t0 += a.bias[nu + 16]; t1 += a.bias[nu + 24];
-            }
+            // folded LayerNorm: rstd * (acc - mean g) + c = rstd acc + (c - mean rstd g); then the Linear's bias
+            const float u0 = __builtin_fmaf(acc[ni][mi][j] * scale, lsc, cq[0][j] - lmr * gq[0][j]) + bq[0][j];
+            const float u1 = __builtin_fmaf(acc[ni][mi][4 + j] * scale, lsc, cq[1][j] - lmr * gq[1][j]) + bq[1][j];
+            const float t0 = __builtin_fmaf(acc[ni][mi][8 + j] * scale, lsc, cq[2][j] - lmr * gq[2][j]) + bq[2][j];
+            const float t1 = __builtin_fmaf(acc[ni][mi][12 + j] * scale, lsc, cq[3][j] - lmr * gq[3][j]) + bq[3][j];
             const float o0 = u0 * gelu_erf_f(t0);  // channel 16i + 4h + j
             const float o1 = u1 * gelu_erf_f(t1);  // channel 16i + 8 + 4h + j
             half_swap(o0, o1, r[j], r[4 + j]);
@@ -983,7 +1020,9 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
   // two 8-wave workgroups per CU (GEGLU 525-780 vs 485-770 for 256x256 and 400-700 for the 64-deep tile)
   const bool many256 = N % 256 == 0 && tm256 * (N / 256) * batch_z >= 512;
   if (geglu && K >= 1280 && many256) return 62;   // 1280 -> 10240: 831 vs 760-790
-  if (N % 128 == 0 && tm256 * (N / 128) * batch_z >= 400 && (geglu || K <= 768)) return 53;
+  // (round 2, profiles/r2_sweep5_short_k_tiles.log: the 4-wave form of the same tile - wave tile 128x64, half the
+  // fragment reads per MFMA - is 10-13 % ahead of the 8-wave one on the GEGLU projections and the 640-channel linears)
+  if (N % 128 == 0 && tm256 * (N / 128) * batch_z >= 400 && (geglu || K <= 768)) return 51;
   // 256x256 with the ping-pong schedule (two wave groups one barrier apart, 2nd DMA piece among the MFMAs):
   // +3...10 % over the one-barrier 256x256 tile in interleaved rounds (VAE 512-channel convs 1068 vs 996)
   if (many256) return 62;
