@@ -55,14 +55,19 @@ def pmc_traffic(kernel_class):
     """HBM bytes per launch of the dominant kernel class from the rocprofv3 PMC passes of THIS command
     (scripts/gpu_round.sh pmc: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
     /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes for gfx950's wide coalesced reads),
-    committed as profiles/r1_pmc_hbm_traffic.json.  PMC counters cannot be read from inside the timed
-    process, so the figure is the one measured offline for the same workload; None if absent."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
+    committed as profiles/r<N>_pmc_hbm_traffic.json (the newest round present is used).  PMC counters cannot be read
+    from inside the timed process, so the figure is the one measured offline for the same workload; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    path = files[-1]
     try:
         with open(path) as f:
             t = json.load(f).get(kernel_class)
+        rel = os.path.relpath(path, ROOT)
         return None if t is None else {"bytes_per_launch": t["bytes_per_launch"], "launches": t["launches"],
-                                       "source": "profiles/r1_pmc_hbm_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE)"}
+                                       "source": f"{rel} (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE)"}
     except (OSError, ValueError, KeyError):
         return None
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Turns the two rocprofv3 --pmc passes of bench.py (gpurun_out/pmc_fetch, gpurun_out/pmc_write; made by
-`scripts/gpu_round.sh pmc`) into profiles/r1_pmc_hbm_traffic.{csv,json}: HBM bytes per launch per kernel,
-FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads - MI355X_MICROARCH.md, HBM)."""
+`scripts/gpu_round.sh pmc`) into profiles/<round>_pmc_hbm_traffic.{csv,json}: HBM bytes per launch per kernel,
+FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads - MI355X_MICROARCH.md, HBM).
+Usage: python tools/pmc_traffic.py [round tag, default r2]"""
 import collections
 import csv
 import json
@@ -26,12 +27,14 @@ def load(path, name):
 
 
 def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
     base = os.path.join(ROOT, "gpurun_out")
-    f = load(os.path.join(base, "pmc_fetch", "r1_counter_collection.csv"), "FETCH_SIZE")
-    w = load(os.path.join(base, "pmc_write", "r1_counter_collection.csv"), "WRITE_SIZE")
-    classes = {"igemm_mfma": "igemm2_", "flash_attn64": "flash_attn64", "groupnorm": "gn_", "layernorm": "layernorm"}
+    f = load(os.path.join(base, "pmc_fetch", "r2_counter_collection.csv"), "FETCH_SIZE")
+    w = load(os.path.join(base, "pmc_write", "r2_counter_collection.csv"), "WRITE_SIZE")
+    classes = {"igemm_mfma": "igemm2_", "conv3x3_patch": "conv_patch_", "flash_attn64": "flash_attn64", "groupnorm": "gn_",
+               "layernorm": "layernorm"}
     out = {}
-    with open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.csv"), "w") as c:
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.csv"), "w") as c:
         c.write("kernel,launches,FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum,hbm_MB_per_launch_corrected\n")
         for k in sorted(f, key=lambda k: -f[k][1]):
             n, fs = f[k]
@@ -44,7 +47,7 @@ def main():
         if n:
             out[cls] = {"launches": n, "bytes_per_launch": (2 * fs + ws) * 1024 / n,
                         "fetch_kb_sum": fs, "write_kb_sum": ws}
-    with open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json"), "w") as j:
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json"), "w") as j:
         json.dump(out, j, indent=1)
     print(json.dumps(out, indent=1))
 
