@@ -16,6 +16,8 @@
 //     output channels of one pixel -> 16-byte NHWC stores / residual loads (32-byte for fp32),
 //     v_cvt_pk_bf16_f32 instead of integer rounding.  GEGLU pairs u/gate rows 16 apart (32-row
 //     interleave, weights.py::pack_geglu) so it keeps the 16-byte stores too.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -51,6 +53,7 @@ struct Igemm2Args {
   float2* ln_out;
   int ln_slots;
   float ln_eps;
+  int gelu_erf;   // A/B: 1 = GELU through the Abramowitz-Stegun erf (two transcendentals) instead of the polynomial CDF
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -586,16 +589,22 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
             gq[q4][0] = gv.x; gq[q4][1] = gv.y; gq[q4][2] = gv.z; gq[q4][3] = gv.w;
             cq[q4][0] = cv.x; cq[q4][1] = cv.y; cq[q4][2] = cv.z; cq[q4][3] = cv.w;
           }
-          const float lsc = a.ln_in ? lst.y : 1.f, lmr = a.ln_in ? lst.y * lst.x : 0.f;   // rstd, mean * rstd
+          // folded LayerNorm: rstd * (acc - mean g) + c = (rstd scale) acc + (c - mean rstd g); the Linear's own bias is
+          // part of c there, and the only offset otherwise: two fused multiply-adds per accumulator either way
+          const float lsc = (a.ln_in ? lst.y : 1.f) * scale, lmr = a.ln_in ? -lst.y * lst.x : 0.f;
+          float off[4][4];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) off[q4][j] = __builtin_fmaf(lmr, gq[q4][j], cq[q4][j] + bq[q4][j]);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            // folded LayerNorm: rstd * (acc - mean g) + c = rstd acc + (c - mean rstd g); then the Linear's bias
-            const float u0 = __builtin_fmaf(acc[ni][mi][j] * scale, lsc, cq[0][j] - lmr * gq[0][j]) + bq[0][j];
-            const float u1 = __builtin_fmaf(acc[ni][mi][4 + j] * scale, lsc, cq[1][j] - lmr * gq[1][j]) + bq[1][j];
-            const float t0 = __builtin_fmaf(acc[ni][mi][8 + j] * scale, lsc, cq[2][j] - lmr * gq[2][j]) + bq[2][j];
-            const float t1 = __builtin_fmaf(acc[ni][mi][12 + j] * scale, lsc, cq[3][j] - lmr * gq[3][j]) + bq[3][j];
-            const float o0 = u0 * gelu_erf_f(t0);  // channel 16i + 4h + j
-            const float o1 = u1 * gelu_erf_f(t1);  // channel 16i + 8 + 4h + j
+            const float u0 = __builtin_fmaf(acc[ni][mi][j], lsc, off[0][j]);
+            const float u1 = __builtin_fmaf(acc[ni][mi][4 + j], lsc, off[1][j]);
+            const float t0 = __builtin_fmaf(acc[ni][mi][8 + j], lsc, off[2][j]);
+            const float t1 = __builtin_fmaf(acc[ni][mi][12 + j], lsc, off[3][j]);
+            const float o0 = u0 * (a.gelu_erf ? gelu_erf_f(t0) : gelu_poly_f(t0));  // channel 16i + 4h + j
+            const float o1 = u1 * (a.gelu_erf ? gelu_erf_f(t1) : gelu_poly_f(t1));  // channel 16i + 8 + 4h + j
             half_swap(o0, o1, r[j], r[4 + j]);
           }
           if (m < a.M && nok) {
@@ -929,6 +938,10 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.ln_c = (const float*)op->p[11];
   a.ln_slots = op->i[26];
   a.ln_eps = op->f[1];
+  {
+    static const int erf_ab = [] { const char* e = getenv("MARIGOLD_GELU_ERF"); return (e && e[0] == '1') ? 1 : 0; }();
+    a.gelu_erf = erf_ab;
+  }
   if (a.ln_out) {
     MG_REQUIRE(a.epi == MG_EPI_BF16 && trans_from < 0 && a.N % 32 == 0 && batch_z == 1 && (uintptr_t)a.ln_out % 8 == 0,
                "igemm: row statistics (ln_out) need the bf16 epilogue, N %% 32 == 0, no transposed section / batching");
