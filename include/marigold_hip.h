@@ -167,7 +167,9 @@ enum mg_op_kind {
   MG_OP_COPY = 31    /* p[0] src p[1] dst ; l[0] bytes (device to device) */
 };
 
-enum { MG_EPI_BF16 = 0, MG_EPI_GEGLU = 1, MG_EPI_F32 = 2 };
+enum { MG_EPI_BF16 = 0, MG_EPI_GEGLU = 1, MG_EPI_F32 = 2,
+       MG_EPI_SOFTMAX2 = 3 /* bf16 out = softmax over column pairs (2h, 2h+1) of f[2] * acc; i[27] = real columns, the rest -> 0:
+                              the collapsed 2-token cross-attention's probabilities straight from the scores GEMM */ };
 enum { MG_POST_NONE = 0, MG_POST_DEPTH = 1, MG_POST_NORMALS = 2, MG_POST_UNIT = 3 /* IID: clip, (x+1)/2 */,
        MG_POST_SCHED = 4 /* scheduler update in place of the store, see MG_OP_POST_NCHW */ };
 

@@ -53,6 +53,8 @@ struct Igemm2Args {
   float2* ln_out;
   int ln_slots;
   float ln_eps;
+  float sm_scale;  // MG_EPI_SOFTMAX2: softmax scale and the number of real score columns (2 x heads)
+  int sm_cols;
   int gelu_erf;   // A/B: 1 = GELU through the Abramowitz-Stegun erf (two transcendentals) instead of the polynomial CDF
 };
 
@@ -677,6 +679,19 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
               float* o = (float*)a.out + (long long)z * a.sO + orow * a.ldo + n;
               *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
               *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else if (a.epi == MG_EPI_SOFTMAX2) {
+              // 2-key softmax of the collapsed cross-attention (columns 2h, 2h+1 = the two context tokens of head h) taken
+              // on the accumulators: the fp32 scores never reach HBM and no softmax launch follows.  Pad columns -> 0.
+              uint32_t w4[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float s0 = v[2 * k] * a.sm_scale, s1 = v[2 * k + 1] * a.sm_scale;
+                const float mx = fmaxf(s0, s1);
+                const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx);
+                const float inv = 1.0f / (e0 + e1);
+                w4[k] = (n + 2 * k < a.sm_cols) ? pack2bf(e0 * inv, e1 * inv) : 0u;
+              }
+              *(uint4*)((bf16_t*)a.out + (long long)z * a.sO + orow * a.ldo + n) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
             } else {
               if (a.res) {
                 const uint4 r4 = *(const uint4*)(a.res + (long long)z * a.sR + (long long)m * a.ldr + n);
@@ -938,6 +953,11 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.ln_c = (const float*)op->p[11];
   a.ln_slots = op->i[26];
   a.ln_eps = op->f[1];
+  a.sm_scale = op->f[2];
+  a.sm_cols = op->i[27];
+  if (a.epi == MG_EPI_SOFTMAX2)
+    MG_REQUIRE(trans_from < 0 && batch_z == 1 && a.sm_cols > 0 && a.sm_cols % 2 == 0 && a.sm_cols <= a.N && !a.res,
+               "igemm: the pair-softmax epilogue takes an even number of score columns <= N, no residual / transposed section");
   {
     static const int erf_ab = [] { const char* e = getenv("MARIGOLD_GELU_ERF"); return (e && e[0] == '1') ? 1 : 0; }();
     a.gelu_erf = erf_ab;

@@ -428,9 +428,16 @@ class Builder:
         the first one."""
         C, M = h.C, h.M
         if st is not None:
+            # scores GEMM with the LayerNorm folded in and the 2-key softmax as its epilogue: probabilities out, no fp32
+            # scores in HBM, no softmax launch
             wqk, g, c, vot, npad = self.ws.cross_ln(prefix, ctx, heads, norm)
-            s = self.raw(M * npad * 4)
-            self.add(O.linear(h.t, wqk, s, M=M, K=C, N=npad, epi=L.EPI_F32, ln_in=st, ln_g=g, ln_c=c), f"{prefix}.scores")
+            p = self.raw(M * npad * 2)
+            self.add(O.linear(h.t, wqk, p, M=M, K=C, N=npad, epi=L.EPI_SOFTMAX2, ln_in=st, ln_g=g, ln_c=c,
+                              sm_scale=1.0 / math.sqrt(C // heads), sm_cols=2 * heads), f"{prefix}.scores+softmax2")
+            self.add(O.linear(p, vot, h.t, M=M, K=npad, N=C, bias=self.ws.bias(f"{prefix}.to_out.0"),
+                              residual=h.t, ln_out=st_out), f"{prefix}.blend")
+            self.free(p)
+            return
         else:
             wqk, vot, npad = self.ws.cross(prefix, ctx, heads)
             s = self.raw(M * npad * 4)

@@ -30,7 +30,7 @@ def op_cost(op):
         M, K = B * Ho * Wo, taps * Cin
         flops = 2 * M * (i[22] or N) * (i[23] or K) * bz   # i[22] / i[23]: un-padded N / K of the boundary convs
         n_out = N // 2 if epi == L.EPI_GEGLU else N
-        osz = 4 if epi == L.EPI_F32 else 2
+        osz = 4 if epi == L.EPI_F32 else 2   # bf16 for the plain, GEGLU and pair-softmax epilogues
         if taps == 4:   # sub-pixel up-sampling conv: the 4 parities share one input, each writes its own output pixels
             byts = B * H * W * Cin * 2 + bz * (N * K * 2 + M * n_out * osz)
         else:

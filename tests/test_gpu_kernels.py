@@ -486,6 +486,31 @@ def test_igemm_layernorm_fold(dev):
     _close("ln_fold/qkv/vt", vt[:, :, :T], refq[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1), tol=2e-2)
 
 
+def test_igemm_pair_softmax_epilogue(dev):
+    """MG_EPI_SOFTMAX2: the collapsed cross-attention's probabilities straight from the scores GEMM (LayerNorm folded in),
+    against layer_norm -> linear -> softmax over the key pair in torch fp32; pad columns must come out zero."""
+    from marigold_amd import _lib as L, ops, weights as Wm
+    g = torch.Generator().manual_seed(31)
+    for M, C, heads in ((900, 320, 5), (333, 640, 10), (130, 1280, 20)):
+        npad = 64
+        x = _bf(torch.randn(M, C, generator=g) * 1.2 + 0.3 * torch.randn(M, 1, generator=g))
+        gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+        wqk = torch.zeros(npad, C)
+        wqk[:2 * heads] = torch.randn(2 * heads, C, generator=g) * (3.0 / math.sqrt(C))
+        scale = 1.0 / math.sqrt(64)
+        y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+        sc = (y @ wqk.t())[:, :2 * heads].reshape(M, heads, 2) * scale
+        ref = torch.zeros(M, npad)
+        ref[:, :2 * heads] = torch.softmax(sc, dim=-1).reshape(M, 2 * heads)
+        wp, gv, cv = Wm.fold_layernorm(wqk, None, gamma, beta)
+        stx = torch.stack([x.reshape(M, C // 32, 32).sum(-1), (x ** 2).reshape(M, C // 32, 32).sum(-1)], dim=-1).to(dev).contiguous()
+        out = torch.full((M, npad), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.linear(x.to(dev, torch.bfloat16), wp.to(dev), out, M=M, K=C, N=npad, epi=L.EPI_SOFTMAX2, ln_in=stx,
+                        ln_g=gv.to(dev), ln_c=cv.to(dev), sm_scale=scale, sm_cols=2 * heads))
+        _close(f"pair softmax epilogue C{C}", out, ref, tol=1.5e-2)
+        assert (out[:, 2 * heads:] == 0).all()
+
+
 def test_igemm_pingpong_short_k_and_repeatability(dev):
     """Tile variant 60 (two wave groups one barrier apart, four phases per K tile): the one- and two-tile K loops
     (prologue / drain only), and a many-tile problem launched repeatedly - every launch must give the same bits
