@@ -107,13 +107,30 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 // Bijective XCD-aware remap of a linear workgroup id: consecutive remapped ids live on the
 // same XCD (hardware places block b on XCD b % 8), so neighbouring tiles share that XCD's L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int NX = 8;
-  int xcd = bid % NX, idx = bid / NX;
-  int q = nwg / NX, r = nwg % NX;
-  int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return start + idx;
+__device__ __forceinline__ int xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned NX = 8;
+  const unsigned xcd = bid % NX, idx = bid / NX;
+  const unsigned q = nwg / NX, r = nwg % NX;
+  const unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return (int)(start + idx);
 }
+
+// Division of x < 2^31 by a launch-time constant d >= 1 in three integer instructions (the compiler's generic 32-bit
+// division is ~25, and the GEMM prologue / epilogue run a dozen of them per thread - measured: half of the instructions a
+// short-K tile executes).  L = ceil(log2 d), m = ceil(2^(31+L) / d) < 2^32: floor(x / d) = (x * m) >> (31 + L) exactly,
+// since the error term x * (m d - 2^(31+L)) < 2^31 * d <= 2^(31+L).  Written as umulhi(2x, m) >> L so that d = 1 needs no case.
+struct mg_fastdiv {
+  uint32_t m, l;
+};
+inline mg_fastdiv mg_make_fastdiv(long long d) {
+  mg_fastdiv f;
+  uint32_t l = 0;
+  while ((1ull << l) < (unsigned long long)d) ++l;
+  f.l = l;
+  f.m = (uint32_t)(((1ull << (31 + l)) + (unsigned long long)d - 1) / (unsigned long long)d);   // d < 2^31: l <= 31
+  return f;
+}
+__device__ __forceinline__ int fdiv(int x, const mg_fastdiv f) { return (int)(__umulhi((uint32_t)x << 1, f.m) >> f.l); }
 
 #define MG_ZERO_BYTES (128 * 1024)
 extern void* g_zero_page;  // MG_ZERO_BYTES zero bytes in device memory (mg_init): padding source

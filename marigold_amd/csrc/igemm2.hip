@@ -56,6 +56,11 @@ struct Igemm2Args {
   float sm_scale;  // MG_EPI_SOFTMAX2: softmax scale and the number of real score columns (2 x heads)
   int sm_cols;
   int gelu_erf;   // A/B: 1 = GELU through the Abramowitz-Stegun erf (two transcendentals) instead of the polynomial CDF
+  // Launch-time constants of the index arithmetic (common.h: fdiv) and the straight-row switch: `lin` = Linear layer /
+  // conv1x1 (taps 1, stride 1, no padding / up-sampling), whose output row m reads input row m - no (image, y, x) split.
+  mg_fastdiv fd_per_z, fd_tiles, fd_tiles_n, fd_rpi, fd_wo, fd_cpt;
+  int lin;
+  double inv_cin;   // 1 / Cin (folded LayerNorm statistics)
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -121,11 +126,11 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tiles = a.tiles_m * a.tiles_n;
   const int per_z = tiles * a.splits;
-  const int z = bid / per_z;
+  const int z = fdiv(bid, a.fd_per_z);
   const int rz = bid - z * per_z;
-  const int split = rz / tiles;
+  const int split = fdiv(rz, a.fd_tiles);
   const int t = rz - split * tiles;
-  const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
+  const int tile_m = fdiv(t, a.fd_tiles_n), tile_n = t - tile_m * a.tiles_n;
   const int m0 = tile_m * BM, n0 = a.n_begin + tile_n * BN;
 
   const bf16_t* __restrict__ Ab = a.A + (long long)z * a.sA;
@@ -143,7 +148,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   const int pad_y = a.subpix ? 1 - (z >> 1) : a.pad, pad_x = a.subpix ? 1 - (z & 1) : a.pad;
   // ---- staging rows owned by this thread (fixed over the K loop) ----
   int a_by[A_IT], a_bx[A_IT], a_qoff[A_IT];
-  long long a_img[A_IT];
+  int a_img[A_IT];   // first pixel of the row's image (B * H * W < 2^31: M is an int)
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int ci = it * NT + tid;
@@ -152,12 +157,18 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     const int m = m0 + a_row_of(r);
     const bool ok = m < a.M;
     const int mm = ok ? m : 0;
-    const int img = mm / a.rows_per_img;
-    const int rem = mm - img * a.rows_per_img;
-    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-    a_by[it] = ok ? oy * a.stride - pad_y : -(1 << 28);  // rows beyond M never pass the bounds test
-    a_bx[it] = ox * a.stride - pad_x;
-    a_img[it] = (long long)img * a.H * a.W;
+    if (a.lin) {   // input row = output row: a_by carries it (negative beyond M), the (image, y, x) split is not needed
+      a_by[it] = ok ? m : -1;
+      a_bx[it] = 0;
+      a_img[it] = 0;
+    } else {
+      const int img = fdiv(mm, a.fd_rpi);
+      const int rem = mm - img * a.rows_per_img;
+      const int oy = fdiv(rem, a.fd_wo), ox = rem - oy * a.Wo;
+      a_by[it] = ok ? oy * a.stride - pad_y : -(1 << 28);  // rows beyond M never pass the bounds test
+      a_bx[it] = ox * a.stride - pad_x;
+      a_img[it] = img * a.H * a.W;
+    }
   }
   const char* b_ptr[B_IT];
 #pragma unroll
@@ -180,7 +191,13 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     int dy = 0, dx = 0;
     const bf16_t* __restrict__ Sb = second ? A1b : Ab;
     const int ld = second ? a.lda1 : a.lda;
-    if (a.tw > 1) { dy = tap / a.tw; dx = tap - dy * a.tw; }
+    if (a.lin) {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)
+        a_ptr[it] = a_by[it] >= 0 ? (const char*)(Sb + (long long)a_by[it] * ld + a_qoff[it]) : zero;
+      return;
+    }
+    if (a.tw > 1) { dy = a.tw == 3 ? (tap * 11) >> 5 : tap >> 1; dx = tap - dy * a.tw; }   // tap / tw for tap < 9
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       int iy = a_by[it] + dy, ix = a_bx[it] + dx;
@@ -189,11 +206,11 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
         if (a.up2) { iy >>= 1; ix >>= 1; }
         else { iy = ok ? (iy * a.H) / a.Hu : 0; ix = ok ? (ix * a.W) / a.Wu : 0; }
       }
-      const char* pv = (const char*)(Sb + (a_img[it] + (long long)iy * a.W + ix) * ld + a_qoff[it]);
+      const char* pv = (const char*)(Sb + (long long)(a_img[it] + iy * a.W + ix) * ld + a_qoff[it]);
       a_ptr[it] = ok ? pv : zero;
     }
   };
-  int i_tap = kt0 / a.cpt, i_c = kt0 - i_tap * a.cpt;  // (tap, channel tile) of the NEXT tile to issue
+  int i_tap = kt0 ? fdiv(kt0, a.fd_cpt) : 0, i_c = kt0 - i_tap * a.cpt;  // (tap, channel tile) of the NEXT tile to issue
   tap_setup(i_tap, i_c >= a.c0t);
   if (const int skip = i_c >= a.c0t ? i_c - a.c0t : i_c) {
 #pragma unroll
@@ -276,11 +293,10 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
       for (int o = LN_TS / 2; o > 0; o >>= 1) { sd += __shfl_xor(sd, o); qd += __shfl_xor(qd, o); }
       if (r < BM && ln_sub == 0) {
         float2 st = make_float2(0.f, 1.f);
-        if (m < a.M) {
-          const double mean = sd / (double)a.Cin;
-          double var = qd / (double)a.Cin - mean * mean;
-          if (var < 0.0) var = 0.0;
-          st = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)a.ln_eps)));
+        if (m < a.M) {   // fp64 for the cancellation E[x^2] - mean^2 only; 1/sqrt in fp32 (v_rsq_f32, ~1 ulp)
+          const double mean = sd * a.inv_cin;
+          const float var = fmaxf((float)__builtin_fma(qd, a.inv_cin, -mean * mean), 0.f);
+          st = make_float2((float)mean, __builtin_amdgcn_rsqf(var + a.ln_eps));
         }
         lnst[r] = st;
       }
@@ -561,50 +577,235 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   }
 
   // ---------------- epilogue ----------------
+  // Latency structure (round 2: the first version loaded bias / LayerNorm vectors / residual inside the innermost
+  // (mi, ni, gp) iteration, behind branches and behind the previous iteration's stores - ~50 serialized L2 round trips
+  // per tile, 10 us that no K loop of 5-20 steps could hide).  Now every optional per-column vector is loaded
+  // UNCONDITIONALLY (absent ones point at the zero page; clamped column index), once per 16-column block before its row
+  // loop, together with the block's residual rows: one batch of loads per (ni, gp), i.e. 2 NI round trips per tile.
   ln_finish();
   const float scale = a.scale;
+  const float* const zf = (const float*)a.zero;
+  // ---- interior tiles (every row < M, column blocks of 16 wholly inside or outside n_end), bf16 / GEGLU output ----
+  // What a short-K tile costs is the instruction count of its prologue + epilogue (PMC, profiles/r2_shortk_pmc_*.log:
+  // ~1065 VALU + ~570 SALU per wave of a 64x64 wave tile at K = 64, against 16 MFMAs), so this path is written for
+  // count: per-row pointers built once (lane column included; the (ni, gp) block offset is an instruction immediate),
+  // no bounds masks, and the optional terms (folded LayerNorm, residual, time-embedding row, row statistics) are
+  // compile-time flags of a generic lambda, selected by a wave-uniform branch.  Edge tiles, fp32 / pair-softmax /
+  // split-K / sub-pixel outputs take the general epilogue below.
+  if constexpr (!TRANS) {
+    const bool interior = m0 + BM <= a.M && (a.n_end & 15) == 0 && a.splits <= 1 && !a.subpix;
+    const int lrow = wm * TM + l31;          // the lane's first row inside the tile
+    const int colw = n0 + wn * TN;           // the wave's first column
+    if (interior && a.epi == MG_EPI_GEGLU) {
+      auto geglu_fast = [&](auto LN) {
+        constexpr bool kLN = decltype(LN)::value;
+        const float* const pb = (a.bias ? a.bias + colw : zf) + 4 * half;
+        const float* const pg = kLN ? a.ln_g + colw + 4 * half : zf;
+        const float* const pc = kLN ? a.ln_c + colw + 4 * half : zf;
+        bf16_t* po[MI];
+        float l_sc[MI], l_mr[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          po[mi] = (bf16_t*)a.out + (long long)z * a.sO + (long long)(m0 + lrow + mi * 32) * a.ldo + (colw >> 1) + 8 * half;
+          l_sc[mi] = scale;
+          l_mr[mi] = 0.f;
+          if constexpr (kLN) {
+            const float2 lst = lnst[lrow + mi * 32];
+            l_sc[mi] = lst.y * scale;
+            l_mr[mi] = -lst.y * lst.x;
+          }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if (colw + ni * 32 >= a.n_end) break;   // wave-uniform
+          float bq[4][4], gq[4][4];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 bv = *(const float4*)(pb + ni * 32 + 8 * q4);
+            bq[q4][0] = bv.x; bq[q4][1] = bv.y; bq[q4][2] = bv.z; bq[q4][3] = bv.w;
+            if constexpr (kLN) {
+              const float4 gv = *(const float4*)(pg + ni * 32 + 8 * q4);
+              const float4 cv = *(const float4*)(pc + ni * 32 + 8 * q4);
+              bq[q4][0] += cv.x; bq[q4][1] += cv.y; bq[q4][2] += cv.z; bq[q4][3] += cv.w;
+              gq[q4][0] = gv.x; gq[q4][1] = gv.y; gq[q4][2] = gv.z; gq[q4][3] = gv.w;
+            }
+          }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float o4[4];
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                const float off = kLN ? __builtin_fmaf(l_mr[mi], gq[q4][j], bq[q4][j]) : bq[q4][j];
+                o4[q4] = __builtin_fmaf(acc[ni][mi][4 * q4 + j], l_sc[mi], off);
+              }
+              const float o0 = o4[0] * (a.gelu_erf ? gelu_erf_f(o4[2]) : gelu_poly_f(o4[2]));  // channel 16i + 4h + j
+              const float o1 = o4[1] * (a.gelu_erf ? gelu_erf_f(o4[3]) : gelu_poly_f(o4[3]));  // channel 16i + 8 + 4h + j
+              half_swap(o0, o1, r[j], r[4 + j]);
+            }
+            uint4 pk;
+            pk.x = cvt_pk_bf16(r[0], r[1]); pk.y = cvt_pk_bf16(r[2], r[3]);
+            pk.z = cvt_pk_bf16(r[4], r[5]); pk.w = cvt_pk_bf16(r[6], r[7]);
+            *(uint4*)(po[mi] + ni * 16) = pk;
+          }
+        }
+      };
+      if (a.ln_in) geglu_fast(std::true_type{});
+      else geglu_fast(std::false_type{});
+      return;
+    }
+    if (interior && a.epi == MG_EPI_BF16) {
+      auto bf16_fast = [&](auto LN, auto RES, auto RV, auto LNO) {
+        constexpr bool kLN = decltype(LN)::value, kRES = decltype(RES)::value, kRV = decltype(RV)::value, kLNO = decltype(LNO)::value;
+        const float* const pb = (a.bias ? a.bias + colw : zf) + 8 * half;
+        const float* const pg = kLN ? a.ln_g + colw + 8 * half : zf;
+        const float* const pc = kLN ? a.ln_c + colw + 8 * half : zf;
+        bf16_t* po[MI];
+        const bf16_t* pr[MI];
+        const float* pv[MI];
+        float2* pl[MI];
+        float l_sc[MI], l_mr[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int m = m0 + lrow + mi * 32;
+          po[mi] = (bf16_t*)a.out + (long long)z * a.sO + (long long)m * a.ldo + colw + 8 * half;
+          if constexpr (kRES) pr[mi] = a.res + (long long)z * a.sR + (long long)m * a.ldr + colw + 8 * half;
+          if constexpr (kRV) pv[mi] = a.rowvec + (long long)fdiv(m, a.fd_rpi) * a.rv_stride + colw + 8 * half;
+          if constexpr (kLNO) pl[mi] = a.ln_out + (long long)m * (a.N >> 5) + (colw >> 5);
+          l_sc[mi] = scale;
+          l_mr[mi] = 0.f;
+          if constexpr (kLN) {
+            const float2 lst = lnst[lrow + mi * 32];
+            l_sc[mi] = lst.y * scale;
+            l_mr[mi] = -lst.y * lst.x;
+          }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          float ps[MI], pq[MI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) ps[mi] = pq[mi] = 0.f;
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            constexpr int dummy = 0; (void)dummy;
+            const int c = ni * 32 + gp * 16;              // compile-time after unrolling: an immediate offset
+            if (colw + c >= a.n_end) break;               // wave-uniform
+            const float4 b0 = *(const float4*)(pb + c), b1 = *(const float4*)(pb + c + 4);
+            float cb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float gg[8];
+            if constexpr (kLN) {
+              const float4 g0 = *(const float4*)(pg + c), g1 = *(const float4*)(pg + c + 4);
+              const float4 c0 = *(const float4*)(pc + c), c1 = *(const float4*)(pc + c + 4);
+              gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+              cb[0] += c0.x; cb[1] += c0.y; cb[2] += c0.z; cb[3] += c0.w; cb[4] += c1.x; cb[5] += c1.y; cb[6] += c1.z; cb[7] += c1.w;
+            }
+            uint4 rr[MI];
+            float4 rv0[MI], rv1[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              if constexpr (kRES) rr[mi] = *(const uint4*)(pr[mi] + c);
+              if constexpr (kRV) { rv0[mi] = *(const float4*)(pv[mi] + c); rv1[mi] = *(const float4*)(pv[mi] + c + 4); }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              float v[8];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) half_swap(acc[ni][mi][8 * gp + j], acc[ni][mi][8 * gp + 4 + j], v[j], v[4 + j]);
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                v[j] = __builtin_fmaf(v[j], l_sc[mi], kLN ? __builtin_fmaf(l_mr[mi], gg[j], cb[j]) : cb[j]);
+              if constexpr (kRV) {
+                v[0] += rv0[mi].x; v[1] += rv0[mi].y; v[2] += rv0[mi].z; v[3] += rv0[mi].w;
+                v[4] += rv1[mi].x; v[5] += rv1[mi].y; v[6] += rv1[mi].z; v[7] += rv1[mi].w;
+              }
+              if constexpr (kRES) {
+                const uint4 r4 = rr[mi];
+                v[0] += bflo(r4.x); v[1] += bfhi(r4.x); v[2] += bflo(r4.y); v[3] += bfhi(r4.y);
+                v[4] += bflo(r4.z); v[5] += bfhi(r4.z); v[6] += bflo(r4.w); v[7] += bfhi(r4.w);
+              }
+              if constexpr (kLNO) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ps[mi] += v[j]; pq[mi] = __builtin_fmaf(v[j], v[j], pq[mi]); }
+              }
+              uint4 pk;
+              pk.x = cvt_pk_bf16(v[0], v[1]); pk.y = cvt_pk_bf16(v[2], v[3]);
+              pk.z = cvt_pk_bf16(v[4], v[5]); pk.w = cvt_pk_bf16(v[6], v[7]);
+              *(uint4*)(po[mi] + c) = pk;
+            }
+          }
+          if constexpr (kLNO) {   // both halves of the lane pair hold 16 of the row's 32 columns (N % 32 == 0: whole blocks)
+            if (colw + ni * 32 < a.n_end) {
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) {
+                const float s2 = ps[mi] + __shfl_xor(ps[mi], 32), q2 = pq[mi] + __shfl_xor(pq[mi], 32);
+                if (half == 0) pl[mi][ni] = make_float2(s2, q2);
+              }
+            }
+          }
+        }
+      };
+      using T = std::true_type;
+      using F = std::false_type;
+      const bool fLN = a.ln_in != nullptr, fRES = a.res != nullptr, fRV = a.rowvec != nullptr, fLNO = a.ln_out != nullptr;
+      const int key = (fLN ? 1 : 0) | (fRES ? 2 : 0) | (fRV ? 4 : 0) | (fLNO ? 8 : 0);
+      bool done = true;
+      switch (key) {
+        case 0: bf16_fast(F{}, F{}, F{}, F{}); break;    // projections, shortcuts
+        case 1: bf16_fast(T{}, F{}, F{}, F{}); break;    // Linear on LayerNorm(x), folded
+        case 2: bf16_fast(F{}, T{}, F{}, F{}); break;    // + residual
+        case 10: bf16_fast(F{}, T{}, F{}, T{}); break;   // + residual, row statistics for the next folded LayerNorm
+        case 8: bf16_fast(F{}, F{}, F{}, T{}); break;    // proj_in: row statistics
+        case 4: bf16_fast(F{}, F{}, T{}, F{}); break;    // resnet conv1: + time-embedding row
+        default: done = false;
+      }
+      if (done) return;
+    }
+  }
   if constexpr (!TRANS) {
     if (a.epi == MG_EPI_GEGLU) {
       // Weight rows are interleaved in 32-row groups (weights.py::pack_geglu): rows [32i,32i+16) =
       // u(16i..16i+15), rows [32i+16,32i+32) = their gates.  acc groups g = 0,1 are u(16i+8g+4h+j),
       // g = 2,3 the gates of the same channels; a lane^32 exchange then leaves 8 consecutive output
       // channels per lane -> one 16-byte store per (mi, ni).
+      const float* const pb = a.bias ? a.bias : zf;
+      const float* const pg = a.ln_in ? a.ln_g : zf;
+      const float* const pc = a.ln_in ? a.ln_c : zf;
+      float l_sc[MI], l_mr[MI];   // rstd * scale, -mean * rstd of the lane's rows
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * TM + mi * 32 + l31;
         const float2 lst = a.ln_in ? lnst[wm * TM + mi * 32 + l31] : make_float2(0.f, 1.f);
+        l_sc[mi] = lst.y * scale;
+        l_mr[mi] = -lst.y * lst.x;
+      }
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int nb = n0 + wn * TN + ni * 32;
-          const bool nok = nb < a.n_end;
+      for (int ni = 0; ni < NI; ++ni) {
+        const int nb = n0 + wn * TN + ni * 32;
+        const bool nok = nb < a.n_end;
+        const int nu0 = (nok ? nb : n0) + 4 * half;   // clamped: the loads below are unconditional
+        float bq[4][4], gq[4][4], cq[4][4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 bv = *(const float4*)(pb + nu0 + 8 * q4);
+          const float4 gv = *(const float4*)(pg + nu0 + 8 * q4);
+          const float4 cv = *(const float4*)(pc + nu0 + 8 * q4);
+          bq[q4][0] = bv.x + cv.x; bq[q4][1] = bv.y + cv.y; bq[q4][2] = bv.z + cv.z; bq[q4][3] = bv.w + cv.w;
+          gq[q4][0] = gv.x; gq[q4][1] = gv.y; gq[q4][2] = gv.z; gq[q4][3] = gv.w;
+          (void)cq;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int m = m0 + wm * TM + mi * 32 + l31;
           float r[8];
-          // per-column vectors of this lane's four 4-column groups (u: +0, +8; gates: +16, +24), 16-byte loads
-          const int nu0 = nb + 4 * half;
-          float bq[4][4], gq[4][4], cq[4][4];
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 bv = (a.bias && nok) ? *(const float4*)(a.bias + nu0 + 8 * q4) : z4;
-            const float4 gv = (a.ln_in && nok) ? *(const float4*)(a.ln_g + nu0 + 8 * q4) : z4;
-            const float4 cv = (a.ln_in && nok) ? *(const float4*)(a.ln_c + nu0 + 8 * q4) : z4;
-            bq[q4][0] = bv.x; bq[q4][1] = bv.y; bq[q4][2] = bv.z; bq[q4][3] = bv.w;
-            gq[q4][0] = gv.x; gq[q4][1] = gv.y; gq[q4][2] = gv.z; gq[q4][3] = gv.w;
-            cq[q4][0] = cv.x; cq[q4][1] = cv.y; cq[q4][2] = cv.z; cq[q4][3] = cv.w;
-          }
-          // folded LayerNorm: rstd * (acc - mean g) + c = (rstd scale) acc + (c - mean rstd g); the Linear's own bias is
-          // part of c there, and the only offset otherwise: two fused multiply-adds per accumulator either way
-          const float lsc = (a.ln_in ? lst.y : 1.f) * scale, lmr = a.ln_in ? -lst.y * lst.x : 0.f;
-          float off[4][4];
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) off[q4][j] = __builtin_fmaf(lmr, gq[q4][j], cq[q4][j] + bq[q4][j]);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float u0 = __builtin_fmaf(acc[ni][mi][j], lsc, off[0][j]);
-            const float u1 = __builtin_fmaf(acc[ni][mi][4 + j], lsc, off[1][j]);
-            const float t0 = __builtin_fmaf(acc[ni][mi][8 + j], lsc, off[2][j]);
-            const float t1 = __builtin_fmaf(acc[ni][mi][12 + j], lsc, off[3][j]);
+            // folded LayerNorm: rstd * (acc - mean g) + c = (rstd scale) acc + (c - mean rstd g); the Linear's own bias
+            // is part of c there, and the only offset otherwise
+            const float u0 = __builtin_fmaf(acc[ni][mi][j], l_sc[mi], __builtin_fmaf(l_mr[mi], gq[0][j], bq[0][j]));
+            const float u1 = __builtin_fmaf(acc[ni][mi][4 + j], l_sc[mi], __builtin_fmaf(l_mr[mi], gq[1][j], bq[1][j]));
+            const float t0 = __builtin_fmaf(acc[ni][mi][8 + j], l_sc[mi], __builtin_fmaf(l_mr[mi], gq[2][j], bq[2][j]));
+            const float t1 = __builtin_fmaf(acc[ni][mi][12 + j], l_sc[mi], __builtin_fmaf(l_mr[mi], gq[3][j], bq[3][j]));
             const float o0 = u0 * (a.gelu_erf ? gelu_erf_f(t0) : gelu_poly_f(t0));  // channel 16i + 4h + j
             const float o1 = u1 * (a.gelu_erf ? gelu_erf_f(t1) : gelu_poly_f(t1));  // channel 16i + 8 + 4h + j
             half_swap(o0, o1, r[j], r[4 + j]);
@@ -621,109 +822,155 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
       return;
     }
   }
-  // lane^32 exchange: afterwards v[0..7] are 8 consecutive "inner" indices (inner = n, or m when
-  // TRANS) starting at 16*gp + 8*half, for the lane's outer index l31.
+  if constexpr (!TRANS) {
+    // lane^32 exchange: afterwards v[0..7] are 8 consecutive output channels starting at 16*gp + 8*half of pixel l31
+    const float* const pb = a.bias ? a.bias : zf;
+    const float* const pg = a.ln_in ? a.ln_g : zf;
+    const float* const pc = a.ln_in ? a.ln_c : zf;
+    const float* const prv = a.rowvec ? a.rowvec : zf;
+    const int rvs = a.rowvec ? a.rv_stride : 0;
+    float l_sc[MI], l_mr[MI];
+    long long e_row[MI];   // output row of the lane's pixel (identity unless sub-pixel)
+    int e_img[MI];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
+      const float2 lst = a.ln_in ? lnst[wm * TM + mi * 32 + l31] : make_float2(0.f, 1.f);
+      l_sc[mi] = lst.y * (a.splits <= 1 ? scale : 1.f);
+      l_mr[mi] = -lst.y * lst.x;
+      const int m = m0 + wm * TM + mi * 32 + l31;
+      const int mc = m < a.M ? m : a.M - 1;          // clamped: loads stay in range, stores are masked
+      const int img = fdiv(mc, a.fd_rpi);
+      e_img[mi] = img;
+      e_row[mi] = mc;
+      if (a.subpix) {   // low-resolution pixel (img, y, x) of parity (a, b) -> pixel (2y + a, 2x + b) of the 2H x 2W map
+        const int rem = mc - img * a.rows_per_img;
+        const int y = fdiv(rem, a.fd_wo), x = rem - y * a.Wo;
+        e_row[mi] = (long long)img * 4 * a.rows_per_img + (long long)(2 * y + (z >> 1)) * (2 * a.Wo) + 2 * x + (z & 1);
+      }
+    }
+    float ps[MI], pq[MI];   // ln_out: the lane's share of (sum, sum of squares) of its rows over the current 32 columns
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const int mb = m0 + wm * TM + mi * 32, nb = n0 + wn * TN + ni * 32;
-      float ps = 0.f, pq = 0.f;   // ln_out: this lane's share of (sum, sum of squares) of row mb + l31 over columns [nb, nb + 32)
+      const int nb = n0 + wn * TN + ni * 32;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) ps[mi] = pq[mi] = 0.f;
 #pragma unroll
       for (int gp = 0; gp < 2; ++gp) {
-        float v[8];
+        const int n = nb + 16 * gp + 8 * half;
+        const bool nok = n < a.n_end;
+        const int nc = nok ? n : n0;   // clamped column for the unconditional loads
+        if (a.splits > 1) {  // split-K: raw partial sums, everything else happens in splitk_reduce_kernel
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          half_swap(acc[ni][mi][8 * gp + j], acc[ni][mi][8 * gp + 4 + j], v[j], v[4 + j]);
-        }
-        if (a.splits <= 1) {
+          for (int mi = 0; mi < MI; ++mi) {
+            float v[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= scale;
-        }
-        if constexpr (!TRANS) {
-          const int m = mb + l31, n = nb + 16 * gp + 8 * half;
-          long long orow = m;
-          if (a.subpix) {   // low-resolution pixel (img, y, x) of parity (a, b) -> pixel (2y + a, 2x + b) of the 2H x 2W map
-            const int img = m / a.rows_per_img, rem = m - img * a.rows_per_img;
-            const int y = rem / a.Wo, x = rem - y * a.Wo;
-            orow = (long long)img * 4 * a.rows_per_img + (long long)(2 * y + (z >> 1)) * (2 * a.Wo) + 2 * x + (z & 1);
-          }
-          if (a.splits > 1) {  // split-K: raw partial sums, everything else happens in splitk_reduce_kernel
-            if (m < a.M && n < a.n_end) {
+            for (int j = 0; j < 4; ++j) half_swap(acc[ni][mi][8 * gp + j], acc[ni][mi][8 * gp + 4 + j], v[j], v[4 + j]);
+            const int m = m0 + wm * TM + mi * 32 + l31;
+            if (m < a.M && nok) {
               float* o = a.ws + ((long long)split * a.M + m) * a.N + n;
               *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
               *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
-          } else if (m < a.M && n < a.n_end) {
-            if (a.ln_in) {
-              const float2 lst = lnst[wm * TM + mi * 32 + l31];
-              const float4 g0 = *(const float4*)(a.ln_g + n), g1 = *(const float4*)(a.ln_g + n + 4);
-              const float4 c0 = *(const float4*)(a.ln_c + n), c1 = *(const float4*)(a.ln_c + n + 4);
-              const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-              const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+          }
+          continue;
+        }
+        // ---- the block's loads, all issued before anything is consumed ----
+        const float4 b0 = *(const float4*)(pb + nc), b1 = *(const float4*)(pb + nc + 4);
+        const float4 g0 = *(const float4*)(pg + nc), g1 = *(const float4*)(pg + nc + 4);
+        const float4 c0 = *(const float4*)(pc + nc), c1 = *(const float4*)(pc + nc + 4);
+        uint4 rr[MI];
+        float4 rv0[MI], rv1[MI];
+        const bool has_res = a.res != nullptr && a.epi == MG_EPI_BF16;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] = lst.y * (v[j] - lst.x * gg[j]) + cc[j];
-            }
-            if (a.bias) {
-              const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
-              v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-              v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-            }
-            if (a.rowvec) {
-              const float* rv = a.rowvec + (long long)(m / a.rows_per_img) * a.rv_stride + n;
-              const float4 r0 = *(const float4*)rv, r1 = *(const float4*)(rv + 4);
-              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-              v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-            }
-            if (a.epi == MG_EPI_F32) {
-              float* o = (float*)a.out + (long long)z * a.sO + orow * a.ldo + n;
+        for (int mi = 0; mi < MI; ++mi) {
+          rr[mi] = has_res ? *(const uint4*)(a.res + (long long)z * a.sR + e_row[mi] * a.ldr + nc) : make_uint4(0, 0, 0, 0);
+          const float* rv = prv + (long long)e_img[mi] * rvs + (a.rowvec ? nc : 0);
+          rv0[mi] = *(const float4*)rv;
+          rv1[mi] = *(const float4*)(rv + 4);
+        }
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float cb[8] = {c0.x + b0.x, c0.y + b0.y, c0.z + b0.z, c0.w + b0.w, c1.x + b1.x, c1.y + b1.y, c1.z + b1.z, c1.w + b1.w};
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) half_swap(acc[ni][mi][8 * gp + j], acc[ni][mi][8 * gp + 4 + j], v[j], v[4 + j]);
+          const float rvv[8] = {rv0[mi].x, rv0[mi].y, rv0[mi].z, rv0[mi].w, rv1[mi].x, rv1[mi].y, rv1[mi].z, rv1[mi].w};
+          // scale, folded LayerNorm (rstd acc - mean rstd g + c), bias, time-embedding row: two fused multiply-adds + an add
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf(v[j], l_sc[mi], __builtin_fmaf(l_mr[mi], gg[j], cb[j])) + rvv[j];
+          const int m = m0 + wm * TM + mi * 32 + l31;
+          const bool ok = m < a.M && nok;
+          if (a.epi == MG_EPI_F32) {
+            if (ok) {
+              float* o = (float*)a.out + (long long)z * a.sO + e_row[mi] * a.ldo + n;
               *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
               *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            } else if (a.epi == MG_EPI_SOFTMAX2) {
-              // 2-key softmax of the collapsed cross-attention (columns 2h, 2h+1 = the two context tokens of head h) taken
-              // on the accumulators: the fp32 scores never reach HBM and no softmax launch follows.  Pad columns -> 0.
-              uint32_t w4[4];
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const float s0 = v[2 * k] * a.sm_scale, s1 = v[2 * k + 1] * a.sm_scale;
-                const float mx = fmaxf(s0, s1);
-                const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx);
-                const float inv = 1.0f / (e0 + e1);
-                w4[k] = (n + 2 * k < a.sm_cols) ? pack2bf(e0 * inv, e1 * inv) : 0u;
-              }
-              *(uint4*)((bf16_t*)a.out + (long long)z * a.sO + orow * a.ldo + n) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-            } else {
-              if (a.res) {
-                const uint4 r4 = *(const uint4*)(a.res + (long long)z * a.sR + (long long)m * a.ldr + n);
-                v[0] += bflo(r4.x); v[1] += bfhi(r4.x); v[2] += bflo(r4.y); v[3] += bfhi(r4.y);
-                v[4] += bflo(r4.z); v[5] += bfhi(r4.z); v[6] += bflo(r4.w); v[7] += bfhi(r4.w);
-              }
-              if (a.ln_out) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { ps += v[j]; pq = __builtin_fmaf(v[j], v[j], pq); }
-              }
-              uint4 pk;
-              pk.x = cvt_pk_bf16(v[0], v[1]); pk.y = cvt_pk_bf16(v[2], v[3]);
-              pk.z = cvt_pk_bf16(v[4], v[5]); pk.w = cvt_pk_bf16(v[6], v[7]);
-              *(uint4*)((bf16_t*)a.out + (long long)z * a.sO + orow * a.ldo + n) = pk;
             }
+          } else if (a.epi == MG_EPI_SOFTMAX2) {
+            // 2-key softmax of the collapsed cross-attention (columns 2h, 2h+1 = the two context tokens of head h) taken
+            // on the accumulators: the fp32 scores never reach HBM and no softmax launch follows.  Pad columns -> 0.
+            uint32_t w4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float s0 = v[2 * k] * a.sm_scale, s1 = v[2 * k + 1] * a.sm_scale;
+              const float mx = fmaxf(s0, s1);
+              const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx);
+              const float inv = 1.0f / (e0 + e1);
+              w4[k] = (n + 2 * k < a.sm_cols) ? pack2bf(e0 * inv, e1 * inv) : 0u;
+            }
+            if (ok) *(uint4*)((bf16_t*)a.out + (long long)z * a.sO + e_row[mi] * a.ldo + n) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+          } else {
+            const uint4 r4 = rr[mi];
+            v[0] += bflo(r4.x); v[1] += bfhi(r4.x); v[2] += bflo(r4.y); v[3] += bfhi(r4.y);
+            v[4] += bflo(r4.z); v[5] += bfhi(r4.z); v[6] += bflo(r4.w); v[7] += bfhi(r4.w);
+            if (a.ln_out && ok) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { ps[mi] += v[j]; pq[mi] = __builtin_fmaf(v[j], v[j], pq[mi]); }
+            }
+            uint4 pk;
+            pk.x = cvt_pk_bf16(v[0], v[1]); pk.y = cvt_pk_bf16(v[2], v[3]);
+            pk.z = cvt_pk_bf16(v[4], v[5]); pk.w = cvt_pk_bf16(v[6], v[7]);
+            if (ok) *(uint4*)((bf16_t*)a.out + (long long)z * a.sO + e_row[mi] * a.ldo + n) = pk;
           }
-        } else {
-          // transposed store: out[z][img][n][tok], 8 consecutive tokens per lane
-          const int n = nb + l31, m = mb + 16 * gp + 8 * half;
-          if (n < a.n_end && m < a.M) {
-            if (a.ln_in) {
-              const float gn = a.ln_g[n], cn = a.ln_c[n];
+        }
+      }
+      if (a.ln_out && a.splits <= 1) {   // both halves of the lane pair hold 16 of the row's 32 columns
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const float2 lst = lnst[m - m0 + j];
-                v[j] = lst.y * (v[j] - lst.x * gn) + cn;
-              }
-            }
-            const float bv = a.bias ? a.bias[n] : 0.f;
+        for (int mi = 0; mi < MI; ++mi) {
+          const float s2 = ps[mi] + __shfl_xor(ps[mi], 32), q2 = pq[mi] + __shfl_xor(pq[mi], 32);
+          const int m = m0 + wm * TM + mi * 32 + l31;
+          if (half == 0 && m < a.M && nb < a.n_end) a.ln_out[(long long)m * (a.N >> 5) + (nb >> 5)] = make_float2(s2, q2);
+        }
+      }
+    }
+  } else {
+    // transposed section (V^T of the fused QKV projection): out[z][img][n][tok], 8 consecutive tokens per lane; the
+    // lane's column n = nb + l31 is fixed per ni: its bias / LayerNorm constants are loaded once per ni
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += bv;
-            const int img = m / a.rows_per_img;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int nb = n0 + wn * TN + ni * 32;
+      const int n = nb + l31;
+      const bool nok = n < a.n_end;
+      const int nc = nok ? n : n0;
+      const float bv = a.bias ? a.bias[nc] : 0.f;
+      const float gn = a.ln_in ? a.ln_g[nc] : 0.f, cn = (a.ln_in ? a.ln_c[nc] : 0.f) + bv;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int mb = m0 + wm * TM + mi * 32;
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) half_swap(acc[ni][mi][8 * gp + j], acc[ni][mi][8 * gp + 4 + j], v[j], v[4 + j]);
+          const int m = mb + 16 * gp + 8 * half;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float2 lst = a.ln_in ? lnst[m - m0 + j] : make_float2(0.f, 1.f);
+            v[j] = __builtin_fmaf(v[j] * scale, lst.y, __builtin_fmaf(-lst.y * lst.x, gn, cn));
+          }
+          if (nok && m < a.M) {
+            const int img = fdiv(m, a.fd_rpi);
             const int tok = m - img * a.rows_per_img;
             if (tok + 8 <= a.rows_per_img && (a.rows_per_img & 7) == 0) {
               bf16_t* o = (bf16_t*)a.out + (long long)z * a.sO + ((long long)img * a.ctr + n) * a.ldt + tok;
@@ -736,21 +983,13 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
               for (int j = 0; j < 8; ++j) {
                 const int mj = m + j;
                 if (mj < a.M) {
-                  const int im = mj / a.rows_per_img;
+                  const int im = fdiv(mj, a.fd_rpi);
                   const int tk = mj - im * a.rows_per_img;
                   ((bf16_t*)a.out)[(long long)z * a.sO + ((long long)im * a.ctr + n) * a.ldt + tk] = f2bf(v[j]);
                 }
               }
             }
           }
-        }
-      }
-      if constexpr (!TRANS) {
-        if (a.ln_out) {   // both halves of the lane pair hold 16 of the row's 32 columns
-          ps += __shfl_xor(ps, 32);
-          pq += __shfl_xor(pq, 32);
-          const int m = mb + l31;
-          if (half == 0 && m < a.M && nb < a.n_end) a.ln_out[(long long)m * (a.N >> 5) + (nb >> 5)] = make_float2(ps, pq);
         }
       }
     }
@@ -849,6 +1088,10 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   }
   const long long grid = tiles * b.splits * batch_z;
   MG_REQUIRE(grid > 0 && grid < (1ll << 31), "igemm: bad grid %lld", grid);
+  b.fd_per_z = mg_make_fastdiv(tiles * b.splits);
+  b.fd_tiles = mg_make_fastdiv(tiles);
+  b.fd_tiles_n = mg_make_fastdiv(b.tiles_n);
+  b.fd_cpt = mg_make_fastdiv(b.cpt);
   MG_LAUNCH(kern, dim3((unsigned)grid), dim3(NT), LDS, s, b);
   if (b.splits > 1) {
     const long long nvec = (long long)a.M * (a.N / 8);
@@ -890,7 +1133,10 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
     case 62: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 4>(a, batch_z, s);   //   2nd DMA piece among the MFMAs
     case 63: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 5>(a, batch_z, s);   //   both
     case 46: return launch2<128, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);   // full-width tiles for N = 320
-    case 47: return launch2<256, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);
+    case 47:   // (no transposed instantiation: 160 accumulators + the token-major epilogue do not fit 256 VGPRs)
+      if constexpr (!TRANS) return launch2<256, 320, 4, 2, 2, false, true>(a, batch_z, s);
+      else MG_REQUIRE(false, "igemm: tile variant 47 has no transposed section");
+      return 0;
     case 48: return launch2<128, 320, 4, 2, 2, TRANS, false>(a, batch_z, s);
     // EXPERIMENTAL (gated tests only): 128x320 with 32-deep K tiles and 4 waves (wave tile 64x160) - 56 KB of LDS, two
     // workgroups per CU, for the K = C linears of the 320-channel level (one workgroup per CU runs them at half the
@@ -976,6 +1222,11 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.kps = 0;
   a.ws = nullptr;
   a.ctr = 0;
+  a.fd_rpi = mg_make_fastdiv(a.rows_per_img > 0 ? a.rows_per_img : 1);
+  a.fd_wo = mg_make_fastdiv(a.Wo > 0 ? a.Wo : 1);
+  a.fd_per_z = a.fd_tiles = a.fd_tiles_n = a.fd_cpt = mg_make_fastdiv(1);
+  a.lin = a.taps == 1 && a.stride == 1 && a.pad == 0 && a.Hu == 0 && a.Ho == a.H && a.Wo == a.W;
+  a.inv_cin = 1.0 / (double)(a.Cin > 0 ? a.Cin : 1);
   a.tiles_m = a.tiles_n = 0;
   MG_REQUIRE(g_zero_page || g_dry_run, "igemm: mg_init() not called");
   MG_REQUIRE(a.A && a.Wt && (a.out || out2), "igemm: null pointer");
