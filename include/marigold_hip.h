@@ -36,13 +36,16 @@ enum mg_op_kind {
    *  p[4] rowvec f32 [B][N] | NULL (time-embedding add)   p[5] residual bf16 [M][ldr] | NULL
    *  p[6] out2 (transposed section)    p[7] A1 bf16 [B][H][W][lda1] | NULL: second channel source - channels [C0, Cin)
    *  of every tap come from A1, [0, C0) from A (the UNet's skip concat; i[24] = C0, i[25] = lda1)
-   *  p[8] ln_out f32 [M][N/32][2] | NULL: the epilogue also writes (sum, sum of squares) of every output row over each
-   *  32-column slot - the LayerNorm statistics of the tensor it produces (bf16 epilogue, N % 32 == 0)
-   *  p[9] ln_in f32 [M][i[26]][2] | NULL, p[10] ln_g f32 [N], p[11] ln_c f32 [N]: LayerNorm FOLDED into this Linear layer
+   *  p[8] ln_out f32 [M][N/32 + 1][2] bytes | NULL: the LayerNorm statistics of the tensor this launch produces (bf16
+   *  epilogue, N % 32 == 0, f[1] = eps): every tile writes (sum, sum of squares) of its rows over each 32-column slot into
+   *  [M][N/32][2], and the last column tile of a row block to finish reduces them to (mean, rstd) rows [M][2] stored
+   *  BEHIND the slots (at ln_out + M * (N/32) * 8 bytes) - that address is the ln_in of the consuming layers.  Launches
+   *  that write statistics share one ticket array: they must be stream-ordered with respect to each other.
+   *  p[9] ln_in f32 [M][2] (mean, rstd) | NULL, p[10] ln_g f32 [N], p[11] ln_c f32 [N]: LayerNorm FOLDED into this Linear layer
    *  (diffusers BasicTransformerBlock: norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q, norm3 -> ff.net.0.proj): A holds the
    *  raw rows x, Wt = W * gamma, and out = rstd[m] * (acc - mean[m] * ln_g[n]) + ln_c[n] with ln_g[n] = sum_k Wt[n][k],
-   *  ln_c[n] = sum_k beta[k] W[n][k] + bias[n]; (mean, rstd) come from the producer's ln_out slots (i[26] = Cin / 32 of
-   *  them), f[1] = eps.  No separate normalisation pass, no normalised tensor in HBM.
+   *  ln_c[n] = sum_k beta[k] W[n][k] + bias[n]; (mean, rstd) come from the producer's ln_out.  No separate normalisation
+   *  pass, no normalised tensor in HBM.
    *  i[0] B  i[1] H  i[2] W  i[3] Cin  i[4] Ho  i[5] Wo
    *  i[6] N  i[7] taps (1 | 9 | 4 = the sub-pixel form of nearest-2x + conv3x3: batch_z = 4 output parities, see
    *  MG_OP_CONV3X3)  i[8] stride  i[9] pad  i[10] Hu  i[11] Wu (virtual nearest-

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmarigold_hip.so")
+LIB_PATH = os.environ.get("MARIGOLD_HIP_LIB") or os.path.join(_HERE, "libmarigold_hip.so")   # (override: same-box A/B of two builds)
 ABI_VERSION = 2
 
 # enum mg_op_kind

@@ -138,6 +138,9 @@ extern void* g_zero_page;  // MG_ZERO_BYTES zero bytes in device memory (mg_init
 // returns before touching the device - the CPU test-suite validates full-size programs with it.
 extern thread_local bool g_dry_run;
 #define MG_SPLITK_WS_BYTES (64ll * 1024 * 1024)
+#define MG_LN_COUNTERS 65536
+extern unsigned* g_ln_counters;  // MG_LN_COUNTERS zeroed tickets (mg_init): one per row block of a GEMM launch that writes row
+                                 // statistics (the last column tile of a row block reduces them); self-resetting, stream-ordered
 extern void* g_splitk_ws;  // fp32 partial sums of split-K GEMM launches (mg_init); stream-ordered reuse
 #define MG_LAUNCH(...)                                   \
   do {                                                   \

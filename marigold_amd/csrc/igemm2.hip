@@ -45,13 +45,16 @@ struct Igemm2Args {
   float scale;
   // LayerNorm folded into this GEMM (Linear layers that consume LN(x)): A = the RAW rows x, weights = W * gamma, and
   //   out = rstd[m] * (acc - mean[m] * ln_g[n]) + ln_c[n],  ln_g[n] = sum_k (W gamma)[n][k],  ln_c[n] = sum_k beta[k] W[n][k] + bias[n]
-  // with (mean, rstd) of row m taken from ln_in: [M][ln_slots] (sum, sum of squares) over 32-column slots, written by the
-  // epilogue of the GEMM that produced x (ln_out of that launch: one slot per 32 output columns).
+  // with (mean, rstd) of row m = ln_in[m], written by the GEMM launch that produced x: its epilogue stores (sum, sum of
+  // squares) of every output row over each 32-column slot into ln_out [M][N/32], and the LAST column tile of a row block
+  // to finish (ticket in ln_ctr[tile_m]) reduces the block's slots to (mean, rstd) at ln_out + M * (N/32) - the ln_in of
+  // the consumers.  (Round 2, first form: every consumer tile reduced the slots itself - 10-40 strided 8-byte loads per
+  // row and fp64 arithmetic in front of each of its N / BN tiles: GEGLU 320->2560 +30 us, 640->5120 +100 us.)
   const float2* ln_in;
   const float* ln_g;
   const float* ln_c;
   float2* ln_out;
-  int ln_slots;
+  unsigned* ln_ctr;
   float ln_eps;
   float sm_scale;  // MG_EPI_SOFTMAX2: softmax scale and the number of real score columns (2 x heads)
   int sm_cols;
@@ -60,7 +63,7 @@ struct Igemm2Args {
   // conv1x1 (taps 1, stride 1, no padding / up-sampling), whose output row m reads input row m - no (image, y, x) split.
   mg_fastdiv fd_per_z, fd_tiles, fd_tiles_n, fd_rpi, fd_wo, fd_cpt;
   int lin;
-  double inv_cin;   // 1 / Cin (folded LayerNorm statistics)
+  double inv_n;     // 1 / N (row statistics of the output -> mean, rstd)
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -248,60 +251,26 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   };
 
   f32x16 acc[NI][MI];
+  auto zero_acc = [&]() {   // called after ln_publish: the statistics slots' registers are dead by then
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+  };
 
-  // folded LayerNorm: (mean, rstd) of the tile's BM rows, kept in LDS behind the ring for the epilogue.  NT / BM threads
-  // share a row (fixed slot -> thread assignment, fp64 sums: reproducible).  The slot loads are issued HERE, ahead of the
-  // first LDS-DMA stage, into registers and only consumed after the K loop: their latency hides under tile 0's, and no
-  // compiler-inserted vmcnt(0) sits between the DMA prologue and the first K step (rows wider than LNR * TS slots -
-  // the 1280-channel levels - take the slots after the loop instead).
+  // folded LayerNorm: (mean, rstd) of the tile's BM rows (ln_in, finalized by the producer's last column tile), kept in
+  // LDS behind the ring for the epilogue.  One 8-byte load per row, issued ahead of the first LDS-DMA stage and published
+  // right after it (ln_publish); the K loop's barriers order the LDS write before the epilogue's reads.
   float2* const lnst = (float2*)(smem + NSTAGE * STAGE);
-  constexpr int LN_TS = NT >= BM ? (NT / BM >= 4 ? 4 : NT / BM) : 1;   // threads per row (a power of two <= 4)
-  constexpr int LNR = MI * NI * 16 >= 128 ? 1 : 8;   // the 128-accumulator tiles have no registers to spare (slots after the loop)
-  static_assert(BM * LN_TS <= NT || LN_TS == 1, "one row per thread");
-  const int ln_r = tid / LN_TS, ln_sub = tid % LN_TS;
-  const bool ln_row = a.ln_in && ln_r < BM && m0 + ln_r < a.M;
-  const bool ln_regs = a.ln_in && LNR > 1 && a.ln_slots <= LNR * LN_TS;
-  float2 lnreg[LNR];
-  if (ln_regs) {
-    const float2* p = a.ln_in + (long long)(m0 + ln_r) * a.ln_slots;
-#pragma unroll
-    for (int i = 0; i < LNR; ++i) {
-      const int sl = ln_sub + i * LN_TS;
-      lnreg[i] = (ln_row && sl < a.ln_slots) ? p[sl] : make_float2(0.f, 0.f);
-    }
-  }
-  auto ln_finish = [&]() {   // after the K loop: reduce the slots, publish (mean, rstd) of the tile's rows
+  static_assert(NT >= BM, "one statistics row per thread (or less)");
+  float2 ln_mr = make_float2(0.f, 1.f);
+  if (a.ln_in && tid < BM && m0 + tid < a.M) ln_mr = a.ln_in[m0 + tid];
+  auto ln_publish = [&]() {
     if (!a.ln_in) return;
-    for (int r0 = 0; r0 < BM; r0 += NT / LN_TS) {   // one pass unless NT < BM
-      const int r = r0 + ln_r;
-      const int m = m0 + r;
-      double sd = 0.0, qd = 0.0;
-      if (ln_regs) {
-#pragma unroll
-        for (int i = 0; i < LNR; ++i) { sd += (double)lnreg[i].x; qd += (double)lnreg[i].y; }
-      } else if (r < BM && m < a.M) {
-        const float2* p = a.ln_in + (long long)m * a.ln_slots;
-        for (int sl = ln_sub; sl < a.ln_slots; sl += LN_TS) { const float2 v = p[sl]; sd += (double)v.x; qd += (double)v.y; }
-      }
-#pragma unroll
-      for (int o = LN_TS / 2; o > 0; o >>= 1) { sd += __shfl_xor(sd, o); qd += __shfl_xor(qd, o); }
-      if (r < BM && ln_sub == 0) {
-        float2 st = make_float2(0.f, 1.f);
-        if (m < a.M) {   // fp64 for the cancellation E[x^2] - mean^2 only; 1/sqrt in fp32 (v_rsq_f32, ~1 ulp)
-          const double mean = sd * a.inv_cin;
-          const float var = fmaxf((float)__builtin_fma(qd, a.inv_cin, -mean * mean), 0.f);
-          st = make_float2((float)mean, __builtin_amdgcn_rsqf(var + a.ln_eps));
-        }
-        lnst[r] = st;
-      }
-    }
-    __syncthreads();
+    if (tid < BM) lnst[tid] = ln_mr;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS write has left before this wave's next barrier
   };
 
   int rowA[MI], rowB[NI];
@@ -315,6 +284,10 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
 #pragma unroll
     for (int d = 0; d < D; ++d)
       if (d < KT) issue(d);
+  }
+  if constexpr (!PP) {
+    ln_publish();
+    zero_acc();
   }
   int st_c = 0;                 // stage holding tile kt
   int st_i = D % NSTAGE;        // stage receiving tile kt + D
@@ -430,6 +403,8 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     // prologue: the whole first tile, H0 and H1 landed for everyone before the first phase
     issue_half(0, 0); issue_half(0, 1); issue_half(0, 2); issue_half(0, 3);
     advance();
+    ln_publish();
+    zero_acc();
     wait_vmcnt<4>();
     rendezvous();
     if (wm == 1) rendezvous();   // the second wave group runs one barrier behind the first
@@ -582,7 +557,6 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   // per tile, 10 us that no K loop of 5-20 steps could hide).  Now every optional per-column vector is loaded
   // UNCONDITIONALLY (absent ones point at the zero page; clamped column index), once per 16-column block before its row
   // loop, together with the block's residual rows: one batch of loads per (ni, gp), i.e. 2 NI round trips per tile.
-  ln_finish();
   const float scale = a.scale;
   const float* const zf = (const float*)a.zero;
   // ---- interior tiles (every row < M, column blocks of 16 wholly inside or outside n_end), bf16 / GEGLU output ----
@@ -592,6 +566,50 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   // no bounds masks, and the optional terms (folded LayerNorm, residual, time-embedding row, row statistics) are
   // compile-time flags of a generic lambda, selected by a wave-uniform branch.  Edge tiles, fp32 / pair-softmax /
   // split-K / sub-pixel outputs take the general epilogue below.
+  // Row statistics of the output (ln_out): every tile has stored its slots with write-through (sc1) stores; the row
+  // block's last column tile to get here (one relaxed agent-scope ticket per workgroup - the hand-off of
+  // norm.hip::gn_stats_kernel) reduces the block's N / 32 slots per row to (mean, rstd) in a FIXED order (8 threads per
+  // row, fp64 for the cancellation): bit-reproducible whichever tile is last, no extra launch, and the consumers' tiles
+  // read 8 bytes per row.
+  auto store_slot = [&](float2* p, float s2, float q2) {
+    const unsigned long long bits = ((unsigned long long)__float_as_uint(q2) << 32) | __float_as_uint(s2);
+    __hip_atomic_store((unsigned long long*)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto ln_out_finish = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slot stores have been written through
+    __syncthreads();                                     // (also: every wave is past the K loop - the ring is free)
+    int* const flag = (int*)smem;
+    if (tid == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(&a.ln_ctr[tile_m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = ticket == (unsigned)(a.tiles_n - 1);
+      if (last) __hip_atomic_store(&a.ln_ctr[tile_m], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+    const int slots = a.N >> 5;
+    float2* const mr = a.ln_out + (long long)a.M * slots;
+    static_assert(BM % (NT / 8) == 0, "whole passes of NT / 8 rows");
+    for (int r = tid >> 3; r < BM; r += NT >> 3) {
+      const int m = m0 + r, sub = tid & 7;
+      double sd = 0.0, qd = 0.0;
+      if (m < a.M) {
+        const unsigned long long* p = (const unsigned long long*)(a.ln_out + (long long)m * slots);
+        for (int sl = sub; sl < slots; sl += 8) {
+          const unsigned long long bits = __hip_atomic_load(p + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sd += (double)__uint_as_float((unsigned)bits);
+          qd += (double)__uint_as_float((unsigned)(bits >> 32));
+        }
+      }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) { sd += __shfl_xor(sd, o); qd += __shfl_xor(qd, o); }
+      if (sub == 0 && m < a.M) {   // fp64 for the cancellation E[x^2] - mean^2 only; 1/sqrt in fp32 (v_rsq_f32, ~1 ulp)
+        const double mean = sd * a.inv_n;
+        const float var = fmaxf((float)__builtin_fma(qd, a.inv_n, -mean * mean), 0.f);
+        mr[m] = make_float2((float)mean, __builtin_amdgcn_rsqf(var + a.ln_eps));
+      }
+    }
+  };
   if constexpr (!TRANS) {
     const bool interior = m0 + BM <= a.M && (a.n_end & 15) == 0 && a.splits <= 1 && !a.subpix;
     const int lrow = wm * TM + l31;          // the lane's first row inside the tile
@@ -740,7 +758,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
 #pragma unroll
               for (int mi = 0; mi < MI; ++mi) {
                 const float s2 = ps[mi] + __shfl_xor(ps[mi], 32), q2 = pq[mi] + __shfl_xor(pq[mi], 32);
-                if (half == 0) pl[mi][ni] = make_float2(s2, q2);
+                if (half == 0) store_slot(pl[mi] + ni, s2, q2);
               }
             }
           }
@@ -760,7 +778,10 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
         case 4: bf16_fast(F{}, F{}, T{}, F{}); break;    // resnet conv1: + time-embedding row
         default: done = false;
       }
-      if (done) return;
+      if (done) {
+        if (fLNO) ln_out_finish();
+        return;
+      }
     }
   }
   if constexpr (!TRANS) {
@@ -940,10 +961,11 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
         for (int mi = 0; mi < MI; ++mi) {
           const float s2 = ps[mi] + __shfl_xor(ps[mi], 32), q2 = pq[mi] + __shfl_xor(pq[mi], 32);
           const int m = m0 + wm * TM + mi * 32 + l31;
-          if (half == 0 && m < a.M && nb < a.n_end) a.ln_out[(long long)m * (a.N >> 5) + (nb >> 5)] = make_float2(s2, q2);
+          if (half == 0 && m < a.M && nb < a.n_end) store_slot(a.ln_out + (long long)m * (a.N >> 5) + (nb >> 5), s2, q2);
         }
       }
     }
+    if (a.ln_out && a.splits <= 1) ln_out_finish();
   } else {
     // transposed section (V^T of the fused QKV projection): out[z][img][n][tok], 8 consecutive tokens per lane; the
     // lane's column n = nb + l31 is fixed per ni: its bias / LayerNorm constants are loaded once per ni
@@ -1197,7 +1219,6 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.ln_in = (const float2*)op->p[9];
   a.ln_g = (const float*)op->p[10];
   a.ln_c = (const float*)op->p[11];
-  a.ln_slots = op->i[26];
   a.ln_eps = op->f[1];
   a.sm_scale = op->f[2];
   a.sm_cols = op->i[27];
@@ -1209,14 +1230,15 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
     a.gelu_erf = erf_ab;
   }
   if (a.ln_out) {
+    MG_REQUIRE((a.M + 63) / 64 <= MG_LN_COUNTERS, "igemm: too many row blocks for the row-statistics tickets (M %d)", a.M);
     MG_REQUIRE(a.epi == MG_EPI_BF16 && trans_from < 0 && a.N % 32 == 0 && batch_z == 1 && (uintptr_t)a.ln_out % 8 == 0,
                "igemm: row statistics (ln_out) need the bf16 epilogue, N %% 32 == 0, no transposed section / batching");
     a.splits = -1;   // the statistics are taken in the tile epilogue, not in the split-K reduction
   }
   if (a.ln_in) {
-    MG_REQUIRE(a.taps == 1 && batch_z == 1 && !a.A1 && a.ln_g && a.ln_c && a.ln_slots * 32 == a.Cin && (uintptr_t)a.ln_in % 8 == 0 &&
+    MG_REQUIRE(a.taps == 1 && batch_z == 1 && !a.A1 && a.ln_g && a.ln_c && (uintptr_t)a.ln_in % 8 == 0 &&
                (uintptr_t)a.ln_g % 16 == 0 && (uintptr_t)a.ln_c % 16 == 0,
-               "igemm: folded LayerNorm needs a Linear layer (taps 1), ln_g / ln_c and one statistics slot per 32 input columns");
+               "igemm: folded LayerNorm needs a Linear layer (taps 1), ln_g / ln_c and the (mean, rstd) table of its input rows");
     a.splits = -1;
   }
   a.kps = 0;
@@ -1226,7 +1248,8 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.fd_wo = mg_make_fastdiv(a.Wo > 0 ? a.Wo : 1);
   a.fd_per_z = a.fd_tiles = a.fd_tiles_n = a.fd_cpt = mg_make_fastdiv(1);
   a.lin = a.taps == 1 && a.stride == 1 && a.pad == 0 && a.Hu == 0 && a.Ho == a.H && a.Wo == a.W;
-  a.inv_cin = 1.0 / (double)(a.Cin > 0 ? a.Cin : 1);
+  a.inv_n = 1.0 / (double)(a.N > 0 ? a.N : 1);
+  a.ln_ctr = g_ln_counters;
   a.tiles_m = a.tiles_n = 0;
   MG_REQUIRE(g_zero_page || g_dry_run, "igemm: mg_init() not called");
   MG_REQUIRE(a.A && a.Wt && (a.out || out2), "igemm: null pointer");

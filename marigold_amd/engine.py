@@ -191,6 +191,17 @@ class Builder:
     def raw(self, nbytes):
         return self.pool.get(nbytes)
 
+    def ln_table(self, M, C):
+        """Row-statistics buffer of a tensor [M][C] that feeds a folded LayerNorm: C/32 (sum, sum of squares) slots per
+        row written by the producing GEMM's tiles, then [M] (mean, rstd) written by its last column tile per row block
+        (MG_OP_IGEMM ln_out)."""
+        return self.raw(M * (C // 32 + 1) * 8)
+
+    @staticmethod
+    def ln_mean_rstd(table, M, C):
+        """Address of the (mean, rstd) rows inside ``ln_table(M, C)`` - the ln_in of the consuming Linear layers."""
+        return table.data_ptr() + M * (C // 32) * 8
+
     def free(self, *xs):
         for x in xs:
             if x is None:
@@ -408,7 +419,7 @@ class Builder:
         if st is not None:
             wqkv, g, c = self.ws.qkv_ln(prefix, norm)
             self.add(O.igemm(h.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, out2=vt,
-                             trans_from=2 * C, ldt=ldvt, ln_in=st, ln_g=g, ln_c=c), f"{prefix}.qkv")
+                             trans_from=2 * C, ldt=ldvt, ln_in=self.ln_mean_rstd(st, M, C), ln_g=g, ln_c=c), f"{prefix}.qkv")
         else:   # A/B form: the LayerNorm as its own pass
             y = self.layer_norm(h, norm)
             self.add(O.igemm(y.t, self.ws.qkv(prefix, False)[0], qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C,
@@ -432,7 +443,7 @@ class Builder:
             # scores in HBM, no softmax launch
             wqk, g, c, vot, npad = self.ws.cross_ln(prefix, ctx, heads, norm)
             p = self.raw(M * npad * 2)
-            self.add(O.linear(h.t, wqk, p, M=M, K=C, N=npad, epi=L.EPI_SOFTMAX2, ln_in=st, ln_g=g, ln_c=c,
+            self.add(O.linear(h.t, wqk, p, M=M, K=C, N=npad, epi=L.EPI_SOFTMAX2, ln_in=self.ln_mean_rstd(st, M, C), ln_g=g, ln_c=c,
                               sm_scale=1.0 / math.sqrt(C // heads), sm_cols=2 * heads), f"{prefix}.scores+softmax2")
             self.add(O.linear(p, vot, h.t, M=M, K=npad, N=C, bias=self.ws.bias(f"{prefix}.to_out.0"),
                               residual=h.t, ln_out=st_out), f"{prefix}.blend")
@@ -457,7 +468,7 @@ class Builder:
         statistics written by the epilogue of the GEMM that produced the stream (ln_out)."""
         C = x.C
         g = self.group_norm(x, f"{name}.norm", 1e-6, False)
-        st = [self.raw(x.M * (C // 32) * 8) if FOLD_LN else None for _ in range(3)]
+        st = [self.ln_table(x.M, C) if FOLD_LN else None for _ in range(3)]
         h = self.dense(g, self.ws.mat(f"{name}.proj_in"), self.ws.bias(f"{name}.proj_in"), C,
                        label=f"{name}.proj_in", ln_out=st[0])
         self.free(g)
@@ -466,7 +477,8 @@ class Builder:
         self.cross_attention2(h, st[1], f"{b}.attn2", f"{b}.norm2", heads, ctx, st[2])
         if FOLD_LN:
             wg, gg, cg = self.ws.geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3")
-            ff = self.dense(h, wg, None, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu", ln=(st[2], gg, cg))
+            ff = self.dense(h, wg, None, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu",
+                            ln=(self.ln_mean_rstd(st[2], h.M, C), gg, cg))
         else:
             y = self.layer_norm(h, f"{b}.norm3")
             wg, bg = self.ws.geglu(f"{b}.ff.net.0.proj")

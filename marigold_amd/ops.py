@@ -51,7 +51,7 @@ def igemm(a, w, out, *, B, H, W, Cin, Ho, Wo, N, taps=1, stride=1, pad=0, up=Non
     return make_op(L.OP_IGEMM,
                    i=[B, H, W, Cin, Ho, Wo, N, taps, stride, pad, hu, wu, epi, ldo, trans_from,
                       batch_z, ldr, lda, ldt, variant, ldw, int(rowvec_bcast), n_alg, k_alg, C0, lda1,
-                      (taps * Cin) // 32 if ln_in is not None else 0, sm_cols],
+                      0, sm_cols],
                    f=[scale, ln_eps, sm_scale], p=[a, w, out, bias, rowvec, residual, out2, a1, ln_out, ln_in, ln_g, ln_c],
                    l=list(zstrides))
 
