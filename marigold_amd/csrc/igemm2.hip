@@ -593,12 +593,18 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     for (int r = tid >> 3; r < BM; r += NT >> 3) {
       const int m = m0 + r, sub = tid & 7;
       double sd = 0.0, qd = 0.0;
-      if (m < a.M) {
+      if (m < a.M) {   // up to 5 slots per thread (1280 channels): all in flight before any is consumed
         const unsigned long long* p = (const unsigned long long*)(a.ln_out + (long long)m * slots);
-        for (int sl = sub; sl < slots; sl += 8) {
-          const unsigned long long bits = __hip_atomic_load(p + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          sd += (double)__uint_as_float((unsigned)bits);
-          qd += (double)__uint_as_float((unsigned)(bits >> 32));
+        for (int sl0 = sub; sl0 < slots; sl0 += 40) {
+          unsigned long long v[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            v[i] = sl0 + 8 * i < slots ? __hip_atomic_load(p + sl0 + 8 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            sd += (double)__uint_as_float((unsigned)v[i]);
+            qd += (double)__uint_as_float((unsigned)(v[i] >> 32));
+          }
         }
       }
 #pragma unroll

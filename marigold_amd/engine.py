@@ -226,6 +226,8 @@ class Builder:
         # ~768 (chunk, image) blocks: covers the 256 CUs three times over while keeping the
         # second-level reduction (gn_finalize) short; >= 32 rows per chunk
         chunks = max(1, min(HW // 32, max(16, 768 // B)))
+        # (round 2: splitting finer - 8 rows per thread on every level, or on the deep levels only - measured +5.6 ms per
+        # map / no change: profiles/r2_ab_gn_chunks_lost.log)
         slots = chunks * len(srcs)
         part = self.raw(B * slots * self.groups * 2 * 4)
         ss = self.raw(B * 2 * C * 4)
