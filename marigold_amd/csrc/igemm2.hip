@@ -1335,7 +1335,9 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
   if (geglu && K >= 1280 && many256) return 62;   // 1280 -> 10240: 831 vs 760-790
   // (round 2, profiles/r2_sweep5_short_k_tiles.log: the 4-wave form of the same tile - wave tile 128x64, half the
   // fragment reads per MFMA - is 10-13 % ahead of the 8-wave one on the GEGLU projections and the 640-channel linears)
-  if (N % 128 == 0 && tm256 * (N / 128) * batch_z >= 400 && (geglu || K <= 768)) return 51;
+  // (round 2 after the prologue / epilogue diet, profiles/r2_sweep8_lean_epilogue.log: plain Linear layers with K = 640
+  // run better on 128x128 / 2 stages - 640 -> 1920: 609 vs 520, 640 -> 640: 528 vs 504 - and fall through to it below)
+  if (N % 128 == 0 && tm256 * (N / 128) * batch_z >= 400 && (geglu || K <= 512)) return 51;
   // 256x256 with the ping-pong schedule (two wave groups one barrier apart, 2nd DMA piece among the MFMAs):
   // +3...10 % over the one-barrier 256x256 tile in interleaved rounds (VAE 512-channel convs 1068 vs 996)
   if (many256) return 62;
@@ -1346,7 +1348,9 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
   const long long t128x64 = ((M + 127) / 128) * ((N + 63) / 64) * batch_z;
   if (t256 >= 200) {
     if (N % 128 == 64) return 35;
-    return K <= 1536 ? 32 : 33;
+    // long K: the 256x128 tile with the half-K-step software pipeline (round 2, profiles/r2_sweep10_conv_igemm_lean.log:
+    // 956-1021 vs 911-976 TFLOP/s for the one-barrier-per-tile loop on the 24x24 / 48x48 convolutions)
+    return K <= 1536 ? 32 : 36;
   }
   if (t128x64 >= 96) return 35;
   return 23;
