@@ -1335,9 +1335,8 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
   if (geglu && K >= 1280 && many256) return 62;   // 1280 -> 10240: 831 vs 760-790
   // (round 2, profiles/r2_sweep5_short_k_tiles.log: the 4-wave form of the same tile - wave tile 128x64, half the
   // fragment reads per MFMA - is 10-13 % ahead of the 8-wave one on the GEGLU projections and the 640-channel linears)
-  // (round 2 after the prologue / epilogue diet, profiles/r2_sweep8_lean_epilogue.log: plain Linear layers with K = 640
-  // run better on 128x128 / 2 stages - 640 -> 1920: 609 vs 520, 640 -> 640: 528 vs 504 - and fall through to it below)
-  if (N % 128 == 0 && tm256 * (N / 128) * batch_z >= 400 && (geglu || K <= 512)) return 51;
+  // (K = 640 linears on 128x128 / 2 stages instead: ahead in the isolated sweep 8, no change in the pipeline - not kept)
+  if (N % 128 == 0 && tm256 * (N / 128) * batch_z >= 400 && (geglu || K <= 768)) return 51;
   // 256x256 with the ping-pong schedule (two wave groups one barrier apart, 2nd DMA piece among the MFMAs):
   // +3...10 % over the one-barrier 256x256 tile in interleaved rounds (VAE 512-channel convs 1068 vs 996)
   if (many256) return 62;
