@@ -172,7 +172,13 @@ enum mg_op_kind {
 
 enum { MG_EPI_BF16 = 0, MG_EPI_GEGLU = 1, MG_EPI_F32 = 2,
        MG_EPI_SOFTMAX2 = 3 /* bf16 out = softmax over column pairs (2h, 2h+1) of f[2] * acc; i[27] = real columns, the rest -> 0:
-                              the collapsed 2-token cross-attention's probabilities straight from the scores GEMM */ };
+                              the collapsed 2-token cross-attention's probabilities straight from the scores GEMM */,
+       MG_EPI_XATTN2 = 4   /* the whole collapsed cross-attention in one launch (diffusers Attention with a 2-token context,
+                              BasicTransformerBlock.attn2): N = 64 score columns as in MG_EPI_SOFTMAX2; the probabilities stay in
+                              registers as the operand of a second MFMA stage against p[6] = W2 bf16 [i[28]][64] (the context's
+                              values pushed through to_out), out[M][i[28]] = P W2^T + bias (p[3], of the second stage) + residual
+                              (p[5]); p[8] = f32 [M][2] (mean, rstd) of the OUTPUT rows (one wave owns whole rows: no slots, no
+                              ticket).  out may alias A and the residual (a row block belongs to one workgroup). */ };
 enum { MG_POST_NONE = 0, MG_POST_DEPTH = 1, MG_POST_NORMALS = 2, MG_POST_UNIT = 3 /* IID: clip, (x+1)/2 */,
        MG_POST_SCHED = 4 /* scheduler update in place of the store, see MG_OP_POST_NCHW */ };
 

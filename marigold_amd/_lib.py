@@ -21,7 +21,7 @@ OP_ENS_DEPTH_STATS, OP_ENS_DEPTH_MEDIAN, OP_ENS_DEPTH_NORM, OP_ENS_NORMALS = 20,
 OP_RESIZE = 24
 OP_COLORIZE = 25
 OP_MEMSET, OP_COPY = 30, 31
-EPI_BF16, EPI_GEGLU, EPI_F32, EPI_SOFTMAX2 = 0, 1, 2, 3
+EPI_BF16, EPI_GEGLU, EPI_F32, EPI_SOFTMAX2, EPI_XATTN2 = 0, 1, 2, 3, 4
 POST_NONE, POST_DEPTH, POST_NORMALS, POST_UNIT, POST_SCHED = 0, 1, 2, 3, 4
 
 OP_NAMES = {v: k[3:].lower() for k, v in list(globals().items()) if k.startswith("OP_")}

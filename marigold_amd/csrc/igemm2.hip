@@ -64,6 +64,9 @@ struct Igemm2Args {
   mg_fastdiv fd_per_z, fd_tiles, fd_tiles_n, fd_rpi, fd_wo, fd_cpt;
   int lin;
   double inv_n;     // 1 / N (row statistics of the output -> mean, rstd)
+  const bf16_t* w2;  // MG_EPI_XATTN2: second-stage weights [c2][64]
+  int c2;
+  double inv_c2;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -616,6 +619,110 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
       }
     }
   };
+  // ---- MG_EPI_XATTN2: the collapsed 2-token cross-attention in one launch (tile 128 x 64, one wave = 32 whole rows) ----
+  // Stage 1 is the pair-softmax epilogue; its packed probabilities of the (ni, gp) block ARE the pixel-side MFMA fragment
+  // of k-block 2 ni + gp (lane = row, 8 consecutive k per half), so stage 2 (P x W2^T, K = 64) runs straight from
+  // registers: per 32 output channels four weight fragments from global (L2-resident, next block prefetched), four MFMAs,
+  // then the usual regroup + bias + residual + store.  The wave holds whole rows: (mean, rstd) of the new residual stream
+  // come out directly.  In-place on the residual stream is safe - this tile's rows were staged before its last barrier and
+  // no other workgroup touches them.
+  if constexpr (!TRANS && WGN == 1 && TN == 64 && MI == 1) {
+    if (a.epi == MG_EPI_XATTN2) {
+      const int lrow = wm * TM + l31, m = m0 + lrow;
+      const bool row_ok = m < a.M;
+      const int mc = row_ok ? m : a.M - 1;
+      float l_sc = scale, l_mr = 0.f;
+      if (a.ln_in) {
+        const float2 lst = lnst[lrow];
+        l_sc = lst.y * scale;
+        l_mr = -lst.y * lst.x;
+      }
+      const float* const pg = a.ln_in ? a.ln_g + 8 * half : zf;
+      const float* const pc = a.ln_in ? a.ln_c + 8 * half : zf;
+      bf16x8 pf[4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int c = ni * 32 + gp * 16;
+          const float4 g0 = *(const float4*)(pg + c), g1 = *(const float4*)(pg + c + 4);
+          const float4 c0 = *(const float4*)(pc + c), c1 = *(const float4*)(pc + c + 4);
+          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+          const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) half_swap(acc[ni][0][8 * gp + j], acc[ni][0][8 * gp + 4 + j], v[j], v[4 + j]);
+          uint32_t w4[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float s0 = __builtin_fmaf(v[2 * k], l_sc, __builtin_fmaf(l_mr, gg[2 * k], cc[2 * k])) * a.sm_scale;
+            const float s1 = __builtin_fmaf(v[2 * k + 1], l_sc, __builtin_fmaf(l_mr, gg[2 * k + 1], cc[2 * k + 1])) * a.sm_scale;
+            const float mx = fmaxf(s0, s1);
+            const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx);
+            const float inv = 1.0f / (e0 + e1);
+            w4[k] = (c + 8 * half + 2 * k < a.sm_cols) ? pack2bf(e0 * inv, e1 * inv) : 0u;
+          }
+          pf[ni * 2 + gp] = __builtin_bit_cast(bf16x8, make_uint4(w4[0], w4[1], w4[2], w4[3]));
+        }
+      const bf16_t* const wrow = a.w2 + (long long)l31 * 64 + 8 * half;           // + cb * 2048 + kb * 16
+      bf16_t* const po = (bf16_t*)a.out + (long long)mc * a.ldo + 8 * half;      // + cb * 32 + gp * 16
+      const bf16_t* const pr = a.res ? a.res + (long long)mc * a.ldr + 8 * half : (const bf16_t*)zf;
+      const int rstep = a.res ? 32 : 0;
+      const float* const pb = (a.bias ? a.bias : zf) + 8 * half;
+      const int bstep = a.bias ? 32 : 0;
+      const int ncb = a.c2 >> 5;
+      double sd = 0.0, qd = 0.0;
+      uint4 wf[4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) wf[kb] = *(const uint4*)(wrow + kb * 16);
+      for (int cb = 0; cb < ncb; ++cb) {
+        uint4 wn[4];
+        const int cbn = cb + 1 < ncb ? cb + 1 : cb;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) wn[kb] = *(const uint4*)(wrow + (long long)cbn * 2048 + kb * 16);
+        const uint4 r0 = *(const uint4*)(pr + cb * rstep), r1 = *(const uint4*)(pr + cb * rstep + (a.res ? 16 : 0));
+        const float4 b00 = *(const float4*)(pb + cb * bstep), b01 = *(const float4*)(pb + cb * bstep + 4);
+        const float4 b10 = *(const float4*)(pb + cb * bstep + (a.bias ? 16 : 0)), b11 = *(const float4*)(pb + cb * bstep + (a.bias ? 20 : 4));
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kb]), pf[kb], acc2, 0, 0, 0);
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) half_swap(acc2[8 * gp + j], acc2[8 * gp + 4 + j], v[j], v[4 + j]);
+          const float4 ba = gp ? b10 : b00, bb = gp ? b11 : b01;
+          const uint4 r4 = a.res ? (gp ? r1 : r0) : make_uint4(0, 0, 0, 0);
+          v[0] += ba.x + bflo(r4.x); v[1] += ba.y + bfhi(r4.x); v[2] += ba.z + bflo(r4.y); v[3] += ba.w + bfhi(r4.y);
+          v[4] += bb.x + bflo(r4.z); v[5] += bb.y + bfhi(r4.z); v[6] += bb.z + bflo(r4.w); v[7] += bb.w + bfhi(r4.w);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { ps += v[j]; pq = __builtin_fmaf(v[j], v[j], pq); }
+          uint4 pk;
+          pk.x = cvt_pk_bf16(v[0], v[1]); pk.y = cvt_pk_bf16(v[2], v[3]);
+          pk.z = cvt_pk_bf16(v[4], v[5]); pk.w = cvt_pk_bf16(v[6], v[7]);
+          if (row_ok) *(uint4*)(po + cb * 32 + gp * 16) = pk;
+        }
+        sd += (double)ps;
+        qd += (double)pq;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) wf[kb] = wn[kb];
+      }
+      if (a.ln_out) {   // here: [M] (mean, rstd) rows of the output, written directly
+        sd += __shfl_xor(sd, 32);
+        qd += __shfl_xor(qd, 32);
+        if (half == 0 && row_ok) {
+          const double mean = sd * a.inv_c2;
+          const float var = fmaxf((float)__builtin_fma(qd, a.inv_c2, -mean * mean), 0.f);
+          a.ln_out[m] = make_float2((float)mean, __builtin_amdgcn_rsqf(var + a.ln_eps));
+        }
+      }
+      return;
+    }
+  }
   if constexpr (!TRANS) {
     const bool interior = m0 + BM <= a.M && (a.n_end & 15) == 0 && a.splits <= 1 && !a.subpix;
     const int lrow = wm * TM + l31;          // the lane's first row inside the tile
@@ -1142,6 +1249,7 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
     case 27: return launch2<128, 128, 2, 2, 3, TRANS>(a, batch_z, s);
     case 28: return launch2<128, 128, 2, 2, 4, TRANS>(a, batch_z, s);
     case 29: return launch2<128, 32, 4, 1, 3, TRANS>(a, batch_z, s);  // N <= 32 (4 <-> C boundary convs)
+    case 54: return launch2<128, 64, 4, 1, 3, TRANS, true>(a, batch_z, s);   // one wave = 32 rows x all 64 columns (MG_EPI_XATTN2)
     case 30: return launch2<256, 256, 2, 4, 2, TRANS>(a, batch_z, s);
     case 31: return launch2<256, 128, 4, 2, 2, TRANS, true>(a, batch_z, s);
     case 32: return launch2<128, 128, 2, 2, 2, TRANS, true>(a, batch_z, s);
@@ -1228,6 +1336,20 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.ln_eps = op->f[1];
   a.sm_scale = op->f[2];
   a.sm_cols = op->i[27];
+  a.w2 = nullptr;
+  a.c2 = 0;
+  a.inv_c2 = 0.0;
+  if (a.epi == MG_EPI_XATTN2) {
+    a.w2 = (const bf16_t*)op->p[6];
+    a.c2 = op->i[28];
+    out2 = nullptr;
+    MG_REQUIRE(trans_from < 0 && batch_z == 1 && a.taps == 1 && a.N == 64 && a.sm_cols > 0 && a.sm_cols % 2 == 0 && a.sm_cols <= 64 &&
+               a.w2 && (uintptr_t)a.w2 % 16 == 0 && a.c2 > 0 && a.c2 % 32 == 0 && a.ldo >= a.c2 && (long long)a.c2 * 4 + 64 <= MG_ZERO_BYTES &&
+               (variant == 0 || variant == 54) && (!a.bias || (uintptr_t)a.bias % 16 == 0),
+               "igemm: the fused cross-attention epilogue takes N = 64 score columns, second-stage weights [c2][64] (c2 %% 32 == 0) in p[6]");
+    variant = 54;
+    a.inv_c2 = 1.0 / (double)a.c2;
+  }
   if (a.epi == MG_EPI_SOFTMAX2)
     MG_REQUIRE(trans_from < 0 && batch_z == 1 && a.sm_cols > 0 && a.sm_cols % 2 == 0 && a.sm_cols <= a.N && !a.res,
                "igemm: the pair-softmax epilogue takes an even number of score columns <= N, no residual / transposed section");
@@ -1235,7 +1357,10 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
     static const int erf_ab = [] { const char* e = getenv("MARIGOLD_GELU_ERF"); return (e && e[0] == '1') ? 1 : 0; }();
     a.gelu_erf = erf_ab;
   }
-  if (a.ln_out) {
+  if (a.ln_out && a.epi == MG_EPI_XATTN2) {
+    MG_REQUIRE((uintptr_t)a.ln_out % 8 == 0, "igemm: misaligned (mean, rstd) table");
+    a.splits = -1;
+  } else if (a.ln_out) {
     MG_REQUIRE((a.M + 63) / 64 <= MG_LN_COUNTERS, "igemm: too many row blocks for the row-statistics tickets (M %d)", a.M);
     MG_REQUIRE(a.epi == MG_EPI_BF16 && trans_from < 0 && a.N % 32 == 0 && batch_z == 1 && (uintptr_t)a.ln_out % 8 == 0,
                "igemm: row statistics (ln_out) need the bf16 epilogue, N %% 32 == 0, no transposed section / batching");

@@ -23,7 +23,8 @@ LATENT_SCALE = 0.18215  # marigold_depth_pipeline.py:118
 # A/B switches for tuning runs (defaults are the product configuration)
 USE_PATCH = os.environ.get("MARIGOLD_PATCH_CONV", "1") != "0"      # patch-resident conv3x3 kernel where eligible
 FUSE_GN = os.environ.get("MARIGOLD_FUSE_GN", "auto")               # auto | all | none: GroupNorm apply inside the conv
-FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"           # LayerNorms folded into the Linear layers that consume them
+FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"
+XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)           # LayerNorms folded into the Linear layers that consume them
 
 
 class Act:
@@ -441,9 +442,17 @@ class Builder:
         the first one."""
         C, M = h.C, h.M
         if st is not None:
-            # scores GEMM with the LayerNorm folded in and the 2-key softmax as its epilogue: probabilities out, no fp32
-            # scores in HBM, no softmax launch
+            # ONE launch: scores GEMM with the LayerNorm folded in, the 2-key softmax on its accumulators, the probabilities
+            # as the register operand of the blend GEMM (x the context's values pushed through to_out), + bias + residual,
+            # in place on the residual stream, (mean, rstd) of the new rows for the next folded LayerNorm
             wqk, g, c, vot, npad = self.ws.cross_ln(prefix, ctx, heads, norm)
+            if XATTN_FUSED and npad == 64 and C % 32 == 0:
+                self.add(O.linear(h.t, wqk, h.t, M=M, K=C, N=npad, epi=L.EPI_XATTN2, ln_in=self.ln_mean_rstd(st, M, C),
+                                  ln_g=g, ln_c=c, sm_scale=1.0 / math.sqrt(C // heads), sm_cols=2 * heads, out2=vot, c2=C, ldo=C,
+                                  bias=self.ws.bias(f"{prefix}.to_out.0"), residual=h.t, ldr=C,
+                                  ln_out=None if st_out is None else self.ln_mean_rstd(st_out, M, C)),
+                         f"{prefix}.scores+softmax2+blend")
+                return
             p = self.raw(M * npad * 2)
             self.add(O.linear(h.t, wqk, p, M=M, K=C, N=npad, epi=L.EPI_SOFTMAX2, ln_in=self.ln_mean_rstd(st, M, C), ln_g=g, ln_c=c,
                               sm_scale=1.0 / math.sqrt(C // heads), sm_cols=2 * heads), f"{prefix}.scores+softmax2")

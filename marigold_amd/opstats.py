@@ -35,7 +35,11 @@ def op_cost(op):
             byts = B * H * W * Cin * 2 + bz * (N * K * 2 + M * n_out * osz)
         else:
             byts = bz * (B * H * W * Cin * 2 + N * K * 2 + M * n_out * osz)
-        if op.p[5]:
+        if epi == L.EPI_XATTN2:   # second stage: P [M][N] x W2 [c2][N] -> out [M][c2] (+ residual)
+            c2 = i[28]
+            flops += 2 * M * c2 * N
+            byts = B * H * W * Cin * 2 + N * K * 2 + c2 * N * 2 + M * c2 * 2 + (M * c2 * 2 if op.p[5] else 0)
+        elif op.p[5]:
             byts += bz * M * n_out * 2   # fused residual read
     elif k == L.OP_CONV3X3:
         B, H, W, C0, C1, N, subpix = (i[j] for j in range(7))

@@ -550,6 +550,57 @@ def test_igemm_pair_softmax_epilogue(dev):
         assert (out[:, 2 * heads:] == 0).all()
 
 
+def test_igemm_fused_cross_attention(dev):
+    """MG_EPI_XATTN2: LayerNorm -> 2-token scores -> pair softmax -> blend with the pushed-through values + bias + residual,
+    in place on the residual stream, and (mean, rstd) of the new rows - against the same chain in torch fp32 (probabilities
+    rounded to bf16 where the kernel packs them into the second MFMA stage's operand)."""
+    from marigold_amd import _lib as L, ops, weights as Wm
+    g = torch.Generator().manual_seed(41)
+    for M, C, heads in ((900, 320, 5), (333, 640, 10), (130, 1280, 20), (128, 64, 1)):
+        npad = 64
+        x = _bf(torch.randn(M, C, generator=g) * 1.2 + 0.3 * torch.randn(M, 1, generator=g))
+        gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+        wqk = torch.zeros(npad, C)
+        wqk[:2 * heads] = torch.randn(2 * heads, C, generator=g) * (3.0 / math.sqrt(C))
+        vot = torch.zeros(C, npad)
+        vot[:, :2 * heads] = torch.randn(C, 2 * heads, generator=g) * 0.5
+        vot = _bf(vot)
+        bias = torch.randn(C, generator=g) * 0.1
+        scale = 1.0 / math.sqrt(64)
+        y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+        sc = (y @ wqk.t())[:, :2 * heads].reshape(M, heads, 2) * scale
+        P = torch.zeros(M, npad)
+        P[:, :2 * heads] = torch.softmax(sc, dim=-1).reshape(M, 2 * heads)
+        ref = _bf(P) @ vot.t() + bias + x
+        wp, gv, cv = Wm.fold_layernorm(wqk, None, gamma, beta)
+        stx = torch.stack([x.mean(-1), 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5)], dim=-1).to(dev).contiguous()
+        first = None
+        for rep_ in range(3):
+            h = x.to(dev, torch.bfloat16).clone()
+            mr = torch.full((M, 2), float("nan"), device=dev)
+            keep = (wp.to(dev), gv.to(dev), cv.to(dev), vot.to(dev, torch.bfloat16), bias.to(dev))
+            _run(ops.linear(h, keep[0], h, M=M, K=C, N=npad, epi=L.EPI_XATTN2, ln_in=stx, ln_g=keep[1], ln_c=keep[2], sm_scale=scale,
+                            sm_cols=2 * heads, out2=keep[3], c2=C, ldo=C, bias=keep[4], residual=h, ldr=C, ln_out=mr))
+            if first is None:
+                first = (h.clone(), mr.clone())
+                _close(f"fused cross-attention C{C}", h, ref, tol=1.5e-2)
+                _close(f"fused cross-attention C{C} mean", mr[:, 0], ref.mean(-1), tol=3e-3)
+                _close(f"fused cross-attention C{C} rstd", mr[:, 1], 1.0 / torch.sqrt(ref.var(-1, unbiased=False) + 1e-5), tol=3e-3)
+            else:
+                assert torch.equal(first[0], h) and torch.equal(first[1], mr), "fused cross-attention is not bit-repeatable"
+    # without residual / bias / statistics, not in place
+    M, C, heads = 200, 320, 5
+    x = _bf(torch.randn(M, C, generator=g))
+    wqk = torch.zeros(64, C); wqk[:10] = torch.randn(10, C, generator=g) / math.sqrt(C)
+    vot = _bf(torch.randn(C, 64, generator=g) * 0.5)
+    sc = (x @ _bf(wqk).t())[:, :10].reshape(M, heads, 2) * 0.125
+    P = torch.zeros(M, 64); P[:, :10] = torch.softmax(sc, dim=-1).reshape(M, 10)
+    out = torch.full((M, C), float("nan"), device=dev, dtype=torch.bfloat16)
+    keep = (x.to(dev, torch.bfloat16), _bf(wqk).to(dev, torch.bfloat16), vot.to(dev, torch.bfloat16))
+    _run(ops.linear(keep[0], keep[1], out, M=M, K=C, N=64, epi=L.EPI_XATTN2, sm_scale=0.125, sm_cols=10, out2=keep[2], c2=C, ldo=C))
+    _close("fused cross-attention plain", out, _bf(P) @ vot.t(), tol=1.5e-2)
+
+
 def test_igemm_pingpong_short_k_and_repeatability(dev):
     """Tile variant 60 (two wave groups one barrier apart, four phases per K tile): the one- and two-tile K loops
     (prologue / drain only), and a many-tile problem launched repeatedly - every launch must give the same bits
