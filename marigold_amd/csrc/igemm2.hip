@@ -16,6 +16,12 @@
 //     output channels of one pixel -> 16-byte NHWC stores / residual loads (32-byte for fp32),
 //     v_cvt_pk_bf16_f32 instead of integer rounding.  GEGLU pairs u/gate rows 16 apart (32-row
 //     interleave, weights.py::pack_geglu) so it keeps the 16-byte stores too.
+//   * prologue / epilogue are written for INSTRUCTION COUNT (round 2): a short-K tile executed ~1600 instructions around
+//     its 16 MFMAs.  Launch-time constant division (common.h: fdiv), a straight-row path for Linear layers, an interior
+//     epilogue with compile-time optional terms and per-row pointers; LayerNorm statistics are finalized by the producer's
+//     last column tile (ticket hand-off), consumers read 8 bytes per row.
+//   * MG_EPI_XATTN2: the pair-softmax epilogue's packed probabilities are the register operand of a second MFMA stage
+//     (the collapsed cross-attention in one launch).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -1345,7 +1351,7 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
     out2 = nullptr;
     MG_REQUIRE(trans_from < 0 && batch_z == 1 && a.taps == 1 && a.N == 64 && a.sm_cols > 0 && a.sm_cols % 2 == 0 && a.sm_cols <= 64 &&
                a.w2 && (uintptr_t)a.w2 % 16 == 0 && a.c2 > 0 && a.c2 % 32 == 0 && a.ldo >= a.c2 && (long long)a.c2 * 4 + 64 <= MG_ZERO_BYTES &&
-               (variant == 0 || variant == 54) && (!a.bias || (uintptr_t)a.bias % 16 == 0),
+               (variant == 0 || variant == 54) && (!a.bias || (uintptr_t)a.bias % 16 == 0) && (!a.res || a.ldr >= a.c2),
                "igemm: the fused cross-attention epilogue takes N = 64 score columns, second-stage weights [c2][64] (c2 %% 32 == 0) in p[6]");
     variant = 54;
     a.inv_c2 = 1.0 / (double)a.c2;
