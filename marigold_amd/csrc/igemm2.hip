@@ -678,44 +678,55 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
       const int bstep = a.bias ? 32 : 0;
       const int ncb = a.c2 >> 5;
       double sd = 0.0, qd = 0.0;
-      uint4 wf[4];
+      // XG column blocks per pass, every load of the pass in flight before the first MFMA: one block's work is ~0.3 us
+      // against ~2 us for its residual rows to arrive from HBM (first form, one block ahead: 2 us per block, 85 us for the
+      // 40 blocks of a 1280-channel level on 45 workgroups)
+      constexpr int XG = 4;
+      for (int cb0 = 0; cb0 < ncb; cb0 += XG) {
+        uint4 wf[XG][4], rr[XG][2];
+        float4 bb[XG][4];
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) wf[kb] = *(const uint4*)(wrow + kb * 16);
-      for (int cb = 0; cb < ncb; ++cb) {
-        uint4 wn[4];
-        const int cbn = cb + 1 < ncb ? cb + 1 : cb;
+        for (int u = 0; u < XG; ++u) {
+          const int cb = cb0 + u < ncb ? cb0 + u : ncb - 1;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) wn[kb] = *(const uint4*)(wrow + (long long)cbn * 2048 + kb * 16);
-        const uint4 r0 = *(const uint4*)(pr + cb * rstep), r1 = *(const uint4*)(pr + cb * rstep + (a.res ? 16 : 0));
-        const float4 b00 = *(const float4*)(pb + cb * bstep), b01 = *(const float4*)(pb + cb * bstep + 4);
-        const float4 b10 = *(const float4*)(pb + cb * bstep + (a.bias ? 16 : 0)), b11 = *(const float4*)(pb + cb * bstep + (a.bias ? 20 : 4));
-        f32x16 acc2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kb]), pf[kb], acc2, 0, 0, 0);
-        float ps = 0.f, pq = 0.f;
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) half_swap(acc2[8 * gp + j], acc2[8 * gp + 4 + j], v[j], v[4 + j]);
-          const float4 ba = gp ? b10 : b00, bb = gp ? b11 : b01;
-          const uint4 r4 = a.res ? (gp ? r1 : r0) : make_uint4(0, 0, 0, 0);
-          v[0] += ba.x + bflo(r4.x); v[1] += ba.y + bfhi(r4.x); v[2] += ba.z + bflo(r4.y); v[3] += ba.w + bfhi(r4.y);
-          v[4] += bb.x + bflo(r4.z); v[5] += bb.y + bfhi(r4.z); v[6] += bb.z + bflo(r4.w); v[7] += bb.w + bfhi(r4.w);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { ps += v[j]; pq = __builtin_fmaf(v[j], v[j], pq); }
-          uint4 pk;
-          pk.x = cvt_pk_bf16(v[0], v[1]); pk.y = cvt_pk_bf16(v[2], v[3]);
-          pk.z = cvt_pk_bf16(v[4], v[5]); pk.w = cvt_pk_bf16(v[6], v[7]);
-          if (row_ok) *(uint4*)(po + cb * 32 + gp * 16) = pk;
+          for (int kb = 0; kb < 4; ++kb) wf[u][kb] = *(const uint4*)(wrow + (long long)cb * 2048 + kb * 16);
+          rr[u][0] = *(const uint4*)(pr + cb * rstep);
+          rr[u][1] = *(const uint4*)(pr + cb * rstep + (a.res ? 16 : 0));
+          bb[u][0] = *(const float4*)(pb + cb * bstep);
+          bb[u][1] = *(const float4*)(pb + cb * bstep + 4);
+          bb[u][2] = *(const float4*)(pb + cb * bstep + (a.bias ? 16 : 0));
+          bb[u][3] = *(const float4*)(pb + cb * bstep + (a.bias ? 20 : 4));
         }
-        sd += (double)ps;
-        qd += (double)pq;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) wf[kb] = wn[kb];
+        for (int u = 0; u < XG; ++u) {
+          const int cb = cb0 + u;
+          if (cb >= ncb) break;   // wave-uniform
+          f32x16 acc2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u][kb]), pf[kb], acc2, 0, 0, 0);
+          float ps = 0.f, pq = 0.f;
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) half_swap(acc2[8 * gp + j], acc2[8 * gp + 4 + j], v[j], v[4 + j]);
+            const float4 ba = bb[u][2 * gp], bc = bb[u][2 * gp + 1];
+            const uint4 r4 = a.res ? rr[u][gp] : make_uint4(0, 0, 0, 0);
+            v[0] += ba.x + bflo(r4.x); v[1] += ba.y + bfhi(r4.x); v[2] += ba.z + bflo(r4.y); v[3] += ba.w + bfhi(r4.y);
+            v[4] += bc.x + bflo(r4.z); v[5] += bc.y + bfhi(r4.z); v[6] += bc.z + bflo(r4.w); v[7] += bc.w + bfhi(r4.w);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ps += v[j]; pq = __builtin_fmaf(v[j], v[j], pq); }
+            uint4 pk;
+            pk.x = cvt_pk_bf16(v[0], v[1]); pk.y = cvt_pk_bf16(v[2], v[3]);
+            pk.z = cvt_pk_bf16(v[4], v[5]); pk.w = cvt_pk_bf16(v[6], v[7]);
+            if (row_ok) *(uint4*)(po + cb * 32 + gp * 16) = pk;
+          }
+          sd += (double)ps;
+          qd += (double)pq;
+        }
       }
       if (a.ln_out) {   // here: [M] (mean, rstd) rows of the output, written directly
         sd += __shfl_xor(sd, 32);
