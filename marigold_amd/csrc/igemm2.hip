@@ -830,6 +830,20 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
             l_mr[mi] = -lst.y * lst.x;
           }
         }
+        // residual rows of EVERY block up front where the registers allow (<= 12 x 16 bytes per lane): one HBM round trip
+        // per tile instead of one per 16-column block (the loads of a block cannot pass the previous block's stores - the
+        // residual may alias the output - so they were 2 NI dependent round trips of ~1.5 us each)
+        constexpr bool PRE = kRES && NI * 2 * MI <= 12;
+        uint4 rpre[PRE ? NI * 2 : 1][MI];
+        if constexpr (PRE) {
+#pragma unroll
+          for (int b = 0; b < NI * 2; ++b) {
+            const int c = (b >> 1) * 32 + (b & 1) * 16;
+            const bool in = colw + c < a.n_end;   // wave-uniform
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) rpre[b][mi] = in ? *(const uint4*)(pr[mi] + c) : make_uint4(0, 0, 0, 0);
+          }
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           float ps[MI], pq[MI];
@@ -853,7 +867,10 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
             float4 rv0[MI], rv1[MI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-              if constexpr (kRES) rr[mi] = *(const uint4*)(pr[mi] + c);
+              if constexpr (kRES) {
+                if constexpr (PRE) rr[mi] = rpre[ni * 2 + gp][mi];
+                else rr[mi] = *(const uint4*)(pr[mi] + c);
+              }
               if constexpr (kRV) { rv0[mi] = *(const float4*)(pv[mi] + c); rv1[mi] = *(const float4*)(pv[mi] + c + 4); }
             }
 #pragma unroll
