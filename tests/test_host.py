@@ -292,6 +292,19 @@ def test_full_size_programs_validate_without_gpu():
     bad.add(O.linear(buf, buf, buf, M=4, K=40, N=8), "K not a multiple of 64")
     with pytest.raises(L.MarigoldHipError, match="multiple of 64"):
         bad.validate()
+    # the fused cross-attention epilogue takes exactly 64 score columns and a second stage of whole 32-channel blocks
+    buf = torch.zeros(1 << 16, dtype=torch.uint8)
+    for kw, what in ((dict(N=128, c2=320), "128 score columns"), (dict(N=64, c2=40), "c2 not a multiple of 32"),
+                     (dict(N=64, c2=320, out2=False), "no second-stage weights")):
+        kw = dict(kw)
+        w2 = buf if kw.pop("out2", True) else None
+        bad = O.OpSeq("bad")
+        bad.add(O.linear(buf, buf, buf, M=128, K=64, epi=L.EPI_XATTN2, sm_scale=0.125, sm_cols=10, out2=w2, ldo=320, **kw), what)
+        with pytest.raises(L.MarigoldHipError, match="fused cross-attention"):
+            bad.validate()
+    ok = O.OpSeq("ok")
+    ok.add(O.linear(buf, buf, buf, M=128, K=64, N=64, epi=L.EPI_XATTN2, sm_scale=0.125, sm_cols=10, out2=buf, c2=320, ldo=320), "xattn2")
+    ok.validate()
 
 
 # ---- depth-ensembling host logic vs the reference's own outputs (CPU backend for the pixel passes)
