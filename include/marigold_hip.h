@@ -226,6 +226,13 @@ int mg_sched_step(const float* x, const float* model_out, const float* noise, fl
 int mg_ensemble_normals(const float* normals, float* out, float* unc, int E, int64_t hw,
                         int reduction, void* stream);
 
+/* Host arithmetic of ensemble_depth's alignment objective (marigold/util/ensemble.py:129-152, as the closed form of
+ * marigold_amd/ensemble.py): pairwise-RMSE cost of the aligned members and its gradient w.r.t. scales s[E] / shifts t[E],
+ * from the per-member means mean[E] and the centred second-moment matrix C[E*E] gathered by MG_OP_ENS_DEPTH_STATS.
+ * No device work; fp64; summation order = numpy's (bit-identical to the numpy form it replaces). */
+int mg_ens_align_cost_grad(int E, const double* s, const double* t, const double* mean, const double* C,
+                           double* cost, double* gs, double* gt);
+
 /* HIP-event timing helpers for bench.py (the kernels run on the caller's stream). */
 void* mg_event_create(void);
 int mg_event_record(void* ev, void* stream);

@@ -338,3 +338,67 @@ int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
   if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// ---- host arithmetic of the alignment objective (ensemble.py::DepthAligner.cost_and_grad) ----------------------------
+// The reference's optimiser (marigold/util/ensemble.py:154-173: scipy BFGS) calls its cost ~100 times per map; the
+// pairwise-RMSE part is a closed form of E x E numbers (ensemble.py, module docstring).  As numpy calls that is 30+
+// array operations of ~1 us each on 10 x 10 operands; here it is one C call.  Same operations in the same order as the
+// numpy form, INCLUDING numpy's pairwise summation (8 accumulators, blocks of 128), so the values - and with them the
+// BFGS iterates - are bit-identical (tests/test_host.py pins that); this file is built with -ffp-contract=off.
+namespace {
+double np_pairwise_sum(const double* a, int n) {
+  if (n < 8) {
+    double res = 0.;
+    for (int i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+}  // namespace
+
+extern "C" int mg_ens_align_cost_grad(int E, const double* s, const double* t, const double* mean, const double* C,
+                                      double* cost, double* gs, double* gt) {
+  MG_REQUIRE(E >= 1 && E <= 64 && s && t && mean && C && cost && gs && gt, "ens_align_cost_grad: bad arguments");
+  double u[64], s2d[64], sdc[64];
+  static thread_local double r[64 * 64], w[64 * 64], tmp[64 * 64];
+  for (int i = 0; i < E; ++i) {
+    u[i] = s[i] * mean[i] + t[i];
+    s2d[i] = (s[i] * s[i]) * C[i * E + i];
+    sdc[i] = s[i] * C[i * E + i];
+  }
+  for (int i = 0; i < E; ++i)
+    for (int j = 0; j < E; ++j) {
+      const double du = u[i] - u[j];
+      double q = ((s2d[i] + s2d[j]) - ((2.0 * (s[i] * s[j])) * C[i * E + j])) + du * du;
+      if (!(q > 0.0)) q = (q != q) ? q : 0.0;   // np.maximum(q, 0.0): NaN propagates
+      const double rr = sqrt(q);
+      r[i * E + j] = rr;
+      w[i * E + j] = (rr > 0 && i != j) ? 0.5 / rr : 0.0;
+    }
+  int n = 0;
+  for (int i = 0; i < E; ++i)
+    for (int j = i + 1; j < E; ++j) tmp[n++] = r[i * E + j];
+  *cost = np_pairwise_sum(tmp, n);
+  for (int i = 0; i < E; ++i) {
+    for (int j = 0; j < E; ++j) {
+      const double du = u[i] - u[j];
+      tmp[j] = w[i * E + j] * (((2.0 * sdc[i]) - ((2.0 * s[j]) * C[i * E + j])) + ((2.0 * du) * mean[i]));
+    }
+    gs[i] = np_pairwise_sum(tmp, E);
+    for (int j = 0; j < E; ++j) tmp[j] = (w[i * E + j] * 2.0) * (u[i] - u[j]);
+    gt[i] = np_pairwise_sum(tmp, E);
+  }
+  return 0;
+}

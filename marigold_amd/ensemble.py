@@ -33,7 +33,7 @@ How it runs on the device
 import numpy as np
 import torch
 
-from . import ops as O
+from . import _lib as L, ops as O
 
 _SCRATCH_BYTES = 12288
 _FD_STEP = 1.4901161193847656e-08   # scipy's forward-difference step (sqrt(eps)), absolute
@@ -139,11 +139,27 @@ class DepthAligner:
         return p, np.zeros(self.E)
 
     def cost_and_grad(self, p):
-        """Exact cost and gradient at the fp32-cast parameters.  (Host arithmetic on E x E numbers, called ~100 times per
-        map: the constant pieces are taken once in ``_consts`` and the remaining numpy calls kept few - this closure was
-        90 us of the ~130 us an evaluation costs, the device pass being the rest.)"""
+        """Exact cost and gradient at the fp32-cast parameters.  The E x E arithmetic is one call into the library
+        (``mg_ens_align_cost_grad``: the numpy form below, same operations in the same order - numpy's pairwise summation
+        included - hence the same bits; as ~35 numpy calls on 10 x 10 operands it was 50-90 us of the ~130 us an
+        evaluation costs, ~100 evaluations per map)."""
         self.n_eval += 1
         E = self.E
+        k = self._consts()
+        s, t = self._split(_q32(p))
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        out = k["out"]
+        L.check(k["fn"](E, s.ctypes.data, t.ctypes.data, k["mean_p"], k["C_p"], out.ctypes.data, out.ctypes.data + 8,
+                        out.ctypes.data + 8 * (1 + E)), "mg_ens_align_cost_grad")
+        cost = float(out[0])
+        gs, gt = out[1:1 + E].copy(), out[1 + E:1 + 2 * E].copy()
+        return self._add_regulariser(cost, gs, gt, s, t)
+
+    def cost_and_grad_numpy(self, p):
+        """The same objective as numpy array operations (the form ``mg_ens_align_cost_grad`` restates; tests compare the
+        two bit for bit)."""
+        self.n_eval += 1
         k = self._consts()
         s, t = self._split(_q32(p))
         u = s * self.mean + t
@@ -160,6 +176,10 @@ class DepthAligner:
         # d q_ij / d s_i = 2 s_i C_ii - 2 s_j C_ij + 2 (u_i - u_j) m_i ; d q_ij / d t_i = 2 (u_i - u_j)
         gs = (w * (2.0 * (s * dC)[:, None] - 2.0 * s[None, :] * C + 2.0 * du * self.mean[:, None])).sum(axis=1)
         gt = (w * 2.0 * du).sum(axis=1)
+        return self._add_regulariser(cost, gs, gt, s, t)
+
+    def _add_regulariser(self, cost, gs, gt, s, t):
+        E = self.E
         if self.lam > 0:
             s32, t32 = s.astype(np.float32), t.astype(np.float32)
             mn, mx, dmn, dmx = self.backend.regulariser(s32, t32)
@@ -180,7 +200,12 @@ class DepthAligner:
     def _consts(self):
         k = getattr(self, "_k", None)
         if k is None:
-            k = self._k = {"dC": np.diag(self.C).copy(), "iu": np.triu_indices(self.E, 1), "di": np.diag_indices(self.E)}
+            lib = L.load()
+            mean = np.ascontiguousarray(self.mean, dtype=np.float64)
+            C = np.ascontiguousarray(self.C, dtype=np.float64)
+            k = self._k = {"dC": np.diag(self.C).copy(), "iu": np.triu_indices(self.E, 1), "di": np.diag_indices(self.E),
+                           "fn": lib.mg_ens_align_cost_grad, "mean": mean, "C": C, "mean_p": mean.ctypes.data,
+                           "C_p": C.ctypes.data, "out": np.zeros(1 + 2 * self.E)}
         return k
 
     def cost(self, p):

@@ -307,6 +307,42 @@ def test_full_size_programs_validate_without_gpu():
     ok.validate()
 
 
+def test_alignment_objective_native_equals_numpy_bit_for_bit():
+    """``mg_ens_align_cost_grad`` (one C call per BFGS evaluation) restates the numpy form of the pairwise-RMSE objective
+    operation for operation, numpy's pairwise summation included: same bits for every ensemble size the kernels accept,
+    affine / scale-only, median / mean, coincident members (zero distances) and generic ones."""
+    from marigold_amd import ensemble as ens
+
+    class Backend:
+        def __init__(self, E, seed):
+            rng = np.random.default_rng(seed)
+            self.E, self.seed, self.dm, self.dx = E, seed, rng.random(E), rng.random(E)
+
+        def stats(self):
+            rng = np.random.default_rng(self.seed + 1)
+            A = rng.standard_normal((self.E, 40))
+            return np.zeros(self.E), np.ones(self.E), rng.random(self.E), A @ A.T / 40
+
+        def regulariser(self, s32, t32):
+            return 0.013, 0.97, self.dm, self.dx
+
+    n = 0
+    for E in (1, 2, 3, 7, 8, 9, 10, 16, 17, 31, 32):
+        for affine in (True, False):
+            for red in ("median", "mean"):
+                al = ens.DepthAligner(torch.zeros(E, 1, 4, 4), True, affine, red, 0.02, backend=Backend(E, E))
+                rng = np.random.default_rng(E)
+                for it in range(6):
+                    p = al.init_param() + rng.standard_normal(2 * E if affine else E) * 0.05
+                    if it % 3 == 0:
+                        p[:] = al.init_param()
+                    f1, g1 = al.cost_and_grad(p)
+                    f0, g0 = al.cost_and_grad_numpy(p)
+                    assert f0 == f1 and np.array_equal(g0, g1), (E, affine, red, it)
+                    n += 1
+    assert n == 264
+
+
 # ---- depth-ensembling host logic vs the reference's own outputs (CPU backend for the pixel passes)
 
 def _align_cpu(x, **kw):
