@@ -307,6 +307,33 @@ def test_full_size_programs_validate_without_gpu():
     ok.validate()
 
 
+def test_fast_division_constants():
+    """csrc/common.h: mg_make_fastdiv / fdiv - floor(x / d) for x < 2^31 as umulhi(2x, m) >> L with L = ceil(log2 d),
+    m = ceil(2^(31+L) / d).  Restated in integer arithmetic and checked on the divisors the launchers form (tile counts,
+    rows per image, widths, patch widths) and on the edges of the claim."""
+    def make(d):
+        L_ = 0
+        while (1 << L_) < d:
+            L_ += 1
+        m = ((1 << (31 + L_)) + d - 1) // d
+        assert m < (1 << 32)
+        return m, L_
+
+    def fdiv(x, m, L_):
+        return ((((x << 1) & 0xFFFFFFFF) * m) >> 32) >> L_
+
+    rng = np.random.default_rng(0)
+    divisors = [1, 2, 3, 5, 7, 10, 17, 18, 20, 36, 40, 45, 72, 90, 96, 144, 360, 576, 720, 2304, 9216, 92160, 589824,
+                (1 << 31) - 1, 1 << 30, (1 << 30) + 1, 3 * (1 << 29)] + [int(v) for v in rng.integers(1, 1 << 31, 200)]
+    for d in divisors:
+        m, L_ = make(d)
+        xs = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 31) - 1, (1 << 31) - d, ((1 << 31) - 1) // d * d,
+              ((1 << 31) - 1) // d * d - 1] + [int(v) for v in rng.integers(0, 1 << 31, 300)]
+        for x in xs:
+            if 0 <= x < (1 << 31):
+                assert fdiv(x, m, L_) == x // d, (x, d)
+
+
 def test_alignment_objective_native_equals_numpy_bit_for_bit():
     """``mg_ens_align_cost_grad`` (one C call per BFGS evaluation) restates the numpy form of the pairwise-RMSE objective
     operation for operation, numpy's pairwise summation included: same bits for every ensemble size the kernels accept,
