@@ -72,6 +72,132 @@ def pmc_traffic(kernel_class):
         return None
 
 
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+class GpuTelemetry:
+    """Clock / power state of the GPU this rank runs on, sampled from sysfs (amdgpu: pp_dpm_sclk / pp_dpm_mclk mark the
+    active level with '*', hwmon power1_average in microwatts, freq1_input in Hz) by a host thread while the timed region
+    runs.  Box-speed evidence for the bench line (same binary, 353-402 ms per map depending on the box);
+    everything is best effort - a missing file just leaves its field out."""
+
+    def __init__(self, index=0):
+        import glob
+        self.dev = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if _read(os.path.join(c, "pp_dpm_sclk")) is not None]
+        if cards:
+            self.dev = cards[min(index, len(cards) - 1)]
+        self.samples = []
+        self._stop = None
+
+    @staticmethod
+    def _active_mhz(text):
+        if not text:
+            return None
+        for ln in text.splitlines():
+            if ln.strip().endswith("*"):
+                try:
+                    return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                except (IndexError, ValueError):
+                    return None
+        return None
+
+    def sample(self):
+        if self.dev is None:
+            return None
+        import glob
+        d = {"sclk_mhz": self._active_mhz(_read(os.path.join(self.dev, "pp_dpm_sclk"))),
+             "mclk_mhz": self._active_mhz(_read(os.path.join(self.dev, "pp_dpm_mclk")))}
+        for hw in glob.glob(os.path.join(self.dev, "hwmon", "hwmon*")):
+            for key, fn, scale in (("power_w", "power1_average", 1e-6), ("power_w", "power1_input", 1e-6),
+                                   ("gfx_mhz", "freq1_input", 1e-6), ("temp_c", "temp1_input", 1e-3),
+                                   ("power_cap_w", "power1_cap", 1e-6)):
+                v = _read(os.path.join(hw, fn))
+                if v is not None and d.get(key) is None:
+                    try:
+                        d[key] = float(v) * scale
+                    except ValueError:
+                        pass
+        return d
+
+    def start(self, period=0.02):
+        import threading
+        if self.dev is None:
+            return
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                s = self.sample()
+                if s:
+                    self.samples.append(s)
+                self._stop.wait(period)
+        self._thr = threading.Thread(target=run, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        if self._stop is None:
+            return None
+        self._stop.set()
+        self._thr.join(timeout=1.0)
+        out = {"samples": len(self.samples)}
+        for k in ("sclk_mhz", "gfx_mhz", "mclk_mhz", "power_w", "temp_c", "power_cap_w"):
+            vals = [s[k] for s in self.samples if s.get(k) is not None]
+            if vals:
+                out[k] = {"mean": round(sum(vals) / len(vals), 1), "min": round(min(vals), 1), "max": round(max(vals), 1)}
+        return out
+
+
+def calibration(dev):
+    """Box-speed index measured in this process before the warm-up: a fixed 4096^3 bf16 GEMM on this
+    library's own implicit-GEMM kernel (and on torch.matmul = hipBLASLt, for a second opinion), a 1 GiB device-to-device
+    copy, the idle clock / power state.  Random operands (zero-filled ones clock ~20 % higher)."""
+    import torch
+    from marigold_amd import ops as O
+    out = {}
+
+    def timeit(fn, iters):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    try:
+        n = 4096
+        g = torch.Generator(device="cpu").manual_seed(7)
+        a = (torch.rand(n, n, generator=g) * 2 - 1).to(dev, torch.bfloat16)
+        w = (torch.rand(n, n, generator=g) * 2 - 1).to(dev, torch.bfloat16)
+        c = torch.empty(n, n, device=dev, dtype=torch.bfloat16)
+        op = O.linear(a, w, c, M=n, K=n, N=n)
+        ms = min(timeit(lambda: O.launch(op), 10) for _ in range(3))
+        out["gemm4096_bf16_tflops"] = round(2.0 * n ** 3 / ms / 1e9, 1)
+        ms = min(timeit(lambda: torch.matmul(a, w.t(), out=c), 10) for _ in range(3))
+        out["gemm4096_bf16_tflops_hipblaslt"] = round(2.0 * n ** 3 / ms / 1e9, 1)
+        del a, w, c
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
+        dst = torch.empty_like(src)
+        ms = min(timeit(lambda: dst.copy_(src), 5) for _ in range(3))
+        out["copy_1gib_gbs"] = round(2.0 * (1 << 30) / ms / 1e6, 1)   # bytes read + written
+        del src, dst
+        torch.cuda.empty_cache()
+        out["device"] = torch.cuda.get_device_name(dev)
+        out["idle"] = GpuTelemetry(dev.index or 0).sample()
+    except Exception as e:  # noqa: BLE001 - reporting only
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def cpu_baseline(args, members_path):
     """The CPU oracle (restatement of the reference's diffusers path) timed on the host cores, on a
     bounded sample: 1 UNet forward at the full 96x96 latent, VAE encode/decode at 256x256 scaled by
@@ -218,6 +344,9 @@ def main():
     if rank == 0:
         log(f"[bench] synthetic weights + pipeline ready in {time.perf_counter() - t0:.1f}s "
             f"(host cores {os.cpu_count()})")
+    calib = calibration(dev) if rank == 0 else None
+    if rank == 0:
+        log(f"[bench] calibration: {calib}")
     img = syn.synthetic_image(args.res, args.res, seed=0).to(dev)   # resident in HBM before timing
     torch.manual_seed(2024)
     kw = dict(denoising_steps=args.denoise, ensemble_size=args.ensemble, processing_res=0,
@@ -245,12 +374,17 @@ def main():
                 prog.seq.capture()
         torch.cuda.synchronize()
         out = pipe(img, **kw)
+    telemetry = GpuTelemetry(dev.index or 0) if rank == 0 else None
     barrier()
+    if telemetry:
+        telemetry.start()
     t1 = time.perf_counter()
     for _ in range(args.steps):
         out = pipe(img, **kw)
     barrier()
     dt = time.perf_counter() - t1
+    if telemetry and calib is not None:
+        calib["timed_region"] = telemetry.stop()
     tt = torch.tensor([dt], device="cpu" if (world > 1 and dist.get_backend() == "gloo") else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -399,6 +533,7 @@ def main():
                        "hipgraph": bool(args.graph)},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "calibration": calib,
             # whole-map figures only where rank 0 ran the whole map (its programs cover its own members only)
             "algorithmic_tflop_per_map": round(flops_per_map / 1e12, 2) if world == 1 else None,
             "pipeline_tflops": round(flops_per_map * value / 1e12, 1) if world == 1 else None,

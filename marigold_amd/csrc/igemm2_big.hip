@@ -1,0 +1,22 @@
+// Implicit GEMM with a 128 x 128 WAVE tile: 256 x 256 workgroup tile on four waves, one wave per SIMD, the 256 fp32
+// accumulators of a lane in the AGPR half of its 512-register file (this file is built WITHOUT -amdgpu-mfma-vgpr-form, see
+// the Makefile).  Why (round 3, profiles/r3_pmc_sq_summary.json): the SIMD issues from one wave at a time and every
+// instruction costs it ~4-5 cycles, so what bounds the 8-wave tiles is the number of instructions around each MFMA
+// (5-9 VALU + LDS + SALU per MFMA against 0.8 for the vendor GEMM); a 128 x 128 wave tile halves the fragment reads per
+// MFMA (0.5) and all the per-K-step bookkeeping is amortised over 16 MFMAs per k-substep.  Same body, same epilogues.
+#include "igemm2_body.h"
+
+namespace {
+
+template <int NSTAGE, int BK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void igemm2_big_kernel(const Igemm2Args a) {
+  igemm2_body<256, 256, 2, 2, NSTAGE, false, true, 0, 0, BK>(a);
+}
+
+}  // namespace
+
+// which: 0 = 32-deep K tiles, 4 stages (128 KB of LDS); 1 = 64-deep K tiles, 2 stages.  The argument struct has the same
+// layout in every translation unit (igemm2_body.h); the pointer is launched by igemm2.hip::launch2.
+void* mg_igemm2_big_kernel(int which) {
+  return which == 0 ? (void*)igemm2_big_kernel<4, 32> : (void*)igemm2_big_kernel<2, 64>;
+}

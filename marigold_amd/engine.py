@@ -24,7 +24,8 @@ LATENT_SCALE = 0.18215  # marigold_depth_pipeline.py:118
 USE_PATCH = os.environ.get("MARIGOLD_PATCH_CONV", "1") != "0"      # patch-resident conv3x3 kernel where eligible
 FUSE_GN = os.environ.get("MARIGOLD_FUSE_GN", "auto")               # auto | all | none: GroupNorm apply inside the conv
 FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"
-XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)           # LayerNorms folded into the Linear layers that consume them
+XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)
+FLASH_VT_PERM = os.environ.get("MARIGOLD_FLASH_VT_PERM", "1") != "0"   # permuted V^T + generation-3 attention (0: generation 2)
 
 
 class Act:
@@ -419,19 +420,22 @@ class Builder:
         ldvt = (T + 63) // 64 * 64
         qk = self.raw(M * 2 * C * 2)
         vt = self.zeros_persistent(("vt", B, C, ldvt), B * C * ldvt * 2)
+        # V^T with its keys in the QK^T accumulator order inside groups of 16: the QKV epilogue skips its lane regroup and
+        # the attention kernel (generation 3) its v_permlane32_swap - a format private to this producer / consumer pair
+        perm = FLASH_VT_PERM and T % 16 == 0
         if st is not None:
             wqkv, g, c = self.ws.qkv_ln(prefix, norm)
             self.add(O.igemm(h.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, out2=vt,
-                             trans_from=2 * C, ldt=ldvt, ln_in=self.ln_mean_rstd(st, M, C), ln_g=g, ln_c=c), f"{prefix}.qkv")
+                             trans_from=2 * C, ldt=ldvt, ln_in=self.ln_mean_rstd(st, M, C), ln_g=g, ln_c=c, trans_perm=perm), f"{prefix}.qkv")
         else:   # A/B form: the LayerNorm as its own pass
             y = self.layer_norm(h, norm)
             self.add(O.igemm(y.t, self.ws.qkv(prefix, False)[0], qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C,
-                             out2=vt, trans_from=2 * C, ldt=ldvt), f"{prefix}.qkv")
+                             out2=vt, trans_from=2 * C, ldt=ldvt, trans_perm=perm), f"{prefix}.qkv")
             self.free(y)
         o = self.new(h.B, h.H, h.W, C)
         self.add(O.flash_attn64(qk, qk.data_ptr() + C * 2, vt, o.t, B=B, heads=heads, Ntok=T, ldq=2 * C,
                                 ldo=C, ldvt=ldvt, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C,
-                                scale=1.0 / math.sqrt(C // heads)), f"{prefix}.flash")
+                                scale=1.0 / math.sqrt(C // heads), vt_perm=perm), f"{prefix}.flash")
         self.free(qk)
         self.dense(o, self.ws.mat(f"{prefix}.to_out.0"), self.ws.bias(f"{prefix}.to_out.0"), C,
                    residual=h, out=h, label=f"{prefix}.to_out", ln_out=st_out)

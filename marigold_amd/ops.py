@@ -44,14 +44,14 @@ def igemm(a, w, out, *, B, H, W, Cin, Ho, Wo, N, taps=1, stride=1, pad=0, up=Non
           rowvec=None, residual=None, epi=L.EPI_BF16, ldo=None, out2=None, trans_from=-1, ldt=0,
           batch_z=1, ldr=0, lda=0, ldw=0, zstrides=(0, 0, 0, 0), scale=1.0, variant=0,
           rowvec_bcast=False, n_alg=0, k_alg=0, a1=None, C0=0, lda1=0, ln_out=None, ln_in=None, ln_g=None, ln_c=None,
-          ln_eps=1e-5, sm_scale=0.0, sm_cols=0, c2=0):
+          ln_eps=1e-5, sm_scale=0.0, sm_cols=0, c2=0, trans_perm=False):
     hu, wu = up if up else (0, 0)
     if ldo is None:
         ldo = N // 2 if epi == L.EPI_GEGLU else N
     return make_op(L.OP_IGEMM,
                    i=[B, H, W, Cin, Ho, Wo, N, taps, stride, pad, hu, wu, epi, ldo, trans_from,
                       batch_z, ldr, lda, ldt, variant, ldw, int(rowvec_bcast), n_alg, k_alg, C0, lda1,
-                      0, sm_cols, c2],
+                      int(trans_perm), sm_cols, c2],
                    f=[scale, ln_eps, sm_scale], p=[a, w, out, bias, rowvec, residual, out2, a1, ln_out, ln_in, ln_g, ln_c],
                    l=list(zstrides))
 
@@ -89,9 +89,20 @@ def layernorm(x, gamma, beta, out, *, M, C, eps=1e-5):
     return make_op(L.OP_LAYERNORM, i=[M, C], f=[eps], p=[x, gamma, beta, out])
 
 
-def flash_attn64(q, k, vt, o, *, B, heads, Ntok, ldq, ldo, ldvt, sq, sk, svt, so, scale, variant=0):
-    return make_op(L.OP_FLASH_ATTN64, i=[B, heads, Ntok, ldq, ldo, ldvt, variant], f=[scale],
-                   p=[q, k, vt, o], l=[sq, sk, svt, so])
+def flash_attn64(q, k, vt, o, *, B, heads, Ntok, ldq, ldo, ldvt, sq, sk, svt, so, scale, variant=0, vt_perm=False, dbg=None):
+    """``vt_perm``: V^T holds its keys in the order [0-3, 8-11, 4-7, 12-15] inside every group of 16 (what MG_OP_IGEMM's
+    transposed section writes with ``trans_perm``) - generation 3 consumes that order without a lane exchange."""
+    return make_op(L.OP_FLASH_ATTN64, i=[B, heads, Ntok, ldq, ldo, ldvt, variant, int(vt_perm)], f=[scale],
+                   p=[q, k, vt, o, dbg], l=[sq, sk, svt, so])
+
+
+VT_PERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+
+def permute_vt_keys(vt):
+    """Natural V^T [..., keys] (keys a multiple of 16) -> the ``vt_perm`` order (host helper for tests / tools)."""
+    sh = vt.shape
+    return vt.reshape(*sh[:-1], sh[-1] // 16, 16)[..., list(VT_PERM16)].reshape(sh).contiguous()
 
 
 def softmax_rows(s, p, *, R, ncols, lds, ldp):

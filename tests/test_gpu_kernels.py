@@ -92,6 +92,10 @@ CONV_CASES = [
     ("g2_pingpong_big_k_medge", 1, 13, 12, 1280, 256, 1, 1, None, 60),   # 180 K tiles, M = 156 (one partial tile)
     ("g2_pingpong_mid_up_nedge", 2, 16, 24, 192, 320, 1, 1, (32, 48), 62),   # 2nd DMA piece issued among the MFMAs
     ("g2_pingpong_mid_kt9_stride2", 2, 16, 16, 64, 64, 2, 1, None, 63),
+    ("g2_big_bk32_up_nedge", 2, 16, 24, 192, 320, 1, 1, (32, 48), 70),   # 128 x 128 wave tile (igemm2_big.hip), 4 stages of 32
+    ("g2_big_bk32_kt9_stride2", 2, 16, 16, 64, 64, 2, 1, None, 70),
+    ("g2_big_bk64_big_k_medge", 1, 13, 12, 1280, 256, 1, 1, None, 71),   # 2 stages of 64, M = 156 (one partial tile)
+    ("g2_big_bk64_up_nedge", 2, 16, 24, 192, 320, 1, 1, (32, 48), 71),
     ("g2_128x320", 2, 12, 20, 128, 320, 1, 1, None, 46),
     ("g2_256x320", 2, 12, 20, 64, 640, 1, 1, None, 47),
     ("g2_128x320_burst", 1, 12, 12, 320, 320, 1, 1, None, 48),
@@ -361,7 +365,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = torch.randn(N, generator=g) * 0.1
     ref = x @ w.t() + b
-    for variant in (0, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 46, 50, 51, 52, 53, 60, 61, 62, 63):
+    for variant in (0, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 46, 50, 51, 52, 53, 60, 61, 62, 63, 70, 71):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N,
                         bias=b.to(dev), variant=variant))
@@ -373,7 +377,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     xg = _bf(torch.randn(200, C, generator=g))
     u, gt = (xg @ wg.t() + bg).chunk(2, dim=-1)
     ref = u * F.gelu(gt)
-    for group, variants in ((32, (20, 23, 24, 27, 34, 53, 60, 62, 0)),):
+    for group, variants in ((32, (20, 23, 24, 27, 34, 53, 60, 62, 70, 71, 0)),):
         wp, bp = Wm.pack_geglu(wg, bg, group)
         for variant in variants:
             out = torch.full((200, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
@@ -397,6 +401,12 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
                        Ho=T, Wo=1, N=3 * C, bias=bq.to(dev), out2=vt, trans_from=2 * C, ldt=ldt, variant=variant))
         _close(f"qkv/qk/v{variant}", qk[:, :2 * C], refq[:, :2 * C])
         _close(f"qkv/vt/v{variant}", vt[:, :, :T], refv)
+        assert (vt[:, :, T:] == 0).all()
+        # the same section with its tokens in accumulator order inside groups of 16 (flash_attn64 generation 3's V^T)
+        vt.zero_()
+        _run(ops.igemm(xq.to(dev, torch.bfloat16), wqkv.to(dev, torch.bfloat16), qk, B=B, H=T, W=1, Cin=C,
+                       Ho=T, Wo=1, N=3 * C, bias=bq.to(dev), out2=vt, trans_from=2 * C, ldt=ldt, variant=variant, trans_perm=True))
+        _close(f"qkv/vt_perm/v{variant}", vt[:, :, :T], ops.permute_vt_keys(refv.contiguous()))
         assert (vt[:, :, T:] == 0).all()
     # token count not a multiple of 8 (scalar transposed tail)
     T2 = 36
@@ -439,7 +449,7 @@ def test_igemm_layernorm_fold(dev):
     b0 = torch.randn(C, generator=g) * 0.1
     res = _bf(torch.randn(M, C, generator=g))
     ref0 = a @ w0.t() + b0 + res
-    for variant in (0, 46, 53, 35, 62):
+    for variant in (0, 46, 53, 35, 62, 70, 71):
         out = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
         st = torch.full((M * (C // 32 + 1), 2), float("nan"), device=dev)
         for rep_ in range(3):   # the tickets reset themselves: every launch finalizes again
@@ -462,7 +472,7 @@ def test_igemm_layernorm_fold(dev):
     b = torch.randn(N, generator=g) * 0.1
     wp, gv, cv = Wm.fold_layernorm(w, b, gamma, beta)
     ref = y @ w.t() + b
-    for variant in (0, 20, 46, 53, 62):
+    for variant in (0, 20, 46, 53, 62, 70, 71):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(xd, wp.to(dev), out, M=M, K=C, N=N, ln_in=stx, ln_g=gv.to(dev), ln_c=cv.to(dev), variant=variant))
         _close(f"ln_fold/bf16/v{variant}", out, ref, tol=2e-2)
@@ -476,7 +486,7 @@ def test_igemm_layernorm_fold(dev):
     refg = u * F.gelu(gt)
     wpk, bpk = Wm.pack_geglu(wg, bg)
     wpg, gg, cg = Wm.fold_layernorm(wpk, bpk, gamma, beta)
-    for variant in (0, 53, 62):
+    for variant in (0, 53, 62, 70, 71):
         og = torch.full((M, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(xd, wpg.to(dev), og, M=M, K=C, N=8 * C, epi=L.EPI_GEGLU, ln_in=stx, ln_g=gg.to(dev), ln_c=cg.to(dev),
                         variant=variant))
@@ -493,6 +503,12 @@ def test_igemm_layernorm_fold(dev):
                    ln_in=stx, ln_g=gq.to(dev), ln_c=cq.to(dev)))
     _close("ln_fold/qkv/qk", qk, refq[:, :2 * C], tol=2e-2)
     _close("ln_fold/qkv/vt", vt[:, :, :T], refq[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1), tol=2e-2)
+    # permuted token order (flash_attn64 generation 3's V^T): the per-token LayerNorm statistics must follow the permutation
+    T2 = 688
+    vt2 = torch.zeros((1, C, 704), device=dev, dtype=torch.bfloat16)
+    _run(ops.igemm(xd, wpq.to(dev), qk, B=1, H=T2, W=1, Cin=C, Ho=T2, Wo=1, N=3 * C, ldo=2 * C, out2=vt2, trans_from=2 * C, ldt=704,
+                   ln_in=stx, ln_g=gq.to(dev), ln_c=cq.to(dev), trans_perm=True))
+    _close("ln_fold/qkv/vt_perm", vt2[:, :, :T2], ops.permute_vt_keys(refq[:T2, 2 * C:].reshape(1, T2, C).permute(0, 2, 1).contiguous()), tol=2e-2)
 
 
 def test_igemm_row_statistics_bit_stable_at_scale(dev):
@@ -690,12 +706,14 @@ def test_flash_attn64(dev, B, heads, T):
     qkd = qkv.to(dev, torch.bfloat16)
     vt = torch.zeros(B, C, ldvt, device=dev, dtype=torch.bfloat16)
     vt[:, :, :T] = v.permute(0, 2, 1).to(dev, torch.bfloat16)
-    for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):   # 0 = default; 1 = generation 1; 2.. = generation-2 variants
+    vtp = ops.permute_vt_keys(vt)   # the key order generation 3 reads without a lane exchange (MG_OP_IGEMM trans_perm)
+    # 0 = default; 1 = generation 1; 2-8 = generation 2; 9-12 = generation 3; 13-18 (and 0 with vt_perm) = permuted V^T
+    for variant, perm in [(v, False) for v in range(13)] + ([(v, True) for v in (0, 13, 14, 15, 16, 17, 18)] if T % 16 == 0 else []):
         out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
-        _run(ops.flash_attn64(qkd, qkd[:, :, C:], vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C,
+        _run(ops.flash_attn64(qkd, qkd[:, :, C:], vtp if perm else vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C,
                               ldvt=ldvt, sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125,
-                              variant=variant))
-        _close(f"flash_attn64/B{B}h{heads}T{T}/v{variant}", out, ref)
+                              variant=variant, vt_perm=perm))
+        _close(f"flash_attn64/B{B}h{heads}T{T}/v{variant}{'p' if perm else ''}", out, ref)
 
 
 def test_flash_attn64_spiky_scores(dev):
@@ -711,11 +729,64 @@ def test_flash_attn64_spiky_scores(dev):
     ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
     qkv = torch.cat([q, k], dim=-1).to(dev, torch.bfloat16)
     vt = v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16)
-    for variant in (0, 1, 2, 3, 4, 5, 6, 7):
+    vtp = ops.permute_vt_keys(vt)
+    for variant, perm in [(v, False) for v in (0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12)] + [(v, True) for v in (0, 13, 14, 15, 16, 17, 18)]:
         out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
-        _run(ops.flash_attn64(qkv, qkv[:, :, C:], vt, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T,
-                              sq=0, sk=0, svt=0, so=0, scale=0.125, variant=variant))
-        _close(f"flash_attn64/spiky/v{variant}", out, ref)
+        _run(ops.flash_attn64(qkv, qkv[:, :, C:], vtp if perm else vt, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T,
+                              sq=0, sk=0, svt=0, so=0, scale=0.125, variant=variant, vt_perm=perm))
+        _close(f"flash_attn64/spiky/v{variant}{'p' if perm else ''}", out, ref)
+
+
+@pytest.mark.parametrize("case", ["all_negative", "growing", "first_tile_spike", "threshold_edge"])
+def test_flash_attn64_running_max_paths(dev, case):
+    """Generation 3 keeps the running max inside the MFMA's C operand and only raises it when a row maximum exceeds it by
+    more than 2^3 (log2 units): inputs that force each branch of that logic, against fp32 SDPA on the host.
+      all_negative     - every logit is around -60 (the max of the first tile is the reference whatever its sign; with a
+                         zero-initialised max every probability would underflow);
+      growing          - the row maximum grows by ~2.5 log2 units per tile (below the threshold every time: probabilities
+                         reach 2^3 times the reference before the max is raised) and then by ~6 (above);
+      first_tile_spike - the largest logit of some rows sits in tile 0, of others in the last (ragged) tile;
+      threshold_edge   - jumps of exactly 3.0 +- one bf16 step around the threshold."""
+    from marigold_amd import ops
+    T, C = 1008, 64   # 16 tiles, the last one ragged (48 keys), 4 full ring rounds
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(1, T, C, generator=g)
+    k = torch.randn(1, T, C, generator=g)
+    v = _bf(torch.randn(1, T, C, generator=g))
+    if case == "all_negative":
+        u = torch.nn.functional.normalize(torch.randn(C, generator=g), dim=0)
+        q = q * 0.2 + u * 22.0
+        k = k * 0.2 - u * 22.0          # q.k ~ -484, logits ~ -60
+    elif case == "growing":
+        u = torch.nn.functional.normalize(torch.randn(C, generator=g), dim=0)
+        q = q * 0.3 + u * 8.0
+        step = torch.arange(T) // 64    # tile index
+        amp = torch.where(step < 10, step * 1.75, 17.5 + (step - 10) * 4.2)   # logit = amp * 8 / 8: +1.75 (2.5 log2), then +4.2 (6 log2)
+        k = k * 0.3 + u[None, :] * amp[:, None]
+    elif case == "first_tile_spike":
+        k[0, 3] = q[0, 10] * 5.0
+        k[0, 990] = q[0, 500] * 5.0
+        k[0, 1007] = q[0, 700] * 6.0
+    else:
+        u = torch.nn.functional.normalize(torch.randn(C, generator=g), dim=0)
+        q = q * 0.05 + u * 8.0
+        step = (torch.arange(T) // 64).float()
+        amp = step * (3.0 / 1.4426950408889634)                          # +3.0 log2 units per tile ...
+        amp = amp + torch.where(step % 2 == 0, 0.02, -0.02)              # ... give or take
+        k = k * 0.05 + u[None, :] * amp[:, None]
+    q, k = _bf(q), _bf(k)
+    ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+    assert torch.isfinite(ref).all()
+    qkv = torch.cat([q, k], dim=-1).to(dev, torch.bfloat16)
+    ldvt = 1024
+    vt = torch.zeros(1, C, ldvt, device=dev, dtype=torch.bfloat16)
+    vt[:, :, :T] = v.permute(0, 2, 1).to(dev, torch.bfloat16)
+    vtp = ops.permute_vt_keys(vt)
+    for variant, perm in [(v, False) for v in (0, 6, 9, 10, 11, 12)] + [(v, True) for v in (0, 13, 14, 15, 16, 17, 18)]:
+        out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.flash_attn64(qkv, qkv[:, :, C:], vtp if perm else vt, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=ldvt,
+                              sq=0, sk=0, svt=0, so=0, scale=0.125, variant=variant, vt_perm=perm))
+        _close(f"flash_attn64/{case}/v{variant}{'p' if perm else ''}", out, ref)
 
 
 def test_softmax_rows_and_pairs(dev):

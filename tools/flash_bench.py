@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Flash-attention variants side by side on the MI355X (interleaved rounds, median): TFLOP/s at the UNet's self-attention
+shapes and the error of each against CPU SDPA in fp32 on a sub-sampled set of queries.  Tuning tool, not product path."""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from marigold_amd import _lib as L, ops as O  # noqa: E402
+
+VARIANTS = tuple(int(v) for v in os.environ.get("FLASH_VARIANTS", "6,9,10").split(","))
+ROUNDS = int(os.environ.get("FLASH_ROUNDS", "5"))
+dev = torch.device("cuda:0")
+L.init(0)
+
+
+def timeit(fn, warm=1, iters=4):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def case(B, heads, T, qscale=1.0):
+    C = heads * 64
+    g = torch.Generator(device="cpu").manual_seed(2)
+    qkv = (torch.randn(B, T, 3 * C, generator=g)).to(torch.bfloat16)
+    qkv[:, :, :C] *= qscale
+    ldvt = (T + 63) // 64 * 64
+    qkd = qkv.to(dev)
+    vt = torch.zeros(B, C, ldvt, device=dev, dtype=torch.bfloat16)
+    vt[:, :, :T] = qkd[:, :, 2 * C:].permute(0, 2, 1)
+    vtp = O.permute_vt_keys(vt)
+    flops = 4.0 * B * heads * T * T * 64
+    # reference on image 0, head 0, every 37th query
+    q, k, v = (qkv[0, :, i * C:i * C + 64].float() for i in range(3))
+    qs = q[::37]
+    ref = F.scaled_dot_product_attention(qs[None, None], k[None, None], v[None, None])[0, 0]
+    outs, ops, times = {}, {}, {v: [] for v in VARIANTS}
+    for v in VARIANTS:
+        outs[v] = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+        ops[v] = O.flash_attn64(qkd, qkd[:, :, C:], vtp if v >= 13 else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
+                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=v >= 13)
+    for rnd in range(ROUNDS):
+        for v in VARIANTS:
+            times[v].append(timeit(lambda: O.launch(ops[v])))
+    line = f"flash B={B} heads={heads} T={T} qscale={qscale}:"
+    if os.environ.get("FLASH_DBG"):   # generation 3 only: shader cycles / wall ticks per workgroup
+        for v in VARIANTS:
+            if v < 9:
+                continue
+            if v > 16:
+                continue
+            nw = 8 if v in (9, 11, 13, 15) else 4
+            nwg = -(-T // (nw * 32)) * heads * B
+            dbg = torch.zeros(nwg * nw * 8, dtype=torch.int64, device=dev)
+            op = O.flash_attn64(qkd, qkd[:, :, C:], vtp if v >= 13 else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
+                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=v >= 13, dbg=dbg)
+            O.launch(op)
+            O.launch(op)
+            torch.cuda.synchronize()
+            d = dbg.view(nwg, nw, 8).double().cpu()
+            nt = (-(-T // 64) + 3) // 4 * 4
+            cyc, tick = d[:, 0, 0], d[:, 0, 1]
+            per = d[:, :, 2:5].mean(dim=(0, 1)) / nt
+            wv = d[:, :, 2:5].mean(dim=0) / nt          # per wave index
+            print(f"   v{v}: {nwg} workgroups x {nw} waves, cycles per workgroup median {cyc.median():.0f} = {cyc.median() / nt:.0f} per tile; "
+                  f"clock {float((cyc / tick).median()) * 100:.0f} MHz; per tile: barrier wait {per[0]:.0f}, phase A {per[1]:.0f}, phase B {per[2]:.0f}; "
+                  f"rescales per wave {d[:, :, 5].mean():.1f} of {nt}", flush=True)
+            print("        per wave index (barrier / A / B): " + "  ".join(f"{wv[w, 0]:.0f}/{wv[w, 1]:.0f}/{wv[w, 2]:.0f}" for w in range(nw)), flush=True)
+    for v in VARIANTS:
+        ts = sorted(times[v])
+        ms = ts[len(ts) // 2]
+        got = outs[v][0, ::37, :64].float().cpu()
+        err = float((got - ref).abs().max())
+        nan = int(torch.isnan(outs[v].float()).sum())
+        line += f"  v{v}: {flops / ms / 1e9:6.0f} TF/s ({ms * 1e3:7.1f} us, min {ts[0] * 1e3:7.1f}) err {err:.2e}" + (f" NAN {nan}" if nan else "")
+    print(line, flush=True)
+
+
+if __name__ == "__main__":
+    E = int(os.environ.get("FLASH_E", "10"))
+    case(E, 5, 9216)
+    case(E, 10, 2304)
+    case(E, 20, 576)
+    case(E, 20, 144)
+    case(1, 5, 9216)
+    case(2, 5, 9216, qscale=4.0)
