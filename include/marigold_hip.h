@@ -73,6 +73,13 @@ enum mg_op_kind {
   MG_OP_GN_STATS = 2,
   MG_OP_GN_FINALIZE = 3,
   MG_OP_GN_APPLY = 4,
+  /* GroupNorm as ONE launch (statistics + scale/shift [+ normalised output]): a workgroup owns whole groups of one image
+   * (channel window lcm(C / groups, 4) <= 128) over all H x W rows - no partial table, no tickets, one read of the tensor.
+   *  p[0] x0 bf16 [B][HW][C0]  p[1] x1 bf16 [B][HW][C - C0] | NULL (second channel source: the UNet's skip concat)
+   *  p[2] out bf16 [B][HW][C] | NULL (statistics only)  p[3] gamma f32 [C]  p[4] beta f32 [C]  p[5] scale_shift f32 [B][2][C]
+   *  i: B, HW, C, C0 (with x1), groups, silu ; f[0] eps.  The normalised form keeps the rows in registers: H x W x window
+   *  <= 48 rows per thread of a 1024-thread workgroup (the UNet's 96^2 ... 12^2 levels at any width). */
+  MG_OP_GN_SLAB = 9,
   /* LayerNorm over the last dim. p[0] x bf16 [M][C] p[1] gamma f32 p[2] beta f32 p[3] out;
    * i: M,C ; f[0] eps */
   MG_OP_LAYERNORM = 5,

@@ -229,6 +229,145 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   }
 }
 
+
+// ---- GroupNorm as ONE launch per norm (MG_OP_GN_SLAB; round 3) ---------------------------------------------------------
+// The statistics -> ticket -> finalize -> apply chain above costs 16-28 us of serial latency per norm on tensors a
+// streaming read covers in 5-10 us (782 + 536 launches, 31 ms per map).  Here a workgroup owns COMPLETE groups of one
+// image - the channel window [c0, c0 + cw), cw = lcm(channels per group, 4) - over all H x W rows: no cross-workgroup
+// reduction, no partial table, no tickets, and with MAXV > 0 the rows stay in registers between the statistics and the
+// normalisation (one read of the tensor, the apply pass disappears).  8-byte vectors (4 channels): thread (tx, ty) owns
+// channel vector tx of rows ty, ty + nty, ...; its 4 x (sum, sum of squares) go through LDS in a fixed order (bit-
+// reproducible), group totals in fp64.  Two sources = the UNet's skip concat (a vector never straddles the sources).
+struct GnSlabArgs {
+  const bf16_t* x0;
+  const bf16_t* x1;
+  bf16_t* y;            // nullptr: statistics only (the consumer applies scale / shift itself: conv_patch's fused fix-up)
+  const float* gamma;
+  const float* beta;
+  float* ss;            // [B][2][C] (scale, shift)
+  int HW, C, C0, cpg, cw, vw, nty, silu;
+  float eps;
+  mg_fastdiv fd_vw, fd_ncol, fd_cpg;
+};
+
+template <int NT, int MAXV>
+__global__ __launch_bounds__(NT) void gn_slab_kernel(const GnSlabArgs a) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x;
+  const int ty = fdiv(tid, a.fd_vw), tx = tid - ty * a.vw;
+  const int b = blockIdx.y;
+  const int cwin = blockIdx.x * a.cw;            // first channel of the window
+  const int c = cwin + 4 * tx;                   // this thread's 4 channels
+  const bool active = ty < a.nty;
+  const bool second = c >= a.C0;
+  const int ld = second ? a.C - a.C0 : a.C0;
+  const bf16_t* src = (second ? a.x1 + (long long)b * a.HW * ld + (c - a.C0) : a.x0 + (long long)b * a.HW * ld + c);
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  auto acc4 = [&](const uint2& u) {
+    const float v0 = bflo(u.x), v1 = bfhi(u.x), v2 = bflo(u.y), v3 = bfhi(u.y);
+    s[0] += v0; q[0] = __builtin_fmaf(v0, v0, q[0]);
+    s[1] += v1; q[1] = __builtin_fmaf(v1, v1, q[1]);
+    s[2] += v2; q[2] = __builtin_fmaf(v2, v2, q[2]);
+    s[3] += v3; q[3] = __builtin_fmaf(v3, v3, q[3]);
+  };
+  constexpr int NV = MAXV > 0 ? MAXV : 1;
+  uint2 v[NV];
+  if (active) {
+    if constexpr (MAXV > 0) {   // every row of the thread in flight at once, kept for the normalisation
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int r = ty + k * a.nty;
+        v[k] = r < a.HW ? *(const uint2*)(src + (long long)r * ld) : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) acc4(v[k]);   // rows beyond HW are zeros: they add nothing
+    } else {
+      for (int r0 = ty; r0 < a.HW; r0 += 8 * a.nty) {
+        uint2 u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = r0 + k * a.nty;
+          u[k] = r < a.HW ? *(const uint2*)(src + (long long)r * ld) : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc4(u[k]);
+      }
+    }
+  }
+  const int ncol = a.cw * 2;                     // (sum, sum of squares) per channel of the window
+  float* red = lds;                              // [nty][ncol]
+  float* red2 = red + NT * 8;                    // [parts][ncol]
+  float* tot = red2 + NT;                        // [ncol]
+  float* gst = tot + 256;                        // [groups of the window][2] (mean, rstd)
+  float* lss = gst + 64;                         // [2][cw] (scale, shift)
+  if (active) {
+    float4* d = (float4*)(red + ((long long)ty * a.vw + tx) * 8);
+    d[0] = make_float4(s[0], q[0], s[1], q[1]);
+    d[1] = make_float4(s[2], q[2], s[3], q[3]);
+  }
+  __syncthreads();
+  const int parts = min(a.nty, NT / ncol);       // >= 1: ncol <= 256 <= NT
+  {
+    const int part = fdiv(tid, a.fd_ncol), col = tid - part * ncol;
+    if (part < parts) {
+      float t = 0.f;
+      for (int y = part; y < a.nty; y += parts) t += red[(long long)y * ncol + col];
+      red2[part * ncol + col] = t;
+    }
+  }
+  __syncthreads();
+  if (tid < ncol) {
+    float t = 0.f;
+    for (int p = 0; p < parts; ++p) t += red2[p * ncol + tid];
+    tot[tid] = t;
+  }
+  __syncthreads();
+  const int gpw = fdiv(a.cw, a.fd_cpg);
+  if (tid < gpw) {
+    double sd = 0.0, qd = 0.0;
+    for (int i = 0; i < a.cpg; ++i) { sd += (double)tot[(tid * a.cpg + i) * 2]; qd += (double)tot[(tid * a.cpg + i) * 2 + 1]; }
+    const double cnt = (double)a.HW * a.cpg;
+    const double mean = sd / cnt;
+    double var = qd / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    gst[2 * tid] = (float)mean;
+    gst[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  if (tid < a.cw) {
+    const int g = fdiv(tid, a.fd_cpg);
+    const int cg = cwin + tid;
+    const float sc = gst[2 * g + 1] * a.gamma[cg];
+    const float sh = a.beta[cg] - gst[2 * g] * sc;
+    a.ss[((long long)b * 2 + 0) * a.C + cg] = sc;
+    a.ss[((long long)b * 2 + 1) * a.C + cg] = sh;
+    lss[tid] = sc;
+    lss[a.cw + tid] = sh;
+  }
+  if constexpr (MAXV > 0) {
+    __syncthreads();
+    if (!active) return;
+    const float4 sc = *(const float4*)(lss + 4 * tx), sh = *(const float4*)(lss + a.cw + 4 * tx);
+    bf16_t* dst = a.y + (long long)b * a.HW * a.C + c;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int r = ty + k * a.nty;
+      if (r >= a.HW) break;
+      float o0 = __builtin_fmaf(bflo(v[k].x), sc.x, sh.x), o1 = __builtin_fmaf(bfhi(v[k].x), sc.y, sh.y);
+      float o2 = __builtin_fmaf(bflo(v[k].y), sc.z, sh.z), o3 = __builtin_fmaf(bfhi(v[k].y), sc.w, sh.w);
+      if (a.silu) { o0 = silu_fast_f(o0); o1 = silu_fast_f(o1); o2 = silu_fast_f(o2); o3 = silu_fast_f(o3); }
+      *(uint2*)(dst + (long long)r * a.C) = make_uint2(cvt_pk_bf16_f32(o0, o1), cvt_pk_bf16_f32(o2, o3));
+    }
+  }
+}
+
+template <int NT, int MAXV>
+int launch_gn_slab(const GnSlabArgs& a, int B, hipStream_t s) {
+  const size_t lds = (size_t)(NT * 9 + 256 + 64 + 256) * sizeof(float);
+  MG_LAUNCH((gn_slab_kernel<NT, MAXV>), dim3(a.C / a.cw, B), dim3(NT), lds, s, a);
+  return 0;
+}
+
 // LayerNorm over the last dim: one wave per R rows, all R rows' 16-byte loads issued before any
 // reduction (with a single row in flight per wave the kernel sits at ~2.7 TB/s: bytes in flight =
 // waves x 640 B, Little's law).  C <= 64 * 8 * NV.
@@ -352,6 +491,45 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
       MG_REQUIRE(C0 > 0 && C0 <= C && C0 % 8 == 0, "gn_apply: first source has %d of %d channels", C0, C);
       MG_LAUNCH(gn_apply_kernel, dim3(chunks, B), dim3(256), 0, s, (const bf16_t*)op->p[0],
                 (const float*)op->p[1], (bf16_t*)op->p[2], HW, C, op->i[3], chunks, x1, C0);
+      break;
+    }
+    case MG_OP_GN_SLAB: {
+      GnSlabArgs a;
+      a.x0 = (const bf16_t*)op->p[0];
+      a.x1 = (const bf16_t*)op->p[1];
+      a.y = (bf16_t*)op->p[2];
+      a.gamma = (const float*)op->p[3];
+      a.beta = (const float*)op->p[4];
+      a.ss = (float*)op->p[5];
+      const int B = op->i[0];
+      a.HW = op->i[1]; a.C = op->i[2]; a.C0 = a.x1 ? op->i[3] : a.C;
+      const int groups = op->i[4];
+      a.silu = op->i[5];
+      a.eps = op->f[0];
+      MG_REQUIRE(a.x0 && a.gamma && a.beta && a.ss && B > 0 && a.HW > 0 && groups > 0 && a.C % groups == 0, "gn_slab: bad arguments");
+      a.cpg = a.C / groups;
+      a.cw = a.cpg % 4 == 0 ? a.cpg : (a.cpg % 2 == 0 ? 2 * a.cpg : 4 * a.cpg);   // lcm(cpg, 4)
+      MG_REQUIRE(a.cw <= 128 && a.C % a.cw == 0 && a.C0 % 4 == 0 && a.C0 > 0 && a.C0 <= a.C,
+                 "gn_slab: %d channels per group need a %d-channel window (<= 128, dividing C = %d; C0 = %d a multiple of 4)", a.cpg, a.cw, a.C, a.C0);
+      MG_REQUIRE((uintptr_t)a.x0 % 8 == 0 && (uintptr_t)a.x1 % 8 == 0 && (uintptr_t)a.y % 8 == 0, "gn_slab: 8-byte alignment");
+      a.vw = a.cw / 4;
+      a.fd_vw = mg_make_fastdiv(a.vw);
+      a.fd_ncol = mg_make_fastdiv(a.cw * 2);
+      a.fd_cpg = mg_make_fastdiv(a.cpg);
+      const long long slab = (long long)a.HW * a.cw * 2;
+      const int NT = slab >= 48 * 1024 ? 1024 : 256;
+      a.nty = NT / a.vw;
+      const int need = (a.HW + a.nty - 1) / a.nty;   // rows per thread
+      int rc;
+      if (!a.y) rc = NT == 1024 ? launch_gn_slab<1024, 0>(a, B, s) : launch_gn_slab<256, 0>(a, B, s);
+      else if (NT == 1024) {
+        MG_REQUIRE(need <= 48, "gn_slab: %d rows per thread exceed the register-resident form (H x W %d, window %d)", need, a.HW, a.cw);
+        rc = need <= 12 ? launch_gn_slab<1024, 12>(a, B, s) : need <= 24 ? launch_gn_slab<1024, 24>(a, B, s) : launch_gn_slab<1024, 48>(a, B, s);
+      } else {
+        MG_REQUIRE(need <= 48, "gn_slab: %d rows per thread exceed the register-resident form (H x W %d, window %d)", need, a.HW, a.cw);
+        rc = need <= 8 ? launch_gn_slab<256, 8>(a, B, s) : need <= 24 ? launch_gn_slab<256, 24>(a, B, s) : launch_gn_slab<256, 48>(a, B, s);
+      }
+      if (rc) return rc;
       break;
     }
     case MG_OP_LAYERNORM: {

@@ -40,6 +40,7 @@ static int dispatch(const mg_op* op, hipStream_t s) {
     case MG_OP_GN_STATS:
     case MG_OP_GN_FINALIZE:
     case MG_OP_GN_APPLY:
+    case MG_OP_GN_SLAB:
     case MG_OP_LAYERNORM: return mg_launch_norm(op, s);
     case MG_OP_FLASH_ATTN64:
     case MG_OP_SOFTMAX_ROWS:

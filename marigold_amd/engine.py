@@ -25,6 +25,7 @@ USE_PATCH = os.environ.get("MARIGOLD_PATCH_CONV", "1") != "0"      # patch-resid
 FUSE_GN = os.environ.get("MARIGOLD_FUSE_GN", "auto")               # auto | all | none: GroupNorm apply inside the conv
 FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"
 XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)
+GN_SLAB = os.environ.get("MARIGOLD_GN_SLAB", "1") != "0"           # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 FLASH_VT_PERM = os.environ.get("MARIGOLD_FLASH_VT_PERM", "1") != "0"   # permuted V^T + generation-3 attention (0: generation 2)
 
 
@@ -220,9 +221,41 @@ class Builder:
         self.seq.add(op, label)
 
     # ---- primitive layers ----------------------------------------------------------------
+    def gn_slab_ok(self, srcs, apply):
+        """One-launch GroupNorm (MG_OP_GN_SLAB: a workgroup owns whole groups of an image over all rows)?  UNet-sized
+        maps with enough (image, channel window) pairs to fill the chip; the normalising form keeps the rows in registers
+        (<= 48 rows per thread).  The VAE's 128-channel 768^2 tensors (4-channel groups: 8-byte row segments) stay on the
+        chunked statistics / apply passes."""
+        B, HW = srcs[0].B, srcs[0].HW
+        C = sum(x.C for x in srcs)
+        if not GN_SLAB or len(srcs) > 2 or C % self.groups or any(x.C % 4 for x in srcs):
+            return False
+        cpg = C // self.groups
+        cw = cpg * (4 // math.gcd(cpg, 4))
+        if not (16 <= cw <= 128) or HW > 16384 or B * (C // cw) < 64:
+            return False
+        if apply:
+            nt = 1024 if HW * cw * 2 >= 48 * 1024 else 256
+            if -(-HW // (nt // (cw // 4))) > 48:
+                return False
+        return True
+
+    def gn_slab(self, srcs, name, eps, silu, apply):
+        """-> (scale/shift buffer, normalised Act | None) in ONE launch."""
+        x = srcs[0]
+        C = sum(y.C for y in srcs)
+        ss = self.raw(x.B * 2 * C * 4)
+        out = self.new(x.B, x.H, x.W, C) if apply else None
+        self.add(O.gn_slab(x.t, None if out is None else out.t, ss, B=x.B, HW=x.HW, C=C, groups=self.groups,
+                           gamma=self.ws.vec(f"{name}.weight"), beta=self.ws.vec(f"{name}.bias"), eps=eps, silu=silu,
+                           x1=srcs[1].t if len(srcs) > 1 else None, C0=x.C), f"{name}.slab" + ("+apply" if apply else ""))
+        return ss, out
+
     def gn_scale_shift(self, srcs, name, eps):
         """GroupNorm statistics over the channel concat of ``srcs`` (never materialised: one statistics launch per
         source into a shared partial table) -> fp32 [B][2][C] (scale, shift) buffer."""
+        if self.gn_slab_ok(srcs, False):
+            return self.gn_slab(srcs, name, eps, False, False)[0]
         B, HW = srcs[0].B, srcs[0].HW
         C = sum(x.C for x in srcs)
         # ~768 (chunk, image) blocks: covers the 256 CUs three times over while keeping the
@@ -255,6 +288,10 @@ class Builder:
         return out
 
     def group_norm(self, x, name, eps, silu):
+        if self.gn_slab_ok([x], True):
+            ss, out = self.gn_slab([x], name, eps, silu, True)
+            self.free(ss)
+            return out
         ss = self.gn_scale_shift([x], name, eps)
         out = self.gn_apply([x], ss, name, silu)
         self.free(ss)
@@ -391,9 +428,15 @@ class Builder:
         patch = USE_PATCH and self.patch_eligible(x.H, x.W, x.B, cout)
 
         def norm_conv(inputs, norm, conv, rowvec=None, residual=None, out=None):
-            ss = self.gn_scale_shift(inputs, norm, eps)
             cin = sum(y.C for y in inputs)
-            if patch and self.fuse_norm_into_conv(x.B, x.H, x.W, cin, cout):
+            fused = patch and self.fuse_norm_into_conv(x.B, x.H, x.W, cin, cout)
+            if not fused and self.gn_slab_ok(inputs, True):   # statistics + normalisation (+ the concat) in one launch
+                ss, h = self.gn_slab(inputs, norm, eps, True, True)
+                y = self.conv3x3(h, conv, cout, rowvec=rowvec, residual=residual, out=out)
+                self.free(h, ss)
+                return y
+            ss = self.gn_scale_shift(inputs, norm, eps)
+            if fused:
                 y = self.conv3x3p(inputs, conv, cout, ss=ss, silu=True, rowvec=rowvec, residual=residual, out=out)
             else:
                 h = self.gn_apply(inputs, ss, norm, True)

@@ -85,6 +85,11 @@ def gn_apply(x, ss, out, *, B, HW, C, silu, x1=None, C0=0):
     return make_op(L.OP_GN_APPLY, i=[B, HW, C, int(silu), C0], p=[x, ss, out, x1])
 
 
+def gn_slab(x0, out, ss, *, B, HW, C, groups, gamma, beta, eps, silu=False, x1=None, C0=0):
+    """GroupNorm in one launch (MG_OP_GN_SLAB): scale / shift into ``ss`` and, with ``out``, the normalised tensor."""
+    return make_op(L.OP_GN_SLAB, i=[B, HW, C, C0, groups, int(silu)], f=[eps], p=[x0, x1, out, gamma, beta, ss])
+
+
 def layernorm(x, gamma, beta, out, *, M, C, eps=1e-5):
     return make_op(L.OP_LAYERNORM, i=[M, C], f=[eps], p=[x, gamma, beta, out])
 

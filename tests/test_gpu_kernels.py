@@ -679,6 +679,53 @@ def test_groupnorm(dev, B, H, W, C, silu, eps):
     _close(f"groupnorm/C{C}", out.float().permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("B,H,W,C0,C1,silu,eps", [
+    (2, 48, 48, 640, 0, True, 1e-5),       # level 1: 20-channel groups, 92 KB slabs, 12 rows per thread in registers
+    (2, 24, 24, 1280, 1280, True, 1e-5),   # skip concat 2560: 80-channel groups, a window never straddles the sources
+    (3, 12, 12, 1280, 0, False, 1e-6),     # 256-thread workgroups
+    (1, 96, 96, 320, 0, False, 1e-6),      # level 0: 10-channel groups -> 20-channel windows (a vector straddles two groups)
+    (2, 48, 48, 640, 320, True, 1e-5),     # 960 = 30-channel groups -> 60-channel windows, second source from channel 640
+    (1, 13, 9, 320, 320, True, 1e-5),      # odd map
+])
+def test_groupnorm_one_launch(dev, B, H, W, C0, C1, silu, eps):
+    """MG_OP_GN_SLAB (statistics + scale/shift + normalised output in one launch, rows resident in registers) against
+    torch group_norm in fp32; the statistics-only form against the same scale / shift; both bit-stable across launches."""
+    from marigold_amd import ops
+    C = C0 + C1
+    g = torch.Generator().manual_seed(C + H)
+    x = _bf(torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3 + torch.randn(1, C, 1, 1, generator=g))
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    ref = F.group_norm(x, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    xg = x.reshape(B, 32, -1)
+    mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    cpg = C // 32
+    sc_ref = rstd.repeat_interleave(cpg, 1) * gamma
+    sh_ref = beta - mean.repeat_interleave(cpg, 1) * sc_ref
+    HW = H * W
+    xn = _nhwc(x)
+    x0 = xn[..., :C0].contiguous().to(dev, torch.bfloat16)
+    x1 = xn[..., C0:].contiguous().to(dev, torch.bfloat16) if C1 else None
+    outs = []
+    for rep in range(2):
+        ss = torch.full((B, 2, C), float("nan"), device=dev)
+        out = torch.full((B, HW, C), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.gn_slab(x0, out, ss, B=B, HW=HW, C=C, groups=32, gamma=gamma.to(dev), beta=beta.to(dev), eps=eps, silu=silu,
+                         x1=x1, C0=C0))
+        outs.append((ss.clone(), out.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ss, out = outs[0]
+    _close(f"gn_slab/scale/C{C}", ss[:, 0], sc_ref, tol=2e-4)
+    _close(f"gn_slab/shift/C{C}", ss[:, 1], sh_ref, tol=2e-4)
+    _close(f"gn_slab/out/C{C}", out.reshape(B, H, W, C).float().permute(0, 3, 1, 2), ref)
+    ss2 = torch.full((B, 2, C), float("nan"), device=dev)
+    _run(ops.gn_slab(x0, None, ss2, B=B, HW=HW, C=C, groups=32, gamma=gamma.to(dev), beta=beta.to(dev), eps=eps, x1=x1, C0=C0))
+    _close(f"gn_slab/stats_only/C{C}", ss2, ss, tol=1e-5)
+
+
 @pytest.mark.parametrize("M,C", [(37, 64), (200, 320), (50, 1280), (131, 640), (9, 2048), (1, 1024)])
 def test_layernorm(dev, M, C):
     from marigold_amd import ops
