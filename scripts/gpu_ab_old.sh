@@ -8,7 +8,7 @@ import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
         j=json.loads(l); k=j['kernels']
-        print('$side', 'ms', j['ms_per_step'], ' '.join(f\"{n}={v['ms']:.1f}\" for n,v in k.items() if v['ms']>1.5))
+        print('$side', 'ms', j['ms_per_step'], ' '.join(f\"{n}={v['ms']:.1f}\" for n,v in k.items() if v['ms']>1.5), 'ens', j['stages'].get('ensemble',{}).get('ms'))
 ")
   done
 done

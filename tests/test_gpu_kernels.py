@@ -755,7 +755,7 @@ def test_flash_attn64(dev, B, heads, T):
     vt[:, :, :T] = v.permute(0, 2, 1).to(dev, torch.bfloat16)
     vtp = ops.permute_vt_keys(vt)   # the key order generation 3 reads without a lane exchange (MG_OP_IGEMM trans_perm)
     # 0 = default; 1 = generation 1; 2-8 = generation 2; 9-12 = generation 3; 13-18 (and 0 with vt_perm) = permuted V^T
-    for variant, perm in [(v, False) for v in range(13)] + ([(v, True) for v in (0, 13, 14, 15, 16, 17, 18)] if T % 16 == 0 else []):
+    for variant, perm in [(v, False) for v in list(range(13)) + [21]] + ([(v, True) for v in (0, 13, 14, 15, 16, 17, 18, 19, 20)] if T % 16 == 0 else []):
         out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.flash_attn64(qkd, qkd[:, :, C:], vtp if perm else vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C,
                               ldvt=ldvt, sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125,
@@ -777,7 +777,7 @@ def test_flash_attn64_spiky_scores(dev):
     qkv = torch.cat([q, k], dim=-1).to(dev, torch.bfloat16)
     vt = v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16)
     vtp = ops.permute_vt_keys(vt)
-    for variant, perm in [(v, False) for v in (0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12)] + [(v, True) for v in (0, 13, 14, 15, 16, 17, 18)]:
+    for variant, perm in [(v, False) for v in (0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 21)] + [(v, True) for v in (0, 13, 14, 15, 16, 17, 18, 19, 20)]:
         out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.flash_attn64(qkv, qkv[:, :, C:], vtp if perm else vt, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T,
                               sq=0, sk=0, svt=0, so=0, scale=0.125, variant=variant, vt_perm=perm))
@@ -829,7 +829,7 @@ def test_flash_attn64_running_max_paths(dev, case):
     vt = torch.zeros(1, C, ldvt, device=dev, dtype=torch.bfloat16)
     vt[:, :, :T] = v.permute(0, 2, 1).to(dev, torch.bfloat16)
     vtp = ops.permute_vt_keys(vt)
-    for variant, perm in [(v, False) for v in (0, 6, 9, 10, 11, 12)] + [(v, True) for v in (0, 13, 14, 15, 16, 17, 18)]:
+    for variant, perm in [(v, False) for v in (0, 6, 9, 10, 11, 12, 21)] + [(v, True) for v in (0, 13, 14, 15, 16, 17, 18, 19, 20)]:
         out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.flash_attn64(qkv, qkv[:, :, C:], vtp if perm else vt, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=ldvt,
                               sq=0, sk=0, svt=0, so=0, scale=0.125, variant=variant, vt_perm=perm))

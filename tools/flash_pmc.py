@@ -19,8 +19,8 @@ vt = qkv[:, :, 2 * C:].permute(0, 2, 1).contiguous()
 vtp = O.permute_vt_keys(vt)
 out = torch.empty(B, T, C, device=dev, dtype=torch.bfloat16)
 for v in [int(x) for x in os.environ.get("FLASH_VARIANTS", "6,10,14,16,17").split(",")]:
-    op = O.flash_attn64(qkv, qkv[:, :, C:], vtp if v >= 13 else vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=T,
-                        sq=T * 3 * C, sk=T * 3 * C, svt=C * T, so=T * C, scale=0.125, variant=v, vt_perm=v >= 13)
+    op = O.flash_attn64(qkv, qkv[:, :, C:], vtp if 13 <= v <= 20 else vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=T,
+                        sq=T * 3 * C, sk=T * 3 * C, svt=C * T, so=T * C, scale=0.125, variant=v, vt_perm=13 <= v <= 20)
     for _ in range(3):
         O.launch(op)
     torch.cuda.synchronize()
