@@ -56,6 +56,9 @@ enum mg_op_kind {
    *  igemm2.hip::dispatch_tile)  i[20] ldw
    *  i[21] rowvec broadcast (1 = a single [N] row shared by every image)
    *  i[22], i[23] un-padded N, K for FLOP accounting (0 = as launched; ignored by the kernel)
+   *  i[26] 1 = the transposed section stores its tokens in accumulator order inside groups of 16 (MG_OP_FLASH_ATTN64 i[7])
+   *  i[29], i[30] low / high 32 bits of the device address of the caller's row-block tickets for the p[8] statistics
+   *  hand-off (65536 zeroed uint32, one buffer per program / stream; 0 = the library's global buffer: single stream only)
    *  l[0..3] z-strides (elements) of A, Wt, out, residual      f[0] scale on the accumulator */
   MG_OP_IGEMM = 1,
   /* GroupNorm, 3 launches (stats partials -> per-(b,c) scale/shift -> apply [+SiLU]).
@@ -87,7 +90,8 @@ enum mg_op_kind {
    * tiles (replaces diffusers Attention / SDPA / xformers, run.py:217-220).
    *  p[0] Q bf16 (row stride ldq)  p[1] K (row stride ldq)  p[2] Vt bf16 [B][heads*64][ldvt]
    *  p[3] O bf16 (row stride ldo); i: B, heads, Ntok, ldq, ldo, ldvt, variant (0 = current
- *  kernel, 1 = generation-1 kernel kept for A/B runs) ;
+   *  kernel, 1 = generation-1 kernel kept for A/B runs), i[7] 1 = Vt's keys are in the order [0-3, 8-11, 4-7, 12-15]
+   *  inside every group of 16 (as written by MG_OP_IGEMM i[26]; Ntok % 16 == 0) ; p[4] tuning only: cycle stamps | NULL ;
    *  l[0] q batch stride l[1] k batch stride l[2] vt batch stride l[3] o batch stride;
    *  f[0] softmax scale */
   MG_OP_FLASH_ATTN64 = 6,

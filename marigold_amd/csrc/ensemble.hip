@@ -19,14 +19,21 @@
 
 namespace {
 
-constexpr int EMAX = 32;
+constexpr int EMAX = 32;        // members a thread keeps in registers (selection kernels) / columns per second-moment block
+constexpr int EMAX_LDS = 128;   // members of the LDS-resident selection (33 ... 128: any size the reference's users ask for in
+                                // practice - it warns above 15, script/depth/run.py:143-144)
 constexpr int ENS_BLOCKS = 512;
 
-// grid (nblk, E): block (x, i) accumulates row i of the raw second-moment matrix
-__global__ __launch_bounds__(256) void depth_stats_kernel(const float* __restrict__ d, double* __restrict__ part,
-                                                          int E, long long HW) {
+// grid (nblk, E, column chunks of 32): block (x, i, jc) accumulates columns [32 jc, 32 jc + 32) of row i of the raw
+// second-moment matrix; partial layout [block x][row i][3 + E] (min, max, sum, row of the matrix)
+__global__ __launch_bounds__(256) void depth_stats_kernel(const float* __restrict__ d0, double* __restrict__ part,
+                                                          int Etot, long long HW) {
   __shared__ double red[4][EMAX + 3];
   const int i = blockIdx.y;
+  const int j0 = blockIdx.z * EMAX;
+  const int E = min(EMAX, Etot - j0);            // columns of this block
+  const float* __restrict__ d = d0 + (long long)j0 * HW;
+  const float* __restrict__ di_row = d0 + (long long)i * HW;
   float acc[EMAX];
 #pragma unroll
   for (int j = 0; j < EMAX; ++j) acc[j] = 0.f;
@@ -38,7 +45,7 @@ __global__ __launch_bounds__(256) void depth_stats_kernel(const float* __restric
   for (int j = 0; j < EMAX; ++j) accd[j] = 0.0;
   int cnt = 0;
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
-    const float di = d[(long long)i * HW + p];
+    const float di = di_row[p];
     mn = fminf(mn, di);
     mx = fmaxf(mx, di);
     sum += (double)di;
@@ -70,40 +77,41 @@ __global__ __launch_bounds__(256) void depth_stats_kernel(const float* __restric
       if (j < E) red[wave][3 + j] = accd[j];
   }
   __syncthreads();
-  double* o = part + ((long long)blockIdx.x * E + i) * (EMAX + 3);
+  double* o = part + ((long long)blockIdx.x * Etot + i) * (Etot + 3);
   for (int k = threadIdx.x; k < E + 3; k += 256) {
     double v;
     if (k == 0) v = fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0]));
     else if (k == 1) v = fmax(fmax(red[0][1], red[1][1]), fmax(red[2][1], red[3][1]));
     else v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-    o[k] = v;
+    if (k < 3) { if (j0 == 0) o[k] = v; }       // min / max / sum of row i: once
+    else o[3 + j0 + (k - 3)] = v;
   }
 }
 
 // one block; out = [min[E], max[E], mean[E], C[E][E]] (C centred)
 __global__ __launch_bounds__(256) void depth_stats_final_kernel(const double* __restrict__ part, double* __restrict__ out,
                                                                 int E, int nblk, long long HW) {
-  __shared__ double mean_s[EMAX];
-  __shared__ double raw[EMAX * EMAX];
+  __shared__ double mean_s[EMAX_LDS];
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < E * (E + 3); idx += 256) {
-    const int i = idx / (E + 3), k = idx % (E + 3);
+  for (int idx = tid; idx < E * 3; idx += 256) {
+    const int i = idx / 3, k = idx % 3;
     double v = (k == 0) ? 3.0e38 : (k == 1 ? -3.0e38 : 0.0);
     for (int b = 0; b < nblk; ++b) {
-      const double x = part[((long long)b * E + i) * (EMAX + 3) + k];
+      const double x = part[((long long)b * E + i) * (E + 3) + k];
       if (k == 0) v = fmin(v, x);
       else if (k == 1) v = fmax(v, x);
       else v += x;
     }
     if (k == 0) out[i] = v;
     else if (k == 1) out[E + i] = v;
-    else if (k == 2) { mean_s[i] = v / (double)HW; out[2 * E + i] = mean_s[i]; }
-    else raw[i * E + (k - 3)] = v / (double)HW;
+    else { mean_s[i] = v / (double)HW; out[2 * E + i] = mean_s[i]; }
   }
   __syncthreads();
   for (int idx = tid; idx < E * E; idx += 256) {
     const int i = idx / E, j = idx % E;
-    out[3 * E + idx] = raw[idx] - mean_s[i] * mean_s[j];
+    double v = 0.0;
+    for (int b = 0; b < nblk; ++b) v += part[((long long)b * E + i) * (E + 3) + 3 + j];   // same order as before: b ascending
+    out[3 * E + idx] = v / (double)HW - mean_s[i] * mean_s[j];
   }
 }
 
@@ -190,6 +198,89 @@ __global__ __launch_bounds__(256) void depth_median_kernel(const float* __restri
   if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; redp[wave] = pmn; redp[4 + wave] = pmx; }
   __syncthreads();
   if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      if (red[w] < red[0] || (red[w] == red[0] && redp[w] < redp[0])) { red[0] = red[w]; redp[0] = redp[w]; }
+      if (red[4 + w] > red[4] || (red[4 + w] == red[4] && redp[4 + w] < redp[4])) { red[4] = red[4 + w]; redp[4] = redp[4 + w]; }
+    }
+    blockmm[2 * blockIdx.x] = red[0];
+    blockmm[2 * blockIdx.x + 1] = red[4];
+    blockpx[2 * blockIdx.x] = redp[0];
+    blockpx[2 * blockIdx.x + 1] = redp[4];
+  }
+}
+
+// 33 ... 128 members: the aligned values of a pixel live in LDS ([member][thread]: conflict-free), the lower-middle order
+// statistic is found by counting ranks (O(E^2) per pixel - large ensembles are rare and the pass stays HBM-light).
+// Same semantics, same outputs as depth_median_kernel.
+__global__ __launch_bounds__(256) void depth_median_lds_kernel(const float* __restrict__ d, const float* __restrict__ st,
+                                                               float* __restrict__ med, float* __restrict__ mad,
+                                                               float* __restrict__ blockmm, long long* __restrict__ blockpx,
+                                                               int E, long long HW, int reduction, int has_shift, int aligned) {
+  extern __shared__ float lds_a[];   // [E][256] aligned values (128 KB at E = 128), then [2 E] scale / shift
+  __shared__ float red[8];
+  __shared__ long long redp[8];
+  const int tid = threadIdx.x;
+  float* a = lds_a + tid;
+  float* sc = lds_a + (long long)E * 256;
+  for (int e = tid; e < E; e += 256) {
+    sc[e] = aligned ? st[e] : 1.f;
+    sc[E + e] = (aligned && has_shift) ? st[E + e] : 0.f;
+  }
+  __syncthreads();
+  long long pmn = 0, pmx = 0;
+  float mn = 3.0e38f, mx = -3.0e38f;
+  const int k = (E - 1) >> 1;
+  // element of rank k (ties by member index), as select_rank; DEV: of the absolute deviations |a - centre| (formed on the
+  // fly: a second [E][256] array would not fit the 160 KB of LDS)
+  auto select = [&](bool dev_, float centre) {
+    auto val = [&](int e) { const float x = a[e * 256]; return dev_ ? fabsf(__fsub_rn(x, centre)) : x; };
+    float res = val(0);
+    for (int e = 0; e < E; ++e) {
+      const float ve = val(e);
+      int rank = 0;
+      for (int j = 0; j < E; ++j) {
+        const float vj = val(j);
+        rank += (vj < ve) || (vj == ve && j < e);
+      }
+      if (rank == k) res = ve;
+    }
+    return res;
+  };
+  for (long long p = (long long)blockIdx.x * 256 + tid; p < HW; p += (long long)gridDim.x * 256) {
+    for (int e = 0; e < E; ++e) {
+      const float v = d[(long long)e * HW + p];
+      a[e * 256] = aligned ? __fadd_rn(__fmul_rn(v, sc[e]), sc[E + e]) : v;
+    }
+    float pred, unc = 0.f;
+    if (reduction == 0) {
+      pred = select(false, 0.f);
+      if (mad) unc = select(true, pred);
+    } else {
+      float s = 0.f;
+      for (int e = 0; e < E; ++e) s += a[e * 256];
+      pred = s / (float)E;
+      if (mad) {
+        float q = 0.f;
+        for (int e = 0; e < E; ++e) { const float dd = a[e * 256] - pred; q += dd * dd; }
+        unc = sqrtf(q / (float)(E > 1 ? E - 1 : 1));
+      }
+    }
+    if (med) med[p] = pred;
+    if (mad) mad[p] = unc;
+    if (pred < mn) { mn = pred; pmn = p; }
+    if (pred > mx) { mx = pred; pmx = p; }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float omn = __shfl_xor(mn, o), omx = __shfl_xor(mx, o);
+    const long long opmn = __shfl_xor(pmn, o), opmx = __shfl_xor(pmx, o);
+    if (omn < mn || (omn == mn && opmn < pmn)) { mn = omn; pmn = opmn; }
+    if (omx > mx || (omx == mx && opmx < pmx)) { mx = omx; pmx = opmx; }
+  }
+  if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; redp[wave] = pmn; redp[4 + wave] = pmx; }
+  __syncthreads();
+  if (tid == 0) {
     for (int w = 1; w < 4; ++w) {
       if (red[w] < red[0] || (red[w] == red[0] && redp[w] < redp[0])) { red[0] = red[w]; redp[0] = redp[w]; }
       if (red[4 + w] > red[4] || (red[4 + w] == red[4] && redp[4 + w] < redp[4])) { red[4] = red[4 + w]; redp[4] = redp[4 + w]; }
@@ -293,9 +384,9 @@ int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
     case MG_OP_ENS_DEPTH_STATS: {
       const int E = op->i[0];
       const long long HW = op->l[0];
-      MG_REQUIRE(E >= 1 && E <= EMAX, "ens_depth_stats: E %d out of range [1,%d]", E, EMAX);
+      MG_REQUIRE(E >= 1 && E <= EMAX_LDS, "ens_depth_stats: E %d out of range [1,%d]", E, EMAX_LDS);
       const int nblk = (int)min((HW + 255) / 256, (long long)128);
-      MG_LAUNCH(depth_stats_kernel, dim3(nblk, E), dim3(256), 0, s, (const float*)op->p[0],
+      MG_LAUNCH(depth_stats_kernel, dim3(nblk, E, (E + EMAX - 1) / EMAX), dim3(256), 0, s, (const float*)op->p[0],
                          (double*)op->p[1], E, HW);
       MG_LAUNCH(depth_stats_final_kernel, dim3(1), dim3(256), 0, s, (const double*)op->p[1],
                          (double*)op->p[2], E, nblk, HW);
@@ -304,10 +395,21 @@ int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
     case MG_OP_ENS_DEPTH_MEDIAN: {
       const int E = op->i[0];
       const long long HW = op->l[0];
-      MG_REQUIRE(E >= 1 && E <= EMAX, "ens_depth_median: E %d out of range [1,%d]", E, EMAX);
+      MG_REQUIRE(E >= 1 && E <= EMAX_LDS, "ens_depth_median: E %d out of range [1,%d]", E, EMAX_LDS);
       MG_REQUIRE(op->p[4] && op->p[5], "ens_depth_median: minmax / scratch missing");
       const int nblk = (int)min((HW + 255) / 256, (long long)ENS_BLOCKS);
-      if (E <= 4) launch_median<4>(op, nblk, s);
+      if (E > EMAX) {
+        const size_t lds = ((size_t)E * 256 + 2 * E) * sizeof(float);
+        static bool attr = false;
+        if (!attr && !g_dry_run) {
+          MG_CHECK_HIP(hipFuncSetAttribute((const void*)depth_median_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(((size_t)EMAX_LDS * 256 + 2 * EMAX_LDS) * sizeof(float))));
+          attr = true;
+        }
+        MG_LAUNCH(depth_median_lds_kernel, dim3(nblk), dim3(256), lds, s, (const float*)op->p[0], (const float*)op->p[1],
+                  (float*)op->p[2], (float*)op->p[3], (float*)op->p[5], (long long*)((char*)op->p[5] + 8 * ENS_BLOCKS), E,
+                  op->l[0], op->i[1], op->i[2], op->p[1] != nullptr);
+      } else if (E <= 4) launch_median<4>(op, nblk, s);
       else if (E <= 8) launch_median<8>(op, nblk, s);
       else if (E <= 10) launch_median<10>(op, nblk, s);
       else if (E <= 16) launch_median<16>(op, nblk, s);
@@ -370,9 +472,9 @@ double np_pairwise_sum(const double* a, int n) {
 
 extern "C" int mg_ens_align_cost_grad(int E, const double* s, const double* t, const double* mean, const double* C,
                                       double* cost, double* gs, double* gt) {
-  MG_REQUIRE(E >= 1 && E <= 64 && s && t && mean && C && cost && gs && gt, "ens_align_cost_grad: bad arguments");
-  double u[64], s2d[64], sdc[64];
-  static thread_local double r[64 * 64], w[64 * 64], tmp[64 * 64];
+  MG_REQUIRE(E >= 1 && E <= 128 && s && t && mean && C && cost && gs && gt, "ens_align_cost_grad: bad arguments");
+  double u[128], s2d[128], sdc[128];
+  static thread_local double r[128 * 128], w[128 * 128], tmp[128 * 128];
   for (int i = 0; i < E; ++i) {
     u[i] = s[i] * mean[i] + t[i];
     s2d[i] = (s[i] * s[i]) * C[i * E + i];

@@ -287,7 +287,12 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.fd_per_z = a.fd_tiles = a.fd_tiles_n = a.fd_cpt = mg_make_fastdiv(1);
   a.lin = a.taps == 1 && a.stride == 1 && a.pad == 0 && a.Hu == 0 && a.Ho == a.H && a.Wo == a.W;
   a.inv_n = 1.0 / (double)(a.N > 0 ? a.N : 1);
-  a.ln_ctr = g_ln_counters;
+  // row-block tickets of the ln_out hand-off: the caller's own buffer (i[29] / i[30] = low / high half of its device address;
+  // MG_LN_COUNTERS zeroed uint32, one per program / stream - engine.py::Builder) or, absent, the library's global one, which
+  // is only safe while every program that writes row statistics runs on ONE stream (the tickets are self-resetting and
+  // stream-ordered, but two streams would draw from the same slots)
+  a.ln_ctr = (op->i[29] | op->i[30]) ? (unsigned*)(uintptr_t)((uint64_t)(uint32_t)op->i[29] | ((uint64_t)(uint32_t)op->i[30] << 32))
+                                     : g_ln_counters;
   a.tiles_m = a.tiles_n = 0;
   MG_REQUIRE(g_zero_page || g_dry_run, "igemm: mg_init() not called");
   MG_REQUIRE(a.A && a.Wt && (a.out || out2), "igemm: null pointer");

@@ -126,8 +126,8 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   const int tile_m = fdiv(t, a.fd_tiles_n), tile_n = t - tile_m * a.tiles_n;
   const int m0 = tile_m * BM, n0 = a.n_begin + tile_n * BN;
 
-  const bf16_t* __restrict__ Ab = a.A + (long long)z * a.sA;
-  const bf16_t* __restrict__ A1b = a.A1;
+  const bf16_t* Ab = a.A + (long long)z * a.sA;   // (no __restrict__: MG_EPI_XATTN2 runs in place, out == A)
+  const bf16_t* A1b = a.A1;
   const bf16_t* __restrict__ Wb = a.Wt + (long long)z * a.sW;
   const char* zero = (const char*)a.zero;
 
@@ -182,7 +182,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   const int hb = a.Hu ? a.Hu : a.H, wb = a.Hu ? a.Wu : a.W;  // bounds in (virtual) input space
   auto tap_setup = [&](int tap, bool second = false) {
     int dy = 0, dx = 0;
-    const bf16_t* __restrict__ Sb = second ? A1b : Ab;
+    const bf16_t* Sb = second ? A1b : Ab;
     const int ld = second ? a.lda1 : a.lda;
     if (a.lin) {
 #pragma unroll
@@ -556,6 +556,10 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   // no bounds masks, and the optional terms (folded LayerNorm, residual, time-embedding row, row statistics) are
   // compile-time flags of a generic lambda, selected by a wave-uniform branch.  Edge tiles, fp32 / pair-softmax /
   // split-K / sub-pixel outputs take the general epilogue below.
+  // Hand-off form (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "valid forms": {sc1 stores AND sc1 loads on both
+  // sides} + every storing wave drains vmcnt + __syncthreads + ONE relaxed agent-scope ticket): no release / acquire fence
+  // is needed because neither side ever holds the payload in a non-coherent cache line - the stores write through, the
+  // reducer's loads bypass its L1.  tests/test_gpu_kernels.py::test_igemm_row_statistics_bit_stable_at_scale gates it.
   // Row statistics of the output (ln_out): every tile has stored its slots with write-through (sc1) stores; the row
   // block's last column tile to get here (one relaxed agent-scope ticket per workgroup - the hand-off of
   // norm.hip::gn_stats_kernel) reduces the block's N / 32 slots per row to (mean, rstd) in a FIXED order (8 threads per

@@ -403,11 +403,14 @@ class Builder:
         of the INPUT is folded into this layer (x holds the raw rows)."""
         M, K = x.M, (K or x.C + (skip.C if skip is not None else 0))
         n_out = N // 2 if epi == L.EPI_GEGLU else N
+        # row-block tickets of the statistics hand-off: this program's own zeroed buffer (never the library-global one: two
+        # programs on different streams would draw from the same slots)
+        ctr = self.zeros_persistent("ln_counters", 4 * 65536) if ln_out is not None else None
         if out is None:
             out = Act(self.pool.get(M * n_out * out_dtype_bytes), x.B, x.H, x.W, n_out)
         self.add(O.linear(x.t, wt, out.t, M=M, K=K, N=N, bias=bias, epi=epi,
                           residual=None if residual is None else residual.t,
-                          a1=None if skip is None else skip.t, C0=x.C if skip is not None else 0, ln_out=ln_out,
+                          a1=None if skip is None else skip.t, C0=x.C if skip is not None else 0, ln_out=ln_out, ln_counters=ctr,
                           ln_in=None if ln is None else ln[0], ln_g=None if ln is None else ln[1],
                           ln_c=None if ln is None else ln[2]), label)
         return out
@@ -504,7 +507,7 @@ class Builder:
             self.add(O.linear(h.t, wqk, p, M=M, K=C, N=npad, epi=L.EPI_SOFTMAX2, ln_in=self.ln_mean_rstd(st, M, C), ln_g=g, ln_c=c,
                               sm_scale=1.0 / math.sqrt(C // heads), sm_cols=2 * heads), f"{prefix}.scores+softmax2")
             self.add(O.linear(p, vot, h.t, M=M, K=npad, N=C, bias=self.ws.bias(f"{prefix}.to_out.0"),
-                              residual=h.t, ln_out=st_out), f"{prefix}.blend")
+                              residual=h.t, ln_out=st_out, ln_counters=self.zeros_persistent("ln_counters", 4 * 65536)), f"{prefix}.blend")
             self.free(p)
             return
         else:
@@ -517,7 +520,8 @@ class Builder:
         self.add(O.softmax_pairs(s, p, M=M, pairs=heads, lds=npad, ldp=npad,
                                  scale=1.0 / math.sqrt(C // heads)), f"{prefix}.softmax2")
         self.add(O.linear(p, vot, h.t, M=M, K=npad, N=C, bias=self.ws.bias(f"{prefix}.to_out.0"),
-                          residual=h.t, ln_out=st_out), f"{prefix}.blend")
+                          residual=h.t, ln_out=st_out,
+                          ln_counters=None if st_out is None else self.zeros_persistent("ln_counters", 4 * 65536)), f"{prefix}.blend")
         self.free(s, p)
 
     def transformer(self, x, name, heads, ctx):

@@ -39,20 +39,21 @@ _SCRATCH_BYTES = 12288
 _FD_STEP = 1.4901161193847656e-08   # scipy's forward-difference step (sqrt(eps)), absolute
 
 
-MAX_ENSEMBLE_SIZE = 32   # members the per-pixel selection kernels keep in registers (csrc/ensemble.hip EMAX)
+MAX_ENSEMBLE_SIZE = 128   # depth / IID selection kernels: <= 32 members in registers, 33 ... 128 in LDS (csrc/ensemble.hip)
 
 
 def _check_members(E):
-    """The reference accepts any ensemble size (it warns above 15, marigold_depth_pipeline.py:236-240); the device
-    kernels hold one value per member in registers and stop at 32 - refused here by name instead of by a launch error."""
+    """The reference accepts any ensemble size (it warns above 15, script/depth/run.py:143-144); the per-pixel order
+    statistics of the depth / IID paths hold the members in registers (<= 32) or LDS (<= 128) - a larger ensemble is
+    refused here by name instead of by a launch error.  ``ensemble_normals`` loops over the members: no limit."""
     if E > MAX_ENSEMBLE_SIZE:
         raise ValueError(f"ensemble_size {E} exceeds the {MAX_ENSEMBLE_SIZE} members the HIP ensembling kernels support")
 
 
 def _check_depth_args(depth, reduction, scale_invariant, shift_invariant):
-    _check_members(depth.shape[0])
     if depth.dim() != 4 or depth.shape[1] != 1:
         raise ValueError(f"Expecting 4D tensor of shape [B,1,H,W]; got {depth.shape}.")
+    _check_members(depth.shape[0])
     if reduction not in ("mean", "median"):
         raise ValueError(f"Unrecognized reduction method: {reduction}.")
     if not scale_invariant and shift_invariant:
@@ -93,7 +94,7 @@ class HipStatsBackend:
     def stats(self):
         E = self.E
         dev = self.d.device
-        sscratch = torch.empty(128 * E * 35, dtype=torch.float64, device=dev)
+        sscratch = torch.empty(128 * E * (E + 3), dtype=torch.float64, device=dev)
         stats = torch.empty(3 * E + E * E, dtype=torch.float64, device=dev)
         O.launch(O.ens_depth_stats(self.d, sscratch, stats, E=E, HW=self.HW))
         st = stats.cpu().numpy()
@@ -272,8 +273,7 @@ def ensemble_normals(normals, output_uncertainty=False, reduction="closest"):
         raise ValueError(f"Expecting 4D tensor of shape [B,3,H,W]; got {normals.shape}.")
     if reduction not in ("closest", "mean"):
         raise ValueError(f"Unrecognized reduction method: {reduction}.")
-    E, _, H, W = normals.shape
-    _check_members(E)
+    E, _, H, W = normals.shape   # any ensemble size: the kernel loops over the members
     n = normals.to(torch.float32).contiguous()
     out = torch.empty(3, H * W, dtype=torch.float32, device=n.device)
     unc = torch.empty(H * W, dtype=torch.float32, device=n.device) if output_uncertainty else None

@@ -189,8 +189,10 @@ class _MarigoldPipelineBase:
         members = list(range(E))
         step_noises_all = None
         if self._member_parallel and mdist.world_size(self._member_group) > 1:
-            # every rank draws the full [E,4,h,w] noise (same generator state) and keeps its slice,
-            # so results do not depend on the number of GPUs
+            # every rank draws the full [E,4,h,w] noise (same generator state) and keeps its slice, so results do not depend on
+            # the number of GPUs: they are what ONE process draws when its batch holds all E members (batch_size >= E, the
+            # default on this hardware).  With a smaller batch_size the reference draws batch by batch (:281-289), and so
+            # does the single-process path below - the reference's own results depend on the batch size in that case
             if init_latents is None:
                 hh, ww = self._latent_hw(rgb_norm.shape[-2:])
                 init_latents = torch.randn((E, self._target_latent_channels, hh, ww), device=self.device, dtype=self.io_dtype,

@@ -62,3 +62,29 @@ def synthetic_image(height: int = 768, width: int = 768, seed: int = 0):
 def synthetic_latents(n, h, w, seed: int = 2024, dtype=torch.float32):
     g = torch.Generator("cpu").manual_seed(seed)
     return torch.randn(n, 4, h, w, generator=g, dtype=dtype)
+
+
+def heavy_tailed_rows(M, C, seed=0, outlier_frac=0.02, outlier_gain=(30.0, 100.0), mean_sigma=20.0):
+    """Activation rows with the statistics real SD-v2 residual streams show and the seeded N(0, 1/fan_in) weights above
+    never produce: 1-2 % outlier channels at 30-100x, row means up to ``mean_sigma`` standard
+    deviations.  Used by the parity stress tests of the fusions that cancel large numbers (the folded LayerNorm) or
+    approximate on a bounded interval (the polynomial GELU)."""
+    g = torch.Generator("cpu").manual_seed(seed)
+    x = torch.randn(M, C, generator=g)
+    n_out = max(1, int(round(outlier_frac * C)))
+    idx = torch.randperm(C, generator=g)[:n_out]
+    gain = outlier_gain[0] + (outlier_gain[1] - outlier_gain[0]) * torch.rand(n_out, generator=g)
+    x[:, idx] *= gain
+    x += mean_sigma * (torch.rand(M, 1, generator=g) * 2 - 1)
+    return x
+
+
+def heavy_tailed_affine(C, seed=0, n_large=4, gain=8.0):
+    """LayerNorm / GroupNorm (gamma, beta) with a few large entries."""
+    g = torch.Generator("cpu").manual_seed(seed + 1)
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    idx = torch.randperm(C, generator=g)[:n_large]
+    gamma[idx] *= gain
+    beta[idx] *= gain
+    return gamma, beta

@@ -99,7 +99,11 @@ def fold_layernorm(w, bias, gamma, beta):
     """LayerNorm folded into the Linear layer that consumes it (MG_OP_IGEMM ln_in): y = LN(x) W^T + b
     = rstd * (x (W gamma)^T - mean * g) + c  with  g[n] = sum_k (W gamma)[n][k],  c[n] = sum_k beta[k] W[n][k] + b[n].
     ``w`` [N][K] fp32 (rows already in the kernel's order), ``bias`` [N] | None.  Returns (W gamma as bf16, g, c); g sums
-    the ROUNDED weights, so a constant row x = a gives exactly c (the kernel's x (W gamma)^T - mean g cancels)."""
+    the ROUNDED weights, so for a row x = a (constant) the product x (W gamma)^T cancels against mean g up to the row
+    statistics' own rounding: (mean, rstd) are taken by the PRODUCING GEMM's epilogue from its fp32 values BEFORE they are
+    rounded to the bf16 row the consumer reads (igemm2_body.h, ln_out), i.e. they are the statistics of x, not of bf16(x) -
+    a deviation of <= 2^-9 |x| per element from LayerNorm(bf16(x)), below the bf16 resolution of the output (measured:
+    tests/test_gpu_kernels.py::test_igemm_layernorm_fold, heavy-tailed rows included)."""
     wp = (w.double() * gamma.double()[None, :]).float().to(torch.bfloat16)
     g = wp.double().sum(dim=1).float()
     c = w.double() @ beta.double()

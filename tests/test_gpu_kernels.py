@@ -511,6 +511,154 @@ def test_igemm_layernorm_fold(dev):
     _close("ln_fold/qkv/vt_perm", vt2[:, :, :T2], ops.permute_vt_keys(refq[:T2, 2 * C:].reshape(1, T2, C).permute(0, 2, 1).contiguous()), tol=2e-2)
 
 
+def test_layernorm_fold_heavy_tailed(dev):
+    """The folded LayerNorm  rstd (acc - mean g[n]) + c[n]  cancels two large numbers when |mean| / std >> 1, and real
+    SD-v2 residual streams have outlier channels and row means the synthetic weights never produce.  Rows with 2 % outlier
+    channels at 30-100x, row means up to 20 sigma, gamma / beta with large entries, GEGLU gate pre-activations out to
+    +-12: the fold against fp32 torch AND against the unfused device chain (MG_OP_LAYERNORM -> Linear, the
+    MARIGOLD_FOLD_LN=0 path), bf16 / GEGLU / pair-softmax-blend / transposed epilogues.  Bound: the fold may lose at
+    most 2x against the unfused chain (else the operand needs centring)."""
+    from marigold_amd import _lib as L, ops, synthetic as syn, weights as Wm
+    M, C = 704, 320
+    x = _bf(syn.heavy_tailed_rows(M, C, seed=3))
+    gamma, beta = syn.heavy_tailed_affine(C, seed=3)
+    y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    xd = x.to(dev, torch.bfloat16)
+    stx = torch.stack([x.mean(-1), 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5)], dim=-1).to(dev).contiguous()
+    yd = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+    _run(ops.layernorm(xd, gamma.to(dev), beta.to(dev), yd, M=M, C=C))   # the unfused chain's normalised rows
+    g = torch.Generator().manual_seed(31)
+
+    def rel(a, b):
+        a, b = a.float().cpu(), b.float().cpu()
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-9))
+
+    print(f"[stress] rows: |mean|/std up to {float((x.mean(-1).abs() / x.std(-1)).max()):.1f}, max |x| {float(x.abs().max()):.0f}")
+    # --- bf16 epilogue
+    N = 640
+    w = torch.randn(N, C, generator=g) / math.sqrt(C)
+    b = torch.randn(N, generator=g) * 0.1
+    ref = y @ w.t() + b
+    wp, gv, cv = Wm.fold_layernorm(w, b, gamma, beta)
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    _run(ops.linear(xd, wp.to(dev), out, M=M, K=C, N=N, ln_in=stx, ln_g=gv.to(dev), ln_c=cv.to(dev)))
+    unf = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    _run(ops.linear(yd, w.to(dev, torch.bfloat16), unf, M=M, K=C, N=N, bias=b.to(dev)))
+    e_f, e_u = rel(out, ref), rel(unf, ref)
+    print(f"[stress] ln_fold/bf16: fold {e_f:.3e}  unfused {e_u:.3e}  (relative to max|ref| {float(ref.abs().max()):.1f})")
+    assert e_f <= max(2 * e_u, 1.5e-2)
+    # --- GEGLU with gate pre-activations out to +-12 (the polynomial CDF is clamped at |x| = 4)
+    wg = torch.randn(8 * C, C, generator=g) / math.sqrt(C)
+    wg[4 * C:] *= 12.0 / float((y @ wg[4 * C:].t()).abs().max())
+    bg = torch.randn(8 * C, generator=g) * 0.1
+    u, gt = (y @ wg.t() + bg).chunk(2, dim=-1)
+    refg = u * F.gelu(gt)
+    wpk, bpk = Wm.pack_geglu(wg, bg)
+    wpg, gg, cg = Wm.fold_layernorm(wpk, bpk, gamma, beta)
+    og = torch.empty(M, 4 * C, device=dev, dtype=torch.bfloat16)
+    _run(ops.linear(xd, wpg.to(dev), og, M=M, K=C, N=8 * C, epi=L.EPI_GEGLU, ln_in=stx, ln_g=gg.to(dev), ln_c=cg.to(dev)))
+    ug = torch.empty(M, 4 * C, device=dev, dtype=torch.bfloat16)
+    _run(ops.linear(yd, wpk.to(dev, torch.bfloat16), ug, M=M, K=C, N=8 * C, bias=bpk.to(dev), epi=L.EPI_GEGLU))
+    e_f, e_u = rel(og, refg), rel(ug, refg)
+    print(f"[stress] ln_fold/geglu (gate range +-{float(gt.abs().max()):.1f}): fold {e_f:.3e}  unfused {e_u:.3e}")
+    assert e_f <= max(2 * e_u, 2e-2)
+    # --- transposed (V^T) section of the fused QKV projection
+    wq = torch.randn(3 * C, C, generator=g) / math.sqrt(C)
+    wpq, gq, cq = Wm.fold_layernorm(wq, None, gamma, beta)
+    refq = y @ wq.t()
+    qk = torch.empty(M, 2 * C, device=dev, dtype=torch.bfloat16)
+    vt = torch.zeros(1, C, M, device=dev, dtype=torch.bfloat16)
+    _run(ops.igemm(xd, wpq.to(dev), qk, B=1, H=M, W=1, Cin=C, Ho=M, Wo=1, N=3 * C, ldo=2 * C, out2=vt, trans_from=2 * C, ldt=M,
+                   ln_in=stx, ln_g=gq.to(dev), ln_c=cq.to(dev)))
+    e_q, e_v = rel(qk, refq[:, :2 * C]), rel(vt[0], refq[:, 2 * C:].t())
+    print(f"[stress] ln_fold/qkv: qk {e_q:.3e}  vt {e_v:.3e}")
+    assert e_q <= 2e-2 and e_v <= 2e-2
+    # --- the collapsed cross-attention in one launch (scores with the fold -> pair softmax -> blend + residual, in place)
+    heads = C // 64
+    ctx = torch.randn(2, 64, generator=g)
+    wq2, wk2, wv2, wo2 = (torch.randn(C, C, generator=g) / math.sqrt(C), torch.randn(C, 64, generator=g) / 8,
+                          torch.randn(C, 64, generator=g) / 8, torch.randn(C, C, generator=g) / math.sqrt(C))
+    bo = torch.randn(C, generator=g) * 0.1
+    wqk, vot, npad = Wm.cross_attention_tables(wq2, wk2, wv2, wo2, ctx, heads)
+    wpx, gx, cx = Wm.fold_layernorm(wqk, None, gamma, beta)
+    sc = (y @ wqk.t())[:, :2 * heads].reshape(M, heads, 2) / math.sqrt(C // heads)
+    pr = torch.softmax(sc, dim=-1).reshape(M, 2 * heads)
+    refx = x + pr @ vot[:, :2 * heads].t() + bo
+    h = xd.clone()
+    _run(ops.linear(h, wpx.to(dev), h, M=M, K=C, N=npad, epi=L.EPI_XATTN2, ln_in=stx, ln_g=gx.to(dev), ln_c=cx.to(dev),
+                    sm_scale=1.0 / math.sqrt(C // heads), sm_cols=2 * heads, out2=vot.to(dev, torch.bfloat16), c2=C, ldo=C,
+                    bias=bo.to(dev), residual=h, ldr=C))
+    e_x = rel(h, refx)
+    print(f"[stress] ln_fold/xattn2: {e_x:.3e}")
+    assert e_x <= 1.5e-2
+
+
+def test_conv3x3_patch_fused_norm_heavy_tailed(dev):
+    """The in-LDS GroupNorm fix-up of the patch convolution rounds silu(x scale + shift) to bf16 before the MFMAs, as the
+    stand-alone pass does: with outlier channels (x50) and scales up to x30 the fused kernel must still agree with the
+    unfused chain to one bf16 step of the result, and with fp32 torch within the bf16 bound."""
+    from marigold_amd import ops, synthetic as syn, weights as Wm
+    B, H, W, Cin, N = 2, 32, 32, 320, 320
+    g = torch.Generator().manual_seed(17)
+    x = _bf(syn.heavy_tailed_rows(B * H * W, Cin, seed=9, mean_sigma=3.0).reshape(B, H, W, Cin))
+    gamma, beta = syn.heavy_tailed_affine(Cin, seed=9, gain=30.0)
+    xg = x.permute(0, 3, 1, 2).reshape(B, 32, -1)
+    mean, rstd = xg.mean(-1), (xg.var(-1, unbiased=False) + 1e-5).rsqrt()
+    sc = rstd.repeat_interleave(Cin // 32, 1) * gamma
+    sh = beta - mean.repeat_interleave(Cin // 32, 1) * sc
+    ss = torch.stack([sc, sh], dim=1).contiguous()
+    w4 = _bf(torch.randn(N, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = _ref_fused_conv(x.permute(0, 3, 1, 2), w4, bias, ss, True, None, None)
+    xd, ssd, wd, bd = x.to(dev, torch.bfloat16), ss.to(dev), Wm.pack_conv3x3(w4).to(dev, torch.bfloat16), bias.to(dev)
+    out = torch.empty(B, H, W, N, device=dev, dtype=torch.bfloat16)
+    _run(ops.conv3x3(xd, wd, out, B=B, H=H, W=W, C0=Cin, N=N, ss=ssd, silu=True, bias=bd))
+    hh = torch.empty(B, H, W, Cin, device=dev, dtype=torch.bfloat16)
+    _run(ops.gn_apply(xd, ssd, hh, B=B, HW=H * W, C=Cin, silu=True))
+    unf = torch.empty_like(out)
+    _run(ops.igemm(hh, wd, unf, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, N=N, taps=9, stride=1, pad=1, bias=bd))
+    scale = ref.abs().max().item()
+    d_fu = (out.float() - unf.float()).abs().max().item()
+    print(f"[stress] fused conv3x3p vs unfused chain: max|diff| {d_fu:.3e} (scale {scale:.1f}); normalised input up to "
+          f"{float(F.silu(x * sc[:, None, None, :] + sh[:, None, None, :]).abs().max()):.0f}")
+    assert d_fu <= scale / 128
+    _close("conv3x3p/heavy-tailed vs fp32", out.float().permute(0, 3, 1, 2), ref)
+
+
+def test_conv_patch_and_flash_bit_stable_at_scale(dev):
+    """Repeat-launch bit stability at benchmark scale for the two other kernels that regroup accumulators with
+    v_permlane32_swap (the packed-fp32 build that differed from run to run in round 2 was only ever stressed on igemm2):
+    the level-0 ResNet convolution with the fused GroupNorm fix-up (10 x 96 x 96, 320 -> 320) and the level-0 self-attention
+    (10 x 5 heads x 9216 tokens), six launches each."""
+    from marigold_amd import ops, weights as Wm
+    g = torch.Generator().manual_seed(8)
+    B, H, W, C = 10, 96, 96, 320
+    x = torch.randn(B, H, W, C, generator=g).to(dev, torch.bfloat16)
+    w = Wm.pack_conv3x3(torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(dev, torch.bfloat16)
+    ss = torch.stack([1.0 + 0.3 * torch.randn(B, C, generator=g), 0.3 * torch.randn(B, C, generator=g)], dim=1).to(dev).contiguous()
+    bias = (torch.randn(C, generator=g) * 0.1).to(dev)
+    res = torch.randn(B, H, W, C, generator=g).to(dev, torch.bfloat16)
+    first = None
+    for _ in range(6):
+        out = torch.full((B, H, W, C), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.conv3x3(x, w, out, B=B, H=H, W=W, C0=C, N=C, ss=ss, silu=True, bias=bias, residual=res))
+        if first is None:
+            first = out.clone()
+        assert torch.equal(first, out), "conv_patch: launches differ"
+    heads, T = 5, 9216
+    qkv = torch.randn(B, T, 3 * C, generator=g).to(dev, torch.bfloat16)
+    vt = ops.permute_vt_keys(qkv[:, :, 2 * C:].permute(0, 2, 1).contiguous())
+    first = None
+    for _ in range(6):
+        out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.flash_attn64(qkv, qkv[:, :, C:], vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=T,
+                              sq=T * 3 * C, sk=T * 3 * C, svt=C * T, so=T * C, scale=0.125, vt_perm=True))
+        if first is None:
+            first = out.clone()
+        assert torch.equal(first, out), "flash_attn64: launches differ"
+    assert torch.isfinite(first.float()).all()
+
+
 def test_igemm_row_statistics_bit_stable_at_scale(dev):
     """In-place Linear + residual with row statistics at benchmark sizes, on the tiles that share a CU between two
     workgroups: every launch must give the same bits (outputs and (mean, rstd)), and the statistics must match fp32.

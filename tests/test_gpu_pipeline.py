@@ -214,6 +214,33 @@ def test_pipeline_call_depth_ensemble(tiny):
     assert out2.depth_np.shape == (64, 128)
 
 
+def test_pipeline_image_size_not_a_multiple_of_8(tiny):
+    """KITTI (script/depth/eval/21_infer_kitti.sh): 1242 x 375 -> processing_res 768 -> 768 x 231, which the VAE's three
+    stride-2 convolutions take to a 96 x 28 latent and the decoder back to 768 x 224 - smaller than the image.  Here at
+    half that size (384 x 116 -> latent 48 x 14 -> decoded 384 x 112): members against the oracle at the decoded size,
+    then the public call returns the map at the input size (reference :318-325 resizes it back)."""
+    from marigold_amd import schedulers as S, synthetic as syn
+    from oracle import metrics as omet, pipeline as opipe
+    from oracle.schedulers import DDIMScheduler as ODDIM
+    H, W = 116, 384
+    img = syn.synthetic_image(H, W, seed=3)
+    g = torch.Generator().manual_seed(11)
+    lat0 = torch.randn(2, 4, 14, 48, generator=g)
+    pipe = _engine_pipe(tiny, "depth", S.DDIMScheduler())
+    out = pipe(img, denoising_steps=2, ensemble_size=2, processing_res=0, match_input_res=False, color_map=None,
+               show_progress_bar=False, init_latents=lat0)
+    assert out.depth_np.shape == (112, 384)
+    ref, _, preds = opipe.predict("depth", tiny["ounet"], tiny["ovae"], ODDIM(), img, lat0, tiny["ctx"], 2)
+    assert tuple(preds.shape[-2:]) == (112, 384)
+    m = omet.affine_invariant_depth_errors(ref.squeeze().numpy(), out.depth_np)
+    print(f"[parity] pipeline depth at 116 x 384 (decoded 112 x 384) vs oracle: {m}")
+    assert m["rmse"] < 3e-2 and m["delta1"] > 0.97
+    out2 = pipe(img, denoising_steps=1, ensemble_size=1, processing_res=0, match_input_res=True, color_map="Spectral",
+                show_progress_bar=False, init_latents=lat0[:1])
+    assert out2.depth_np.shape == (H, W) and out2.depth_colored.size == (W, H)
+    assert np.isfinite(out2.depth_np).all() and out2.depth_np.min() >= 0 and out2.depth_np.max() <= 1
+
+
 def test_pipeline_call_normals_ensemble(tiny):
     from marigold_amd import schedulers as S
     from oracle import metrics as omet, pipeline as opipe
@@ -322,6 +349,44 @@ def test_graph_capture_matches_eager(tiny):
     assert torch.equal(prog.x, ref)
 
 
+def test_ensembles_above_32_members():
+    """More members than the register-resident selection holds (33 ... 128 run the LDS form; the reference accepts any
+    size, script/depth/run.py:143-144): the per-pixel passes against the oracle's torch restatement, the whole
+    ensemble_depth against the stand-in backend that drives the same optimiser on the CPU."""
+    import scipy.optimize
+    from marigold_amd import ensemble as ens
+    from oracle import ensemble as oens
+    from tests.cpu_backend import TorchStatsBackend
+    g = torch.Generator().manual_seed(40)
+    E, H, W = 40, 48, 64
+    base = torch.rand(1, 1, H, W, generator=g)
+    x = (base * (0.5 + torch.rand(E, 1, 1, 1, generator=g)) + 0.2 * torch.rand(E, 1, 1, 1, generator=g)
+         + 0.02 * torch.randn(E, 1, H, W, generator=g)).clamp_min(1e-3)
+    # un-aligned median / MAD and mean / std over 40 and 100 members (ensemble_iid = the fused kernel without alignment)
+    for n in (40, 100):
+        t = torch.rand(n, 3, 16, 24, generator=g)
+        for red in ("median", "mean"):
+            p, u = ens.ensemble_iid(t.cuda(), output_uncertainty=True, reduction=red)
+            rp, ru = oens.ensemble_iid(t, output_uncertainty=True, reduction=red)
+            assert torch.allclose(p.cpu(), rp, atol=2e-6), (n, red)
+            assert torch.allclose(u.cpu(), ru, atol=2e-6), (n, red)
+    d, u, info = ens.ensemble_depth(x.cuda(), True, True, output_uncertainty=True, return_info=True)
+    al = ens.DepthAligner(x.float(), True, True, "median", 0.02, backend=TorchStatsBackend(x, 0, True))
+    res = scipy.optimize.minimize(al.reference_fd_objective, al.init_param(), jac=True, method="BFGS", tol=1e-6,
+                                  options={"maxiter": 50})
+    np.testing.assert_allclose(info["param"], res.x, rtol=0, atol=2e-4)
+    # the oracle's align -> median / MAD -> normalise with the device's parameters
+    a = oens.depth_align(x.float(), info["param"], True, True)
+    ref, ref_u = oens.depth_reduce(a, "median", True)
+    lo, hi = ref.min(), ref.max()
+    ref, ref_u = (ref - lo) / (hi - lo).clamp(min=1e-6), ref_u / (hi - lo).clamp(min=1e-6)
+    assert (d.cpu() - ref).abs().max() < 1e-5 and (u.cpu() - ref_u).abs().max() < 1e-5
+    nrm = torch.nn.functional.normalize(torch.randn(40, 3, 16, 16, generator=g), dim=1)
+    o, un = ens.ensemble_normals(nrm.cuda(), output_uncertainty=True)
+    ro, ru = oens.ensemble_normals(nrm, output_uncertainty=True)
+    assert (o.cpu() - ro).abs().max() < 1e-5 and (un.cpu() - ru).abs().max() < 1e-5
+
+
 def test_ensemble_depth_metric_config_vs_reference(golden_dir):
     """A11 at the metric configuration: E = 10 members at 768 x 768 against the output of the REFERENCE's own
     ensemble_depth on the same (seeded, regenerated) members (tests/golden/ensemble_ref_768.npz, 92 s of CPU there).
@@ -356,7 +421,7 @@ def test_ensemble_depth_metric_config_vs_reference(golden_dir):
     assert du.max() < 5e-2
 
 
-def _mp_worker(rank, world, port, q):
+def _mp_worker(rank, world, port, q, hw=(64, 128)):
     """One rank of the member-parallel pipeline; both ranks share cuda:0 and meet over gloo (RCCL cannot
     put two ranks on one device - the collective is what differs from the 8-GPU run, the sharding,
     noise slicing and gather ordering are the code under test)."""
@@ -369,7 +434,7 @@ def _mp_worker(rank, world, port, q):
     from marigold_amd.arch import TINY_UNET, TINY_VAE
     pipe = M.build_synthetic_pipeline("depth", TINY_UNET, TINY_VAE, default_processing_resolution=0).to("cuda:0")
     pipe.enable_member_parallel(root=0)
-    img = syn.synthetic_image(64, 128, seed=0)
+    img = syn.synthetic_image(hw[0], hw[1], seed=0)
     g = torch.Generator(device="cuda:0").manual_seed(5)
     out = pipe(img, denoising_steps=2, ensemble_size=3, processing_res=0, color_map=None, show_progress_bar=False,
                generator=g)
@@ -381,9 +446,12 @@ def _mp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_member_parallel_two_ranks_share_one_gpu():
+@pytest.mark.parametrize("hw", [(64, 128), (116, 384)], ids=["64x128", "116x384_not_multiple_of_8"])
+def test_member_parallel_two_ranks_share_one_gpu(hw):
     """E=3 members sharded over 2 processes (member e -> rank e % 2), ONE gather, aggregation on rank 0:
-    same map as the single-process run with the same generator seed."""
+    same map as the single-process run with the same generator seed.  The second size is KITTI's aspect after the
+    768-pixel resize, halved (script/depth/eval/21_infer_kitti.sh: 1242x375 -> 768x231): the decoded maps (112 x 384) are
+    smaller than the image, the gather buffer is sized from the latent, the result is resized back to 116 x 384."""
     import socket
     import torch.multiprocessing as mp
     import marigold_amd as M
@@ -396,7 +464,7 @@ def test_member_parallel_two_ranks_share_one_gpu():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_mp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_mp_worker, args=(r, 2, port, q, hw)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=180)
@@ -405,8 +473,9 @@ def test_member_parallel_two_ranks_share_one_gpu():
         assert p.exitcode == 0
     pipe = M.build_synthetic_pipeline("depth", TINY_UNET, TINY_VAE, default_processing_resolution=0).to("cuda:0")
     g = torch.Generator(device="cuda:0").manual_seed(5)
-    ref = pipe(syn.synthetic_image(64, 128, seed=0), denoising_steps=2, ensemble_size=3, processing_res=0,
+    ref = pipe(syn.synthetic_image(hw[0], hw[1], seed=0), denoising_steps=2, ensemble_size=3, processing_res=0,
                color_map=None, show_progress_bar=False, generator=g).depth_np
+    assert got.shape == tuple(hw) and ref.shape == tuple(hw)
     m = omet.affine_invariant_depth_errors(ref, got)
     print(f"[parity] 2-rank member-parallel vs single process: max|diff| {np.abs(ref - got).max():.2e} {m}")
     assert np.abs(ref - got).max() < 2e-2 and m["rmse"] < 5e-3

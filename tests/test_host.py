@@ -201,11 +201,12 @@ def test_ensemble_argument_validation_without_gpu():
         ens.ensemble_normals(torch.rand(3, 2, 8, 8))
     with pytest.raises(ValueError):
         ens.ensemble_normals(torch.rand(3, 3, 8, 8), reduction="median")
-    # the device kernels hold <= 32 members in registers: larger ensembles are refused by name
-    with pytest.raises(ValueError, match="exceeds the 32 members"):
-        ens.ensemble_depth(torch.rand(33, 1, 8, 8), True, True)
-    with pytest.raises(ValueError, match="exceeds the 32 members"):
-        ens.ensemble_normals(torch.rand(40, 3, 8, 8))
+    # the depth / IID order statistics hold <= 128 members (registers up to 32, LDS beyond): larger ensembles are refused
+    # by name, after the shape checks; ensemble_normals has no limit
+    with pytest.raises(ValueError, match="exceeds the 128 members"):
+        ens.ensemble_depth(torch.rand(129, 1, 8, 8), True, True)
+    with pytest.raises(ValueError, match="Expecting 4D tensor"):
+        ens.ensemble_depth(torch.rand(200, 8, 8), True, True)
 
 
 def _gloo_worker(rank, world, port, E, q):
