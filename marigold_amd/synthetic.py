@@ -35,8 +35,29 @@ def synthetic_state_dict(shapes, seed):
     return {k: _draw(k, tuple(s), seed) for k, s in shapes.items()}
 
 
-def synthetic_unet_state_dict(cfg: UNetConfig = UNetConfig(), seed: int = 1234):
-    return synthetic_state_dict(unet_param_shapes(cfg), seed)
+_STREAM_WRITERS = ("proj_in.weight", "attn1.to_out.0.weight", "attn2.to_out.0.weight", "ff.net.2.weight")
+
+
+def plant_heavy_tails(sd, seed=1234, outlier_frac=0.02, outlier_gain=30.0, affine_gain=8.0, gate_gain=4.0):
+    """SD-like activation statistics for the parity stress run (in place, deterministic per key): the layers
+    that WRITE the transformer residual stream get 2 % of their output channels at ``outlier_gain`` x (outlier channels,
+    |mean| / std >> 1 on the rows the folded LayerNorm cancels), every LayerNorm / GroupNorm gamma and beta a few entries
+    at ``affine_gain`` x, and the GEGLU gate rows ``gate_gain`` x (pre-activations beyond the polynomial CDF's +-4)."""
+    for key, t in sd.items():
+        g = torch.Generator("cpu").manual_seed((zlib.crc32(key.encode()) ^ (seed * 40503) ^ 0x5BD1E995) & 0x7FFFFFFF)
+        if key.endswith(_STREAM_WRITERS):
+            n = max(2, int(round(outlier_frac * t.shape[0])))
+            t[torch.randperm(t.shape[0], generator=g)[:n]] *= outlier_gain
+        elif ("norm" in key) and t.dim() == 1:
+            t[torch.randperm(t.shape[0], generator=g)[:4]] *= affine_gain
+        elif key.endswith("ff.net.0.proj.weight"):
+            t[t.shape[0] // 2:] *= gate_gain
+    return sd
+
+
+def synthetic_unet_state_dict(cfg: UNetConfig = UNetConfig(), seed: int = 1234, heavy_tail: bool = False):
+    sd = synthetic_state_dict(unet_param_shapes(cfg), seed)
+    return plant_heavy_tails(sd, seed) if heavy_tail else sd
 
 
 def synthetic_vae_state_dict(cfg: VAEConfig = VAEConfig(), seed: int = 1234):

@@ -41,6 +41,41 @@ sys.path.insert(0, ROOT)
 IMG_SEED, LAT_SEED, LCM_NOISE_SEED, MEMBERS = 0, 7, 99, 4
 
 
+def main_heavy():
+    """C2 once more on weights with SD-like activation statistics planted (synthetic.plant_heavy_tails: outlier channels in
+    the residual stream, large norm gains, GEGLU gates beyond +-4): member 0, DDIM T = 10, latent after every step and the
+    depth map -> tests/golden/fullsize_768_heavy.npz (about 4 minutes on 8 cores)."""
+    from marigold_amd import synthetic as syn
+    from oracle import pipeline as opipe
+    from oracle.schedulers import DDIMScheduler
+    from oracle.sd2_unet import UNet2DConditionModel
+    from oracle.sd2_vae import AutoencoderKL
+
+    torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", "8")))
+    t0 = time.time()
+    unet = UNet2DConditionModel().eval()
+    unet.load_state_dict(syn.synthetic_unet_state_dict(heavy_tail=True))
+    vae = AutoencoderKL().eval()
+    vae.load_state_dict(syn.synthetic_vae_state_dict())
+    ctx = syn.synthetic_text_embedding()
+    rgb = syn.synthetic_image(768, 768, seed=IMG_SEED).float() / 255.0 * 2.0 - 1.0
+    lat0 = syn.synthetic_latents(MEMBERS, 96, 96, seed=LAT_SEED)
+    out = {}
+    with torch.no_grad():
+        rgb_latent = opipe.encode_rgb(vae, rgb)
+        tr = []
+        x0 = opipe.denoise(unet, DDIMScheduler(), rgb_latent, lat0[:1], ctx, 10, trace=tr)
+        out["ddim10_trace_m0"] = np.concatenate([t[2].numpy() for t in tr])
+        print(f"[{time.time() - t0:7.1f}s] denoise done; |latent| rms per step "
+              + " ".join(f"{float((t[2] ** 2).mean().sqrt()):.3f}" for t in tr), flush=True)
+        d = opipe.decode_latent(vae, x0).mean(dim=1, keepdim=True)
+        out["ddim10_depth_m0"] = ((torch.clip(d, -1.0, 1.0) + 1.0) / 2.0)[0, 0].numpy().astype(np.float16)
+    path = os.path.join(GOLD, "fullsize_768_heavy.npz")
+    np.savez_compressed(path, **out)
+    print("fullsize_768_heavy.npz:", {k: (v.shape, str(v.dtype)) for k, v in out.items()}, os.path.getsize(path) >> 10, "KiB",
+          f"{time.time() - t0:.0f}s")
+
+
 def main():
     from marigold_amd import synthetic as syn
     from oracle import ensemble as oens, pipeline as opipe
@@ -106,4 +141,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main_heavy() if "--heavy" in sys.argv else main()
