@@ -83,6 +83,19 @@ enum mg_op_kind {
    *  i: B, HW, C, C0 (with x1), groups, silu ; f[0] eps.  The normalised form keeps the rows in registers: H x W x window
    *  <= 48 rows per thread of a 1024-thread workgroup (the UNet's 96^2 ... 12^2 levels at any width). */
   MG_OP_GN_SLAB = 9,
+  /* Row-resident GEMM for the token-local Linear layers at K = 320 (the widest transformer level): out[M][N] =
+   * epilogue(x[M][K] W[N][K]^T).  A wave keeps 32 whole rows of x in registers for the launch and the weights stream past
+   * it in 64-column stages, pre-packed in MFMA fragment order with a per-stage trailer of per-channel constants
+   * (marigold_amd/weights.py::pack_rowgemm; csrc/rowgemm.hip).  M % 32 == 0, N % 64 == 0, N >= 128.
+   *  p[0] x bf16 [M][ldx]  p[1] packed weights  p[2] out bf16 [M][ldo]  p[3] residual bf16 [M][ldr] | NULL (may alias out)
+   *  p[4] (mean, rstd) f32 [M][2] of the rows of x | NULL: LayerNorm folded (the packed trailer holds its g and c vectors)
+   *  p[5] (mean, rstd) f32 [M][2] of the OUTPUT rows | NULL  p[6] V^T bf16 [B][N - i[9]][ldt] (QKV form)
+   *  p[7] GroupNorm scale/shift f32 [B][2][K] | NULL: x is normalised while it is loaded (bf16(x * scale + shift))
+   *  i: M, K, N, ldx, ldo, ldr, form (0 bias [+ residual] [+ row statistics], 1 GEGLU: stage = 32 value + 32 gate
+   *  channels, out [M][N/2], 2 QKV: columns >= i[9] go to V^T in MG_OP_FLASH_ATTN64's permuted key order), i[7] tokens per
+   *  image (forms with p[6] / p[7]; % 32 == 0), i[8] ldt, i[9] first V column (% 64 == 0), i[10] waves per workgroup
+   *  (0 = 12; 4 / 8 / 12) ; f[0] LayerNorm eps of p[5]. */
+  MG_OP_ROWGEMM = 10,
   /* LayerNorm over the last dim. p[0] x bf16 [M][C] p[1] gamma f32 p[2] beta f32 p[3] out;
    * i: M,C ; f[0] eps */
   MG_OP_LAYERNORM = 5,

@@ -1,0 +1,380 @@
+// MG_OP_ROWGEMM: row-resident GEMM for the token-local Linear layers of the widest transformer level (gfx950 only).
+//
+//   out[M][N] = epilogue( x[M][K] W[N][K]^T ),  K = 320 (the 96 x 96-token level of the SD2 UNet), M = B * tokens = 92 160
+//
+// Why a second GEMM kernel.  At K = 320 the tile GEMM (igemm2) is neither MFMA- nor HBM-bound: a 128 x 320 output tile
+// re-stages the whole 200 KB weight matrix and its 80 KB of rows through LDS for five K steps of work, then stalls on its
+// own epilogue - 46 us for 118 MB (profiles/r2_trans_section_probe.log), 176 us for the fused QKV projection in the
+// pipeline, against ~50 us of HBM time.  Here the roles are turned round:
+//   * a WAVE owns 32 whole rows of x for the entire launch: their K = 320 values are loaded ONCE, straight into the 80
+//     VGPRs the MFMAs read them from (no LDS pass, no re-read per column tile);
+//   * the WEIGHTS stream: all waves of the workgroup (12 = three per SIMD, 384 rows) walk the N columns in 64-column
+//     stages; a stage is 40 KB of weights pre-packed on the host in MFMA FRAGMENT order (weights.pack_rowgemm), so one
+//     `global_load_lds_dwordx4` moves one fragment (1 KB, contiguous in memory AND in LDS - conflict-free `ds_read_b128`
+//     at immediate offsets from a single address register, no swizzle, no index arithmetic), three stages deep;
+//   * a stage's 32 x 64 outputs are finished in registers (folded LayerNorm, bias, residual, GEGLU, V^T) and stored
+//     while the other two waves of the SIMD keep its matrix pipe busy; row statistics for the next folded LayerNorm
+//     fall out per wave (it holds whole rows) - no tickets, no second pass.
+// 240 workgroups x 12 waves = one round over the chip for E = 10; the weights are read from L2 once per workgroup
+// (614 KB for QKV), x from HBM exactly once.
+//
+// K order.  Lane (row r = lane % 32, half h = lane / 32) holds x[r][160 h + 8 s .. + 8] as the operand of K step s: a
+// permutation of the reduction index, applied identically to the packed weights - each lane reads 320 contiguous bytes.
+// Channel order inside a 32-channel tile: MFMA row index mm holds channel chan(mm) = mm with bits 2 and 3 exchanged, so
+// that a lane's accumulator registers 0-7 / 8-15 are channels 8h .. 8h+7 / 16+8h .. 16+8h+7 - 16-byte stores with no
+// lane exchange.  In the V^T section of the QKV projection the operand roles are swapped (x fragment as MFMA A, weights
+// as B - the register images are the same) and the accumulator then holds, per channel, tokens {4h..4h+3, 8+4h..} - the
+// key order MG_OP_FLASH_ATTN64 i[7] consumes (engine.FLASH_VT_PERM), again 16-byte stores.
+//
+// Synchronisation: one s_barrier per stage.  A wave waits for its OWN LDS-DMA pieces of stage j with a counted vmcnt
+// before barrier j; vmcnt retires in order on gfx9 and counts stores, so the wait leaves exactly the younger operations in
+// flight: this wave's pieces of stage j+1 (>= 3) and the S stores of the previous stage's epilogue.  Every wave issues
+// every store unconditionally (rows past M do not exist: M % 32 == 0 is required and a surplus wave recomputes the last
+// row tile - identical bytes to identical addresses), so S is a compile-time constant.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct RgArgs {
+  const bf16_t* x;      // [M][ldx]
+  const char* wp;       // packed weights: N/64 stages x (2 tiles x K/16 fragments of 1 KB + 1 KB trailer: fp32 [64] per-channel
+                        // constants (bias + folded-LayerNorm c), [64] folded-LayerNorm g) - weights.pack_rowgemm
+  bf16_t* out;          // [M][ldo]
+  bf16_t* vt;           // QKV: V^T [B][N - trans_from][ldt]
+  const bf16_t* res;    // [M][ldr] | NULL
+  const float2* ln_in;  // [M] (mean, rstd)
+  float2* ln_out;       // [M] | NULL
+  const float* gn_ss;   // [B][2][K] GroupNorm (scale, shift) applied to x while it is loaded | NULL
+  int M, N, ldx, ldo, ldr, ldt, T, trans_stage;
+  float ln_eps;
+  double inv_n;
+  int gelu_erf;
+};
+
+enum { RG_BF16 = 0, RG_GEGLU = 1, RG_QKV = 2 };
+
+// The stage trailer (per-channel constants) is read with hand-placed LDS instructions: hipcc's waitcnt pass makes every LDS
+// load it can see wait for ALL outstanding LDS-DMA (vmcnt(0)) - in the middle of the stage that would drain the weight
+// prefetch.  The fragment reads escape that only because they carry no memory operand after unrolling; these would not.
+template <int OFF>
+__device__ __forceinline__ f32x4 rg_lds16(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ float rg_lds4(uint32_t addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// all LDS reads of this wave have landed; the operands tie the consumers behind the wait
+__device__ __forceinline__ void rg_lgk0(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void rg_lgk0(float& a, float& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+
+template <int N>
+__device__ __forceinline__ void rg_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int K, int NW, int EPI, bool LN, bool GN, bool RES, bool LNO>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
+void rowgemm_kernel(const RgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // a stage = 2 tiles x KS fragments of 1 KB + one 1 KB trailer: fp32 [64] per-channel constants, [64] folded-LayerNorm g
+  constexpr int KS = K / 16, KH = K / 2, PIECES = 2 * KS + 1, STAGE = PIECES * 1024, NSTAGE = 3, TRL = 2 * KS * 1024;
+  constexpr int NWMIN = PIECES / NW, NWREM = PIECES - NWMIN * NW;   // LDS-DMA pieces per wave and stage: NWMIN (+1 for waves < NWREM)
+  constexpr int S = (EPI == RG_GEGLU) ? 2 : 4;             // stores per stage epilogue
+  constexpr int XW = NWMIN + S + (RES ? 4 : 0);            // operations younger than stage j's pieces that may stay in flight
+  static_assert(K % 32 == 0 && NWMIN >= 1, "geometry");
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  int row0 = blockIdx.x * (NW * 32) + wave * 32;
+  if (row0 >= a.M) row0 = a.M - 32;                        // surplus wave: recompute the last tile (identical stores)
+  const int m = row0 + l31;
+  const int nst = a.N >> 6;
+
+  auto issue = [&](int j, int slot) {
+    const char* src = a.wp + (long long)j * STAGE + lane * 16;
+    char* dst = smem + slot * STAGE;
+#pragma unroll
+    for (int i = 0; i < NWMIN; ++i) glds16(src + (wave + i * NW) * 1024, dst + (wave + i * NW) * 1024);
+    if (wave < NWREM) glds16(src + (wave + NWMIN * NW) * 1024, dst + (wave + NWMIN * NW) * 1024);
+  };
+  issue(0, 0);
+  if (nst > 1) issue(1, 1);
+
+  // the wave's 32 rows of x: K step s -> x[m][KH * half + 8 s .. + 8]
+  bf16x8 xf[KS];
+  {
+    const bf16_t* px = a.x + (long long)m * a.ldx + KH * half;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[s] = *(const bf16x8*)(px + 8 * s);
+    if constexpr (GN) {   // GroupNorm apply folded into the load: bf16(x * scale + shift), the rounding MG_OP_GN_APPLY has
+      const float* ps = a.gn_ss + (long long)(row0 / a.T) * 2 * K + KH * half;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float4 s0 = *(const float4*)(ps + 8 * s), s1 = *(const float4*)(ps + 8 * s + 4);
+        const float4 h0 = *(const float4*)(ps + K + 8 * s), h1 = *(const float4*)(ps + K + 8 * s + 4);
+        const uint4 v = __builtin_bit_cast(uint4, xf[s]);
+        uint4 o;
+        o.x = cvt_pk_bf16_f32(__builtin_fmaf(bflo(v.x), s0.x, h0.x), __builtin_fmaf(bfhi(v.x), s0.y, h0.y));
+        o.y = cvt_pk_bf16_f32(__builtin_fmaf(bflo(v.y), s0.z, h0.z), __builtin_fmaf(bfhi(v.y), s0.w, h0.w));
+        o.z = cvt_pk_bf16_f32(__builtin_fmaf(bflo(v.z), s1.x, h1.x), __builtin_fmaf(bfhi(v.z), s1.y, h1.y));
+        o.w = cvt_pk_bf16_f32(__builtin_fmaf(bflo(v.w), s1.z, h1.z), __builtin_fmaf(bfhi(v.w), s1.w, h1.w));
+        xf[s] = __builtin_bit_cast(bf16x8, o);
+      }
+    }
+  }
+  float l_sc = 1.f, l_mr = 0.f;
+  if constexpr (LN) {
+    const float2 st = a.ln_in[m];
+    l_sc = st.y;
+    l_mr = -st.y * st.x;
+  }
+  bf16_t* const po = a.out + (long long)m * a.ldo + 8 * half;
+  const bf16_t* const pr = RES ? a.res + (long long)m * a.ldr + 8 * half : nullptr;
+  uint4 rres[4] = {};   // the residual rows of the NEXT stage, requested before that stage's weights (vmcnt retires in order)
+  auto load_res = [&](int j) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rres[g] = *(const uint4*)(pr + j * 64 + g * 16);
+  };
+  if constexpr (RES) load_res(0);
+  // V^T: image b, first token of the wave's tile; lane = channel chan(l31) of a tile, registers = tokens
+  bf16_t* pvt = nullptr;
+  if constexpr (EPI == RG_QKV) {
+    const int b = row0 / a.T, tok0 = row0 - b * a.T;
+    const int ch = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // bits 2 and 3 exchanged
+    pvt = a.vt + ((long long)b * (a.N - a.trans_stage * 64) + ch) * a.ldt + tok0 + 8 * half;
+  }
+  double sd = 0.0, qd = 0.0;
+
+  int slot = 0, slot_i = 2;   // stage j lives in slot j % 3; stage j + 2 goes to slot (j + 2) % 3
+  // One stage.  VSEC (the V^T section of the QKV form) is a compile-time tag and the two sections are two loops: as one
+  // body with a branch, hipcc hoists the (identical) fragment reads of both arms above it - 160 live registers of fragments.
+  auto stage = [&](int j, auto vsec_tag) {
+    constexpr bool vsec = decltype(vsec_tag)::value;
+    if (j + 1 < nst) rg_wait_vmcnt<XW>(); else rg_wait_vmcnt<XW - NWMIN>();
+    __builtin_amdgcn_s_barrier();
+    if (j + 2 < nst) issue(j + 2, slot_i);
+    const char* const sb = smem + slot * STAGE + lane * 16;
+    // fp32 [64] constants, [64] g of this stage; + this lane's first channel (8 half; the V^T section: chan(l31))
+    const uint32_t tcb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + (uint32_t)(slot * STAGE + TRL);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bf16x8 w0 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + s * 1024));
+      const bf16x8 w1 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + (KS + s) * 1024));
+      if constexpr (!vsec) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s], acc1, 0, 0, 0);
+      } else {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w1, acc1, 0, 0, 0);
+      }
+    }
+    // ---- the stage's 32 rows x 64 channels, in registers ----
+    __builtin_amdgcn_sched_barrier(0);   // fragment registers are dead before the epilogue's temporaries go live
+    if constexpr (EPI == RG_GEGLU) {
+      // tile 0 = 32 value channels, tile 1 = their gates (weights.pack_rowgemm_geglu); out column = 32 j + channel
+      uint4 pk[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float o[8];
+#pragma unroll
+        for (int t = 1; t >= 0; --t) {   // the gate tile first: gelu(gate) is all that stays live across the value tile
+          const uint32_t cbp = tcb + (uint32_t)(t * 128 + q * 64 + 32 * half);
+          f32x4 c0 = rg_lds16<0>(cbp), c1 = rg_lds16<16>(cbp), g0 = c0, g1 = c0;
+          if constexpr (LN) { g0 = rg_lds16<256>(cbp); g1 = rg_lds16<272>(cbp); }
+          rg_lgk0(c0, c1, g0, g1);
+          const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float av = t == 0 ? acc0[8 * q + i] : acc1[8 * q + i];
+            const float v = __builtin_fmaf(av, l_sc, LN ? __builtin_fmaf(l_mr, gg[i], cc[i]) : cc[i]);
+            if (t == 1) o[i] = a.gelu_erf ? gelu_erf_f(v) : gelu_poly_f(v);
+            else o[i] = v * o[i];
+          }
+        }
+        pk[q].x = cvt_pk_bf16_f32(o[0], o[1]); pk[q].y = cvt_pk_bf16_f32(o[2], o[3]);
+        pk[q].z = cvt_pk_bf16_f32(o[4], o[5]); pk[q].w = cvt_pk_bf16_f32(o[6], o[7]);
+      }
+      *(uint4*)(po + j * 32) = pk[0];
+      *(uint4*)(po + j * 32 + 16) = pk[1];
+    } else if constexpr (vsec) {
+      // registers 8q .. 8q+7 of tile t = tokens (key slots) 16 q + 8 half .. + 8 of channel 32 t + chan(l31)
+      bf16_t* pv = pvt + (long long)((j - a.trans_stage) * 64) * a.ldt;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ch = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+        float cc = rg_lds4<0>(tcb + (uint32_t)((t * 32 + ch) * 4)), gg = cc;
+        if constexpr (LN) gg = rg_lds4<256>(tcb + (uint32_t)((t * 32 + ch) * 4));
+        rg_lgk0(cc, gg);
+        // the folded LayerNorm's row terms belong to the TOKEN here (a register), not to the lane: fetched from the lane
+        // that owns the row (ds_bpermute - not a vector load, whose in-order return would wait for the weight prefetch)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float av = t == 0 ? acc0[8 * q + i] : acc1[8 * q + i];
+            float sc = 1.f, mr = 0.f;
+            if constexpr (LN) {
+              const int tokl = 16 * q + 8 * (i >> 2) + 4 * half + (i & 3);   // MFMA row of register 8q+i
+              sc = __shfl(l_sc, tokl);
+              mr = __shfl(l_mr, tokl);
+            }
+            v[i] = __builtin_fmaf(av, sc, LN ? __builtin_fmaf(mr, gg, cc) : cc);
+          }
+          uint4 pk;
+          pk.x = cvt_pk_bf16_f32(v[0], v[1]); pk.y = cvt_pk_bf16_f32(v[2], v[3]);
+          pk.z = cvt_pk_bf16_f32(v[4], v[5]); pk.w = cvt_pk_bf16_f32(v[6], v[7]);
+          *(uint4*)(pv + (long long)(t * 32) * a.ldt + 16 * q) = pk;
+        }
+      }
+    } else {
+      float ps = 0.f, pq = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int c = j * 64 + t * 32 + q * 16;
+          const uint32_t cbp = tcb + (uint32_t)(t * 128 + q * 64 + 32 * half);
+          f32x4 c0 = rg_lds16<0>(cbp), c1 = rg_lds16<16>(cbp), g0 = c0, g1 = c0;
+          if constexpr (LN) { g0 = rg_lds16<256>(cbp); g1 = rg_lds16<272>(cbp); }
+          rg_lgk0(c0, c1, g0, g1);
+          const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+          uint4 r4 = make_uint4(0, 0, 0, 0);
+          if constexpr (RES) r4 = rres[t * 2 + q];
+          const float rr[8] = {bflo(r4.x), bfhi(r4.x), bflo(r4.y), bfhi(r4.y), bflo(r4.z), bfhi(r4.z), bflo(r4.w), bfhi(r4.w)};
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float av = t == 0 ? acc0[8 * q + i] : acc1[8 * q + i];
+            v[i] = __builtin_fmaf(av, l_sc, LN ? __builtin_fmaf(l_mr, gg[i], cc[i]) : cc[i]);
+            if constexpr (RES) v[i] += rr[i];
+            if constexpr (LNO) { ps += v[i]; pq = __builtin_fmaf(v[i], v[i], pq); }
+          }
+          uint4 pk;
+          pk.x = cvt_pk_bf16_f32(v[0], v[1]); pk.y = cvt_pk_bf16_f32(v[2], v[3]);
+          pk.z = cvt_pk_bf16_f32(v[4], v[5]); pk.w = cvt_pk_bf16_f32(v[6], v[7]);
+          *(uint4*)(po + c) = pk;
+        }
+      if constexpr (LNO) { sd += (double)ps; qd += (double)pq; }
+      // the next stage's residual rows: behind this stage's stores, ahead of the next weight prefetch in the vmcnt queue
+      if constexpr (RES) { if (j + 1 < nst) load_res(j + 1); }
+    }
+    slot = slot == NSTAGE - 1 ? 0 : slot + 1;
+    slot_i = slot_i == NSTAGE - 1 ? 0 : slot_i + 1;
+  };
+  if constexpr (EPI == RG_QKV) {
+    const int nq = a.trans_stage < nst ? a.trans_stage : nst;
+    for (int j = 0; j < nq; ++j) stage(j, std::false_type{});
+    for (int j = nq; j < nst; ++j) stage(j, std::true_type{});
+  } else {
+    for (int j = 0; j < nst; ++j) stage(j, std::false_type{});
+  }
+  if constexpr (LNO) {   // (mean, rstd) of the new rows: the wave holds them whole (fp64 only for E[x^2] - mean^2)
+    sd += __shfl_xor(sd, 32);
+    qd += __shfl_xor(qd, 32);
+    if (half == 0) {
+      const double mean = sd * a.inv_n;
+      const float var = fmaxf((float)__builtin_fma(qd, a.inv_n, -mean * mean), 0.f);
+      a.ln_out[m] = make_float2((float)mean, __builtin_amdgcn_rsqf(var + a.ln_eps));
+    }
+  }
+}
+
+template <int K, int NW, int EPI, bool LN, bool GN, bool RES, bool LNO>
+int rg_launch(const RgArgs& a, hipStream_t s) {
+  constexpr int LDS = 3 * (K / 8 + 1) * 1024;
+  static bool attr_set = false;
+  auto kern = rowgemm_kernel<K, NW, EPI, LN, GN, RES, LNO>;
+  if (!attr_set && !g_dry_run) {
+    MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const int rows = NW * 32;
+  MG_LAUNCH(kern, dim3((a.M + rows - 1) / rows), dim3(NW * 64), LDS, s, a);
+  return 0;
+}
+
+template <int K, int NW>
+int rg_dispatch(const RgArgs& a, int epi, hipStream_t s) {
+  const bool ln = a.ln_in != nullptr, gn = a.gn_ss != nullptr, res = a.res != nullptr, lno = a.ln_out != nullptr;
+  if (epi == RG_GEGLU) {
+    MG_REQUIRE(!gn && !res && !lno, "rowgemm: the GEGLU form takes no GroupNorm input / residual / row statistics");
+    return ln ? rg_launch<K, NW, RG_GEGLU, true, false, false, false>(a, s) : rg_launch<K, NW, RG_GEGLU, false, false, false, false>(a, s);
+  }
+  if (epi == RG_QKV) {
+    MG_REQUIRE(!gn && !res && !lno, "rowgemm: the QKV form takes no GroupNorm input / residual / row statistics");
+    return ln ? rg_launch<K, NW, RG_QKV, true, false, false, false>(a, s) : rg_launch<K, NW, RG_QKV, false, false, false, false>(a, s);
+  }
+  MG_REQUIRE(!(gn && (ln || res)), "rowgemm: GroupNorm input excludes the folded LayerNorm and the residual");
+  if (gn) return lno ? rg_launch<K, NW, RG_BF16, false, true, false, true>(a, s) : rg_launch<K, NW, RG_BF16, false, true, false, false>(a, s);
+  if (ln) {
+    MG_REQUIRE(!lno, "rowgemm: folded LayerNorm input + row statistics output is not instantiated");
+    return res ? rg_launch<K, NW, RG_BF16, true, false, true, false>(a, s) : rg_launch<K, NW, RG_BF16, true, false, false, false>(a, s);
+  }
+  if (res) return lno ? rg_launch<K, NW, RG_BF16, false, false, true, true>(a, s) : rg_launch<K, NW, RG_BF16, false, false, true, false>(a, s);
+  return lno ? rg_launch<K, NW, RG_BF16, false, false, false, true>(a, s) : rg_launch<K, NW, RG_BF16, false, false, false, false>(a, s);
+}
+
+}  // namespace
+
+int mg_launch_rowgemm(const mg_op* op, hipStream_t s) {
+  RgArgs a;
+  a.M = op->i[0];
+  const int K = op->i[1];
+  a.N = op->i[2];
+  a.ldx = op->i[3] > 0 ? op->i[3] : K;
+  const int epi = op->i[6];
+  a.ldo = op->i[4] > 0 ? op->i[4] : (epi == RG_GEGLU ? a.N / 2 : a.N);
+  a.ldr = op->i[5] > 0 ? op->i[5] : a.N;
+  a.T = op->i[7];
+  a.ldt = op->i[8];
+  const int trans_from = op->i[9];
+  const int nw = op->i[10] > 0 ? op->i[10] : 12;
+  a.ln_eps = op->f[0];
+  a.x = (const bf16_t*)op->p[0];
+  a.wp = (const char*)op->p[1];
+  a.out = (bf16_t*)op->p[2];
+  a.res = (const bf16_t*)op->p[3];
+  a.ln_in = (const float2*)op->p[4];
+  a.ln_out = (float2*)op->p[5];
+  a.vt = (bf16_t*)op->p[6];
+  a.gn_ss = (const float*)op->p[7];
+  a.inv_n = 1.0 / (double)(a.N > 0 ? a.N : 1);
+  a.trans_stage = epi == RG_QKV ? trans_from / 64 : (1 << 30);
+  {
+    static const int erf_ab = [] { const char* e = getenv("MARIGOLD_GELU_ERF"); return (e && e[0] == '1') ? 1 : 0; }();
+    a.gelu_erf = erf_ab;
+  }
+  MG_REQUIRE(epi >= RG_BF16 && epi <= RG_QKV, "rowgemm: unknown epilogue %d", epi);
+  MG_REQUIRE(a.x && a.wp && a.out, "rowgemm: null pointer (x, packed weights, out)");
+  MG_REQUIRE(K == 320, "rowgemm: K = %d is not instantiated (320)", K);
+  MG_REQUIRE(a.M >= 32 && a.M % 32 == 0, "rowgemm: M = %d must be a multiple of 32 (a wave owns 32 whole rows)", a.M);
+  MG_REQUIRE(a.N >= 128 && a.N % 64 == 0, "rowgemm: N = %d must be a multiple of 64, >= 128", a.N);
+  MG_REQUIRE(a.ldx >= K && a.ldx % 8 == 0 && a.ldo % 8 == 0 && a.ldo >= (epi == RG_GEGLU ? a.N / 2 : (epi == RG_QKV ? trans_from : a.N)),
+             "rowgemm: leading dimensions (ldx %d, ldo %d)", a.ldx, a.ldo);
+  MG_REQUIRE((uintptr_t)a.x % 16 == 0 && (uintptr_t)a.wp % 16 == 0 && (uintptr_t)a.out % 16 == 0, "rowgemm: 16-byte alignment of x / weights / out");
+  if (a.ln_in) MG_REQUIRE((uintptr_t)a.ln_in % 8 == 0, "rowgemm: misaligned (mean, rstd) table of the input rows");
+  if (a.res) MG_REQUIRE(epi == RG_BF16 && a.ldr >= a.N && a.ldr % 8 == 0 && (uintptr_t)a.res % 16 == 0, "rowgemm: residual layout");
+  if (a.ln_out) MG_REQUIRE((uintptr_t)a.ln_out % 8 == 0, "rowgemm: misaligned (mean, rstd) table");
+  if (a.gn_ss) MG_REQUIRE(a.T > 0 && a.T % 32 == 0 && a.M % a.T == 0 && (uintptr_t)a.gn_ss % 16 == 0, "rowgemm: GroupNorm input needs tokens per image %% 32 == 0");
+  if (epi == RG_QKV)
+    MG_REQUIRE(a.vt && trans_from > 0 && trans_from % 64 == 0 && trans_from < a.N && a.T > 0 && a.T % 32 == 0 && a.M % a.T == 0 &&
+               a.ldt >= a.T && a.ldt % 8 == 0 && (uintptr_t)a.vt % 16 == 0,
+               "rowgemm: the QKV form needs V^T (p[8]), trans_from %% 64 == 0, tokens per image %% 32 == 0, ldt >= tokens");
+  if (nw == 12) return rg_dispatch<320, 12>(a, epi, s);
+  if (nw == 8) return rg_dispatch<320, 8>(a, epi, s);
+  if (nw == 4) return rg_dispatch<320, 4>(a, epi, s);
+  MG_REQUIRE(false, "rowgemm: %d waves per workgroup is not instantiated (4, 8, 12)", nw);
+}

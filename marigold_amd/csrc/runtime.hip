@@ -37,6 +37,7 @@ static int dispatch(const mg_op* op, hipStream_t s) {
   switch (op->kind) {
     case MG_OP_IGEMM: return mg_launch_igemm(op, s);
     case MG_OP_CONV3X3: return mg_launch_conv_patch(op, s);
+    case MG_OP_ROWGEMM: return mg_launch_rowgemm(op, s);
     case MG_OP_GN_STATS:
     case MG_OP_GN_FINALIZE:
     case MG_OP_GN_APPLY:

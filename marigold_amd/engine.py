@@ -27,6 +27,8 @@ FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"
 XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)
 GN_SLAB = os.environ.get("MARIGOLD_GN_SLAB", "1") != "0"           # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 FLASH_VT_PERM = os.environ.get("MARIGOLD_FLASH_VT_PERM", "1") != "0"   # permuted V^T + generation-3 attention (0: generation 2)
+ROWGEMM = os.environ.get("MARIGOLD_ROWGEMM", "1") != "0"           # row-resident GEMM (MG_OP_ROWGEMM) for the K = 320 token-local layers
+ROWGEMM_MIN_M = int(os.environ.get("MARIGOLD_ROWGEMM_MIN_M", str(120 * 384)))   # below: too few 384-row workgroups for the chip
 
 
 class Act:
@@ -161,6 +163,30 @@ class WeightStore:
             return wp.to(self.device), Wm.f32(g, self.device), Wm.f32(c, self.device)
         return self._memo(("gg_ln", name), f)
 
+    # ---- MG_OP_ROWGEMM forms: weights in fragment order + per-stage constants (weights.pack_rowgemm) ----
+    def rg_mat(self, name):
+        def f():
+            w = self.sd[f"{name}.weight"].float()
+            w = w.reshape(w.shape[0], -1)
+            b = self.sd[f"{name}.bias"].float() if f"{name}.bias" in self.sd else torch.zeros(w.shape[0])
+            return Wm.pack_rowgemm(w, b).to(self.device)
+        return self._memo(("rg_m", name), f)
+
+    def rg_qkv_ln(self, prefix, norm):
+        def f():
+            w = Wm.pack_qkv(*(self.sd[f"{prefix}.{q}.weight"].float() for q in ("to_q", "to_k", "to_v")))
+            wp, g, c = Wm.fold_layernorm(w, None, *self._ln(norm))
+            return Wm.pack_rowgemm(wp.float(), c, g).to(self.device)
+        return self._memo(("rg_qkv_ln", prefix), f)
+
+    def rg_geglu_ln(self, name, norm):
+        def f():
+            w, b = self.sd[f"{name}.weight"].float(), self.sd[f"{name}.bias"].float()
+            order = Wm.rowgemm_geglu_order(w.shape[0])
+            wp, g, c = Wm.fold_layernorm(w[order], b[order], *self._ln(norm))
+            return Wm.pack_rowgemm(wp.float(), c, g).to(self.device)
+        return self._memo(("rg_gg_ln", name), f)
+
     def cross_ln(self, prefix, ctx, heads, norm):
         def f():
             wqk, vot, npad = Wm.cross_attention_tables(
@@ -221,11 +247,17 @@ class Builder:
         self.seq.add(op, label)
 
     # ---- primitive layers ----------------------------------------------------------------
+    @staticmethod
+    def rowgemm_ok(x):
+        """Token-local Linear layers of this activation on MG_OP_ROWGEMM?  K = 320 is what the kernel is built for (a wave
+        keeps 32 rows x 320 channels in 80 registers); whole 32-row tiles inside an image (the V^T section and the folded
+        GroupNorm are per image), enough 384-row workgroups for the chip, and the permuted V^T the QKV form writes."""
+        return ROWGEMM and FLASH_VT_PERM and x.C == 320 and x.HW % 32 == 0 and x.M >= ROWGEMM_MIN_M
+
     def gn_slab_ok(self, srcs, apply):
         """One-launch GroupNorm (MG_OP_GN_SLAB: a workgroup owns whole groups of an image over all rows)?  UNet-sized
         maps with enough (image, channel window) pairs to fill the chip; the normalising form keeps the rows in registers
-        (<= 48 rows per thread).  The VAE's 128-channel 768^2 tensors (4-channel groups: 8-byte row segments) stay on the
-        chunked statistics / apply passes."""
+        (<= 48 rows per thread).  Large tensors (UNet level 0, the VAE) stay on the chunked statistics / apply passes."""
         B, HW = srcs[0].B, srcs[0].HW
         C = sum(x.C for x in srcs)
         if not GN_SLAB or len(srcs) > 2 or C % self.groups or any(x.C % 4 for x in srcs):
@@ -233,6 +265,12 @@ class Builder:
         cpg = C // self.groups
         cw = cpg * (4 // math.gcd(cpg, 4))
         if not (16 <= cw <= 128) or HW > 16384 or B * (C // cw) < 64:
+            return False
+        # measured per layer (profiles/r3_groupnorm_slab_vs_chunked.log): a slab pass beats statistics + apply only while
+        # the tensor is small enough that the chunked passes are launch/latency-bound (<= 16 MiB: UNet levels 2-3), or
+        # when it replaces the TWO statistics launches of a skip concat at levels 1-3; on the big level-0 / VAE tensors
+        # its B * C / cw workgroups are too few and the chunked passes win by 1.3-1.8x
+        if not ((len(srcs) == 2 and HW <= 2304) or B * HW * C * 2 <= (16 << 20)):
             return False
         if apply:
             nt = 1024 if HW * cw * 2 >= 48 * 1024 else 256
@@ -469,7 +507,11 @@ class Builder:
         # V^T with its keys in the QK^T accumulator order inside groups of 16: the QKV epilogue skips its lane regroup and
         # the attention kernel (generation 3) its v_permlane32_swap - a format private to this producer / consumer pair
         perm = FLASH_VT_PERM and T % 16 == 0
-        if st is not None:
+        rg = perm and st is not None and self.rowgemm_ok(h)
+        if rg:
+            self.add(O.rowgemm(h.t, self.ws.rg_qkv_ln(prefix, norm), qk, M=M, K=C, N=3 * C, form=L.RG_QKV, ldo=2 * C,
+                               ln_in=self.ln_mean_rstd(st, M, C), vt=vt, tokens=T, ldt=ldvt, trans_from=2 * C), f"{prefix}.qkv")
+        elif st is not None:
             wqkv, g, c = self.ws.qkv_ln(prefix, norm)
             self.add(O.igemm(h.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, out2=vt,
                              trans_from=2 * C, ldt=ldvt, ln_in=self.ln_mean_rstd(st, M, C), ln_g=g, ln_c=c, trans_perm=perm), f"{prefix}.qkv")
@@ -483,8 +525,12 @@ class Builder:
                                 ldo=C, ldvt=ldvt, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C,
                                 scale=1.0 / math.sqrt(C // heads), vt_perm=perm), f"{prefix}.flash")
         self.free(qk)
-        self.dense(o, self.ws.mat(f"{prefix}.to_out.0"), self.ws.bias(f"{prefix}.to_out.0"), C,
-                   residual=h, out=h, label=f"{prefix}.to_out", ln_out=st_out)
+        if rg and st_out is not None:
+            self.add(O.rowgemm(o.t, self.ws.rg_mat(f"{prefix}.to_out.0"), h.t, M=M, K=C, N=C, residual=h.t,
+                               ln_out=self.ln_mean_rstd(st_out, M, C)), f"{prefix}.to_out")
+        else:
+            self.dense(o, self.ws.mat(f"{prefix}.to_out.0"), self.ws.bias(f"{prefix}.to_out.0"), C,
+                       residual=h, out=h, label=f"{prefix}.to_out", ln_out=st_out)
         self.free(o)
 
     def cross_attention2(self, h, st, prefix, norm, heads, ctx, st_out):
@@ -529,15 +575,31 @@ class Builder:
         that consumes one takes the raw residual stream and corrects in its epilogue (MG_OP_IGEMM ln_in), with the row
         statistics written by the epilogue of the GEMM that produced the stream (ln_out)."""
         C = x.C
-        g = self.group_norm(x, f"{name}.norm", 1e-6, False)
         st = [self.ln_table(x.M, C) if FOLD_LN else None for _ in range(3)]
-        h = self.dense(g, self.ws.mat(f"{name}.proj_in"), self.ws.bias(f"{name}.proj_in"), C,
-                       label=f"{name}.proj_in", ln_out=st[0])
-        self.free(g)
+        rg = FOLD_LN and self.rowgemm_ok(x)
+        if rg:
+            # the GroupNorm never runs as a pass: statistics only, its scale / shift applied while proj_in loads its rows
+            if self.gn_slab_ok([x], False):
+                ss, _ = self.gn_slab([x], f"{name}.norm", 1e-6, False, False)
+            else:
+                ss = self.gn_scale_shift([x], f"{name}.norm", 1e-6)
+            h = self.new(x.B, x.H, x.W, C)
+            self.add(O.rowgemm(x.t, self.ws.rg_mat(f"{name}.proj_in"), h.t, M=x.M, K=C, N=C, gn_ss=ss, tokens=x.HW,
+                               ln_out=self.ln_mean_rstd(st[0], x.M, C)), f"{name}.proj_in")
+            self.free(ss)
+        else:
+            g = self.group_norm(x, f"{name}.norm", 1e-6, False)
+            h = self.dense(g, self.ws.mat(f"{name}.proj_in"), self.ws.bias(f"{name}.proj_in"), C,
+                           label=f"{name}.proj_in", ln_out=st[0])
+            self.free(g)
         b = f"{name}.transformer_blocks.0"
         self.self_attention(h, st[0], f"{b}.attn1", f"{b}.norm1", heads, st[1])
         self.cross_attention2(h, st[1], f"{b}.attn2", f"{b}.norm2", heads, ctx, st[2])
-        if FOLD_LN:
+        if rg:
+            ff = self.new(h.B, h.H, h.W, 4 * C)
+            self.add(O.rowgemm(h.t, self.ws.rg_geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3"), ff.t, M=h.M, K=C, N=8 * C,
+                               form=L.RG_GEGLU, ln_in=self.ln_mean_rstd(st[2], h.M, C)), f"{b}.ff.geglu")
+        elif FOLD_LN:
             wg, gg, cg = self.ws.geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3")
             ff = self.dense(h, wg, None, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu",
                             ln=(self.ln_mean_rstd(st[2], h.M, C), gg, cg))
@@ -551,8 +613,12 @@ class Builder:
                    label=f"{b}.ff.out")
         self.free(ff)
         # NB: the GEMM input must never alias its output (other column tiles still read it)
-        out = self.dense(h, self.ws.mat(f"{name}.proj_out"), self.ws.bias(f"{name}.proj_out"), C,
-                         residual=x, out=x, label=f"{name}.proj_out")
+        if rg:
+            self.add(O.rowgemm(h.t, self.ws.rg_mat(f"{name}.proj_out"), x.t, M=h.M, K=C, N=C, residual=x.t), f"{name}.proj_out")
+            out = x
+        else:
+            out = self.dense(h, self.ws.mat(f"{name}.proj_out"), self.ws.bias(f"{name}.proj_out"), C,
+                             residual=x, out=x, label=f"{name}.proj_out")
         self.free(h)
         return out
 

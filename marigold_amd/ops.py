@@ -68,6 +68,13 @@ def conv3x3(a0, w, out, *, B, H, W, C0, N, a1=None, C1=0, subpix=False, ss=None,
                    p=[a0, w, out, bias, rowvec, residual, a1, ss], l=[wz])
 
 
+def rowgemm(x, wp, out, *, M, K, N, form=L.RG_BF16, ldx=0, ldo=0, ldr=0, residual=None, ln_in=None, ln_out=None, vt=None,
+            gn_ss=None, tokens=0, ldt=0, trans_from=0, waves=0, ln_eps=1e-5):
+    """Row-resident GEMM (MG_OP_ROWGEMM): ``wp`` from weights.pack_rowgemm."""
+    return make_op(L.OP_ROWGEMM, i=[M, K, N, ldx, ldo, ldr, form, tokens, ldt, trans_from, waves], f=[ln_eps],
+                   p=[x, wp, out, residual, ln_in, ln_out, vt, gn_ss])
+
+
 def linear(x, w, out, *, M, K, N, **kw):
     """out[M][N] = x[M][K] @ w[N][K]^T (+ fused epilogue)."""
     return igemm(x, w, out, B=1, H=M, W=1, Cin=K, Ho=M, Wo=1, N=N, taps=1, **kw)

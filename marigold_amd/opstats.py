@@ -9,14 +9,14 @@ MFMA_PEAK_TFLOPS = 2500.0   # bf16 dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0       # HBM3E spec (6.29 TB/s measured streaming)
 
 CLASS = {
-    L.OP_IGEMM: "igemm_mfma", L.OP_CONV3X3: "conv3x3_patch", L.OP_FLASH_ATTN64: "flash_attn64", L.OP_GN_STATS: "groupnorm",
+    L.OP_IGEMM: "igemm_mfma", L.OP_ROWGEMM: "rowgemm_mfma", L.OP_CONV3X3: "conv3x3_patch", L.OP_FLASH_ATTN64: "flash_attn64", L.OP_GN_STATS: "groupnorm",
     L.OP_GN_FINALIZE: "groupnorm", L.OP_GN_APPLY: "groupnorm", L.OP_GN_SLAB: "groupnorm", L.OP_LAYERNORM: "layernorm",
     L.OP_SOFTMAX_ROWS: "softmax", L.OP_SOFTMAX_PAIRS: "softmax",
     L.OP_SCHED_STEP: "scheduler_step", L.OP_LINEAR_SMALL_M: "time_embedding",
     L.OP_LATENT_1X1: "boundary_conv", L.OP_POST_NCHW: "boundary_conv", L.OP_IM2COL_SMALL: "boundary_conv", L.OP_ENS_DEPTH_STATS: "ensemble", L.OP_ENS_DEPTH_MEDIAN: "ensemble",
     L.OP_ENS_DEPTH_NORM: "ensemble", L.OP_ENS_NORMALS: "ensemble", L.OP_RESIZE: "resize", L.OP_COLORIZE: "resize", L.OP_MEMSET: "memops", L.OP_COPY: "memops",
 }
-BOUND = {"igemm_mfma": "mfma", "conv3x3_patch": "mfma", "flash_attn64": "mfma"}   # everything else is HBM-bound streaming
+BOUND = {"igemm_mfma": "mfma", "rowgemm_mfma": "mfma", "conv3x3_patch": "mfma", "flash_attn64": "mfma"}   # everything else is HBM-bound streaming
 
 
 def op_cost(op):
@@ -41,6 +41,10 @@ def op_cost(op):
             byts = B * H * W * Cin * 2 + N * K * 2 + c2 * N * 2 + M * c2 * 2 + (M * c2 * 2 if op.p[5] else 0)
         elif op.p[5]:
             byts += bz * M * n_out * 2   # fused residual read
+    elif k == L.OP_ROWGEMM:
+        M, K, N, form = i[0], i[1], i[2], i[6]
+        flops = 2 * M * N * K
+        byts = M * K * 2 + N * K * 2 + M * (N // 2 if form == L.RG_GEGLU else N) * 2 + (M * N * 2 if op.p[3] else 0)
     elif k == L.OP_CONV3X3:
         B, H, W, C0, C1, N, subpix = (i[j] for j in range(7))
         Cin, par, T = C0 + C1, (4 if subpix else 1), (4 if subpix else 9)

@@ -110,3 +110,40 @@ def fold_layernorm(w, bias, gamma, beta):
     if bias is not None:
         c = c + bias.double()
     return wp.contiguous(), g.contiguous(), c.float().contiguous()
+
+
+# ---- MG_OP_ROWGEMM (csrc/rowgemm.hip): weights in MFMA fragment order, streamed in 64-channel stages ----
+def _rg_chan():
+    """MFMA row index mm -> channel inside a 32-channel tile: bits 2 and 3 exchanged, so that a lane's accumulator registers
+    0-7 / 8-15 are 8 consecutive channels each (16-byte stores without a lane exchange)."""
+    mm = torch.arange(32)
+    return (mm & 0x13) | ((mm & 4) << 1) | ((mm & 8) >> 1)
+
+
+def pack_rowgemm(w, cb, lg=None):
+    """w [N][K] (rows in the order the kernel's channels take: stage j = rows 64 j .. 64 j + 63, tile 0 its first 32) ->
+    uint8 [N/64][(2 K/16 + 1) * 1024]: per stage 2 x K/16 fragments of 1 KB - fragment (tile t, K step s), lane l = 32 g + mm,
+    8 bf16: w[64 j + 32 t + chan(mm)][K/2 g + 8 s + 0..7] (the kernel's permuted reduction order: lane half g owns the
+    contiguous K range [K/2 g, K/2 (g + 1))) - and a 1 KB trailer: fp32 [64] per-channel constants ``cb`` (bias, + the folded
+    LayerNorm's c), fp32 [64] ``lg`` (the folded LayerNorm's g; zeros without), zero padding."""
+    n, k = w.shape
+    assert n % 64 == 0 and k % 32 == 0
+    nst, ks = n // 64, k // 16
+    wb = w.detach().float().cpu().to(torch.bfloat16).contiguous()
+    wv = wb.view(nst, 2, 32, 2, ks, 8)[:, :, _rg_chan()]          # [j][t][mm][g][s][i]
+    frag = wv.permute(0, 1, 4, 3, 2, 5).contiguous()              # [j][t][s][g][mm][i] = 1 KB per (j, t, s)
+    frag = frag.view(torch.uint8).reshape(nst, 2 * ks * 1024)
+    trl = torch.zeros(nst, 256, dtype=torch.float32)
+    trl[:, :64] = cb.detach().float().cpu().reshape(nst, 64)
+    if lg is not None:
+        trl[:, 64:128] = lg.detach().float().cpu().reshape(nst, 64)
+    return torch.cat([frag, trl.view(torch.uint8).reshape(nst, 1024)], dim=1).contiguous()
+
+
+def rowgemm_geglu_order(n2):
+    """Row order of GEGLU's proj [8C, C] for MG_OP_ROWGEMM's GEGLU form: stage j = value rows 32 j .. 32 j + 31, then
+    their gate rows 4C + 32 j .. (diffusers GEGLU: hidden, gate = proj(x).chunk(2))."""
+    h = n2 // 2
+    j = torch.arange(h // 32)[:, None]
+    r = torch.arange(32)[None, :]
+    return torch.cat([32 * j + r, h + 32 * j + r], dim=1).reshape(-1)

@@ -511,6 +511,100 @@ def test_igemm_layernorm_fold(dev):
     _close("ln_fold/qkv/vt_perm", vt2[:, :, :T2], ops.permute_vt_keys(refq[:T2, 2 * C:].reshape(1, T2, C).permute(0, 2, 1).contiguous()), tol=2e-2)
 
 
+@pytest.mark.parametrize("waves", [12, 8, 4])
+def test_rowgemm_all_forms(dev, waves):
+    """MG_OP_ROWGEMM (row-resident GEMM, K = 320) against torch fp32 on the same bf16 operands: every form the transformer
+    uses at the 320-channel level - GroupNorm folded into the load + bias + row statistics (proj_in), QKV with the folded
+    LayerNorm and the permuted V^T section, bias + in-place residual + row statistics (to_out), GEGLU with the folded
+    LayerNorm, bias + residual (proj_out).  M is not a multiple of the workgroup's 384 / 256 / 128 rows: the surplus waves
+    recompute the last row tile (identical stores)."""
+    from marigold_amd import _lib as L, ops, weights as Wm
+    g = torch.Generator().manual_seed(31 + waves)
+    B, T, C = 2, 1056, 320
+    M = B * T
+    x = _bf(torch.randn(M, C, generator=g) * 0.9 + 0.3 * torch.randn(M, 1, generator=g))
+    xd = x.to(dev, torch.bfloat16)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    stx = torch.stack([x.mean(-1), 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5)], dim=-1).to(dev).contiguous()
+    nan_bf = lambda *sh: torch.full(sh, float("nan"), device=dev, dtype=torch.bfloat16)
+
+    # proj_in: GroupNorm scale / shift per (image, channel) applied while the rows are loaded, + bias, + row statistics
+    ss = torch.stack([1 + 0.3 * torch.randn(B, C, generator=g), 0.2 * torch.randn(B, C, generator=g)], 1).contiguous()
+    w, b = torch.randn(C, C, generator=g) / math.sqrt(C), 0.1 * torch.randn(C, generator=g)
+    pk, ssd = Wm.pack_rowgemm(w, b).to(dev), ss.to(dev)
+    out, so = nan_bf(M, C), torch.full((M, 2), float("nan"), device=dev)
+    _run(ops.rowgemm(xd, pk, out, M=M, K=C, N=C, gn_ss=ssd, tokens=T, ln_out=so, waves=waves))
+    xn = _bf(x.view(B, T, C) * ss[:, 0, None, :] + ss[:, 1, None, :]).view(M, C)
+    ref = xn @ _bf(w).t() + b
+    _close(f"rowgemm/gn+bias/{waves}w", out, ref)
+    _close(f"rowgemm/gn+bias/stats/{waves}w", so, torch.stack([ref.mean(-1), 1.0 / torch.sqrt(ref.var(-1, unbiased=False) + 1e-5)], -1), tol=2e-4)
+
+    # QKV: folded LayerNorm; columns >= 2C go to V^T [B][C][ldt] in the attention kernel's permuted key order
+    wq = torch.randn(3 * C, C, generator=g) / math.sqrt(C)
+    wp, lg, lc = Wm.fold_layernorm(wq, None, gamma, beta)
+    pk = Wm.pack_rowgemm(wp.float(), lc, lg).to(dev)
+    ldt = T + 32
+    qk, vt = nan_bf(M, 2 * C), torch.zeros(B, C, ldt, device=dev, dtype=torch.bfloat16)
+    _run(ops.rowgemm(xd, pk, qk, M=M, K=C, N=3 * C, form=L.RG_QKV, ldo=2 * C, ln_in=stx, vt=vt, tokens=T, ldt=ldt, trans_from=2 * C, waves=waves))
+    ref = y @ wq.t()
+    _close(f"rowgemm/qkv/qk/{waves}w", qk, ref[:, :2 * C], tol=2e-2)
+    want_vt = ops.permute_vt_keys(ref[:, 2 * C:].view(B, T, C).transpose(1, 2).contiguous())
+    _close(f"rowgemm/qkv/vt/{waves}w", vt[:, :, :T], want_vt, tol=2e-2)
+    assert not vt[:, :, T:].any(), "V^T pad columns were written"
+
+    # to_out: bias + residual IN PLACE + (mean, rstd) of the new rows
+    h0 = _bf(torch.randn(M, C, generator=g))
+    h, so = h0.to(dev, torch.bfloat16).clone(), torch.full((M, 2), float("nan"), device=dev)
+    pk = Wm.pack_rowgemm(w, b).to(dev)
+    _run(ops.rowgemm(xd, pk, h, M=M, K=C, N=C, residual=h, ln_out=so, waves=waves))
+    ref = x @ _bf(w).t() + b + h0
+    _close(f"rowgemm/residual/{waves}w", h, ref)
+    _close(f"rowgemm/residual/stats/{waves}w", so, torch.stack([ref.mean(-1), 1.0 / torch.sqrt(ref.var(-1, unbiased=False) + 1e-5)], -1), tol=2e-4)
+    # proj_out: bias + residual from another tensor, no statistics; plain bias
+    res = h0.to(dev, torch.bfloat16)
+    out = nan_bf(M, C)
+    _run(ops.rowgemm(xd, pk, out, M=M, K=C, N=C, residual=res, waves=waves))
+    _close(f"rowgemm/residual2/{waves}w", out, ref)
+    out = nan_bf(M, C)
+    _run(ops.rowgemm(xd, pk, out, M=M, K=C, N=C, waves=waves))
+    _close(f"rowgemm/bias/{waves}w", out, x @ _bf(w).t() + b)
+    # folded LayerNorm + bias (+ residual)
+    wl, bl = torch.randn(2 * C, C, generator=g) / math.sqrt(C), 0.1 * torch.randn(2 * C, generator=g)
+    wp, lg, lc = Wm.fold_layernorm(wl, bl, gamma, beta)
+    pk = Wm.pack_rowgemm(wp.float(), lc, lg).to(dev)
+    out = nan_bf(M, 2 * C)
+    _run(ops.rowgemm(xd, pk, out, M=M, K=C, N=2 * C, ln_in=stx, waves=waves))
+    _close(f"rowgemm/ln/{waves}w", out, y @ wl.t() + bl, tol=2e-2)
+
+    # GEGLU: stage = 32 value channels + their 32 gates, folded LayerNorm
+    wg, bg = torch.randn(8 * C, C, generator=g) / math.sqrt(C), 0.1 * torch.randn(8 * C, generator=g)
+    order = Wm.rowgemm_geglu_order(8 * C)
+    wp, lg, lc = Wm.fold_layernorm(wg[order], bg[order], gamma, beta)
+    pk = Wm.pack_rowgemm(wp.float(), lc, lg).to(dev)
+    hid = nan_bf(M, 4 * C)
+    _run(ops.rowgemm(xd, pk, hid, M=M, K=C, N=8 * C, form=L.RG_GEGLU, ln_in=stx, waves=waves))
+    u, gt = (y @ wg.t() + bg).chunk(2, dim=-1)
+    _close(f"rowgemm/geglu/{waves}w", hid, u * F.gelu(gt), tol=2e-2)
+    # run-to-run bit stability (counted waits on the weight stream: a race would show as differing elements)
+    hid2 = nan_bf(M, 4 * C)
+    _run(ops.rowgemm(xd, pk, hid2, M=M, K=C, N=8 * C, form=L.RG_GEGLU, ln_in=stx, waves=waves))
+    assert torch.equal(hid, hid2)
+
+
+def test_rowgemm_rejects_shapes_outside_its_contract(dev):
+    from marigold_amd import _lib as L, ops, weights as Wm
+    x = torch.zeros(64, 320, device=dev, dtype=torch.bfloat16)
+    pk = Wm.pack_rowgemm(torch.zeros(128, 320), torch.zeros(128)).to(dev)
+    out = torch.zeros(64, 128, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(L.MarigoldHipError):
+        ops.launch(ops.rowgemm(x, pk, out, M=48, K=320, N=128))       # M % 32
+    with pytest.raises(L.MarigoldHipError):
+        ops.launch(ops.rowgemm(x, pk, out, M=64, K=640, N=128))       # K
+    with pytest.raises(L.MarigoldHipError):
+        ops.launch(ops.rowgemm(x, pk, out, M=64, K=320, N=96))        # N % 64
+
+
 def test_layernorm_fold_heavy_tailed(dev):
     """The folded LayerNorm  rstd (acc - mean g[n]) + c[n]  cancels two large numbers when |mean| / std >> 1, and real
     SD-v2 residual streams have outlier channels and row means the synthetic weights never produce.  Rows with 2 % outlier

@@ -736,3 +736,31 @@ def test_pingpong_gemm_schedule_model():
                         didx, depoch = read_done_at[o][(t - 2, h)]
                         assert (didx < iidx) if o == g else (depoch < iepoch), ("WAR", mid, KT, g, o, t, h)
 
+
+
+def test_rowgemm_weight_packing():
+    """weights.pack_rowgemm: fragment (stage j, tile t, K step s), lane l = 32 g + mm holds w[64 j + 32 t + chan(mm)][K/2 g + 8 s .. + 8]
+    (csrc/rowgemm.hip's operand order); the trailer holds the stage's per-channel constants; the GEGLU row order pairs
+    32 value rows with their 32 gate rows."""
+    import torch
+    from marigold_amd import weights as Wm
+    g = torch.Generator().manual_seed(5)
+    n, k = 192, 320
+    w, cb, lg = torch.randn(n, k, generator=g), torch.randn(n, generator=g), torch.randn(n, generator=g)
+    pk = Wm.pack_rowgemm(w, cb, lg)
+    ks = k // 16
+    assert pk.shape == (n // 64, (2 * ks + 1) * 1024) and pk.dtype == torch.uint8
+    fr = pk[:, :2 * ks * 1024].contiguous().view(torch.bfloat16).view(n // 64, 2, ks, 2, 32, 8)
+    wb = w.to(torch.bfloat16)
+    chan = [(m & 0x13) | ((m & 4) << 1) | ((m & 8) >> 1) for m in range(32)]
+    assert sorted(chan) == list(range(32)) and chan[:8] == [0, 1, 2, 3, 8, 9, 10, 11]
+    for j in range(n // 64):
+        for t in range(2):
+            for mm in range(32):
+                for h in range(2):
+                    assert torch.equal(fr[j, t, :, h, mm, :].reshape(-1), wb[64 * j + 32 * t + chan[mm], k // 2 * h: k // 2 * (h + 1)])
+    tr = pk[:, 2 * ks * 1024:].contiguous().view(torch.float32)
+    assert torch.equal(tr[:, :64].reshape(-1), cb) and torch.equal(tr[:, 64:128].reshape(-1), lg) and not tr[:, 128:].any()
+    order = Wm.rowgemm_geglu_order(512)
+    assert sorted(order.tolist()) == list(range(512))
+    assert order[:32].tolist() == list(range(32)) and order[32:64].tolist() == list(range(256, 288)) and order[64] == 32
