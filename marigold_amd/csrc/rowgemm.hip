@@ -18,9 +18,10 @@
 // 240 workgroups x 12 waves = one round over the chip for E = 10; the weights are read from L2 once per workgroup
 // (614 KB for QKV), x from HBM exactly once.
 //
-// K order.  Lane (row r = lane % 32, half h = lane / 32) holds x[r][160 h + 8 s .. + 8] as the operand of K step s: a
-// permutation of the reduction index, applied identically to the packed weights - each lane reads 320 contiguous bytes.
-// Channel order inside a 32-channel tile: MFMA row index mm holds channel chan(mm) = mm with bits 2 and 3 exchanged, so
+// K order.  Lane (row r = lane % 32, half h = lane / 32) holds x[r][16 s + 8 h .. + 8] as the operand of K step s - the
+// MFMA's own order, so a stage's packed bf16 output registers ARE the operand of K step 4 j + 2 t + q of a following GEMM
+// (the fused cross-attention uses that for its probabilities) and a row's own channels are at hand as the residual of an
+// in-place layer.  Channel order inside a 32-channel tile: MFMA row index mm holds channel chan(mm) = mm with bits 2 and 3 exchanged, so
 // that a lane's accumulator registers 0-7 / 8-15 are channels 8h .. 8h+7 / 16+8h .. 16+8h+7 - 16-byte stores with no
 // lane exchange.  In the V^T section of the QKV projection the operand roles are swapped (x fragment as MFMA A, weights
 // as B - the register images are the same) and the accumulator then holds, per channel, tokens {4h..4h+3, 8+4h..} - the
@@ -28,9 +29,9 @@
 //
 // Synchronisation: one s_barrier per stage.  A wave waits for its OWN LDS-DMA pieces of stage j with a counted vmcnt
 // before barrier j; vmcnt retires in order on gfx9 and counts stores, so the wait leaves exactly the younger operations in
-// flight: this wave's pieces of stage j+1 (>= 3) and the S stores of the previous stage's epilogue.  Every wave issues
-// every store unconditionally (rows past M do not exist: M % 32 == 0 is required and a surplus wave recomputes the last
-// row tile - identical bytes to identical addresses), so S is a compile-time constant.
+// flight: this wave's pieces of stage j+1 (>= 3) and the S stores of the previous stage's epilogue.  M % 32 == 0 is
+// required, so a wave either owns 32 real rows and issues every store unconditionally (S is a compile-time constant) or
+// - the surplus waves of the last workgroup - owns none and only moves its share of the weight stream.
 #include <stdlib.h>
 
 #include "common.h"
@@ -53,7 +54,7 @@ struct RgArgs {
   int gelu_erf;
 };
 
-enum { RG_BF16 = 0, RG_GEGLU = 1, RG_QKV = 2 };
+enum { RG_BF16 = 0, RG_GEGLU = 1, RG_QKV = 2, RG_XATTN = 3 };
 
 // The stage trailer (per-channel constants) is read with hand-placed LDS instructions: hipcc's waitcnt pass makes every LDS
 // load it can see wait for ALL outstanding LDS-DMA (vmcnt(0)) - in the middle of the stage that would drain the weight
@@ -74,6 +75,7 @@ __device__ __forceinline__ float rg_lds4(uint32_t addr) {
 __device__ __forceinline__ void rg_lgk0(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+__device__ __forceinline__ void rg_lgk0(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void rg_lgk0(float& a, float& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 
 template <int N>
@@ -86,14 +88,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 void rowgemm_kernel(const RgArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // a stage = 2 tiles x KS fragments of 1 KB + one 1 KB trailer: fp32 [64] per-channel constants, [64] folded-LayerNorm g
-  constexpr int KS = K / 16, KH = K / 2, PIECES = 2 * KS + 1, STAGE = PIECES * 1024, NSTAGE = 3, TRL = 2 * KS * 1024;
+  constexpr int KS = K / 16, PIECES = 2 * KS + 1, STAGE = PIECES * 1024, NSTAGE = 3, TRL = 2 * KS * 1024;
   constexpr int NWMIN = PIECES / NW, NWREM = PIECES - NWMIN * NW;   // LDS-DMA pieces per wave and stage: NWMIN (+1 for waves < NWREM)
   constexpr int S = (EPI == RG_GEGLU) ? 2 : 4;             // stores per stage epilogue
   constexpr int XW = NWMIN + S + (RES ? 4 : 0);            // operations younger than stage j's pieces that may stay in flight
   static_assert(K % 32 == 0 && NWMIN >= 1, "geometry");
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   int row0 = blockIdx.x * (NW * 32) + wave * 32;
-  if (row0 >= a.M) row0 = a.M - 32;                        // surplus wave: recompute the last tile (identical stores)
+  // a surplus wave of the last workgroup (M is a multiple of 32, not of the workgroup's rows) only moves its share of the
+  // weight stream and keeps the barriers: it must not touch rows that their owner may already have updated in place
+  const bool active = row0 < a.M;
+  if (!active) row0 = a.M - 32;
   const int m = row0 + l31;
   const int nst = a.N >> 6;
 
@@ -107,18 +112,18 @@ void rowgemm_kernel(const RgArgs a) {
   issue(0, 0);
   if (nst > 1) issue(1, 1);
 
-  // the wave's 32 rows of x: K step s -> x[m][KH * half + 8 s .. + 8]
+  // the wave's 32 rows of x: K step s -> x[m][16 s + 8 half .. + 8] (the MFMA's own K order)
   bf16x8 xf[KS];
   {
-    const bf16_t* px = a.x + (long long)m * a.ldx + KH * half;
+    const bf16_t* px = a.x + (long long)m * a.ldx + 8 * half;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xf[s] = *(const bf16x8*)(px + 8 * s);
+    for (int s = 0; s < KS; ++s) xf[s] = *(const bf16x8*)(px + 16 * s);
     if constexpr (GN) {   // GroupNorm apply folded into the load: bf16(x * scale + shift), the rounding MG_OP_GN_APPLY has
-      const float* ps = a.gn_ss + (long long)(row0 / a.T) * 2 * K + KH * half;
+      const float* ps = a.gn_ss + (long long)(row0 / a.T) * 2 * K + 8 * half;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const float4 s0 = *(const float4*)(ps + 8 * s), s1 = *(const float4*)(ps + 8 * s + 4);
-        const float4 h0 = *(const float4*)(ps + K + 8 * s), h1 = *(const float4*)(ps + K + 8 * s + 4);
+        const float4 s0 = *(const float4*)(ps + 16 * s), s1 = *(const float4*)(ps + 16 * s + 4);
+        const float4 h0 = *(const float4*)(ps + K + 16 * s), h1 = *(const float4*)(ps + K + 16 * s + 4);
         const uint4 v = __builtin_bit_cast(uint4, xf[s]);
         uint4 o;
         o.x = cvt_pk_bf16_f32(__builtin_fmaf(bflo(v.x), s0.x, h0.x), __builtin_fmaf(bfhi(v.x), s0.y, h0.y));
@@ -157,9 +162,18 @@ void rowgemm_kernel(const RgArgs a) {
   // body with a branch, hipcc hoists the (identical) fragment reads of both arms above it - 160 live registers of fragments.
   auto stage = [&](int j, auto vsec_tag) {
     constexpr bool vsec = decltype(vsec_tag)::value;
-    if (j + 1 < nst) rg_wait_vmcnt<XW>(); else rg_wait_vmcnt<XW - NWMIN>();
+    if (active) {
+      if (j + 1 < nst) rg_wait_vmcnt<XW>(); else rg_wait_vmcnt<XW - NWMIN>();
+    } else {   // nothing but weight pieces in this wave's queue
+      if (j + 1 < nst) rg_wait_vmcnt<NWMIN>(); else rg_wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();
     if (j + 2 < nst) issue(j + 2, slot_i);
+    if (!active) {
+      slot = slot == NSTAGE - 1 ? 0 : slot + 1;
+      slot_i = slot_i == NSTAGE - 1 ? 0 : slot_i + 1;
+      return;
+    }
     const char* const sb = smem + slot * STAGE + lane * 16;
     // fp32 [64] constants, [64] g of this stage; + this lane's first channel (8 half; the V^T section: chan(l31))
     const uint32_t tcb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + (uint32_t)(slot * STAGE + TRL);
@@ -284,12 +298,170 @@ void rowgemm_kernel(const RgArgs a) {
   if constexpr (LNO) {   // (mean, rstd) of the new rows: the wave holds them whole (fp64 only for E[x^2] - mean^2)
     sd += __shfl_xor(sd, 32);
     qd += __shfl_xor(qd, 32);
+    if (half == 0 && active) {
+      const double mean = sd * a.inv_n;
+      const float var = fmaxf((float)__builtin_fma(qd, a.inv_n, -mean * mean), 0.f);
+      a.ln_out[m] = make_float2((float)mean, __builtin_amdgcn_rsqf(var + a.ln_eps));
+    }
+  }
+}
+
+// ---- the collapsed 2-token cross-attention (diffusers BasicTransformerBlock.attn2 against the constant empty-prompt
+// context; MG_OP_IGEMM's MG_EPI_XATTN2) in the row-resident form, IN PLACE on the residual stream -------------------------
+//   scores [32 rows][64] = LN(x) Wqk^T (folded LayerNorm, one ordinary stage) -> softmax over column pairs (2 keys per head)
+//   -> the packed probabilities are K steps 0..3 of  out = P VO^T + bias + x  (c2 = K channels, K/64 sub-stages of 8
+//   fragments) -> (mean, rstd) of the new rows.  x is read once (its registers are also the residual), the result written
+//   once: 118 MB for the 92 160 x 320 level.  Two weight images, both requested up front: [41 KB scores stage][K/64 x 8 KB
+//   of VO^T fragments + 2 KB of bias].
+struct RgXArgs {
+  const bf16_t* x;
+  const char* wp;
+  bf16_t* out;
+  const float2* ln_in;
+  float2* ln_out;
+  int M, ldx, ldo, sm_cols;
+  float sm_scale, ln_eps;
+  double inv_n;
+};
+
+template <int K, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
+void rowgemm_xattn_kernel(const RgXArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = K / 16, NSUB = K / 64, P0 = 2 * KS + 1, P1 = NSUB * 8 + 2, S0 = P0 * 1024;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  int row0 = blockIdx.x * (NW * 32) + wave * 32;
+  const bool active = row0 < a.M;   // (see rowgemm_kernel: a surplus wave moves weights and keeps the barriers, nothing else)
+  if (!active) row0 = a.M - 32;
+  const int m = row0 + l31;
+  auto issue = [&](auto pieces_tag, int src_off, int dst_off) {
+    constexpr int P = decltype(pieces_tag)::value;
+    const char* src = a.wp + src_off + lane * 16;
+    char* dst = smem + dst_off;
+#pragma unroll
+    for (int i = 0; i < P / NW; ++i) glds16(src + (wave + i * NW) * 1024, dst + (wave + i * NW) * 1024);
+    if (wave < P % NW) glds16(src + (wave + (P / NW) * NW) * 1024, dst + (wave + (P / NW) * NW) * 1024);
+  };
+  issue(std::integral_constant<int, P0>{}, 0, 0);
+  bf16x8 xf[KS];
+  {
+    const bf16_t* px = a.x + (long long)m * a.ldx + 8 * half;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[s] = *(const bf16x8*)(px + 16 * s);
+  }
+  const float2 st = a.ln_in[m];
+  const float l_sc = st.y, l_mr = -st.y * st.x;
+  issue(std::integral_constant<int, P1>{}, S0, S0);
+  rg_wait_vmcnt<P1 / NW>();   // everything older than this wave's second-image pieces: the scores stage, x, the statistics
+  __builtin_amdgcn_s_barrier();
+  const char* const sb = smem + lane * 16;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
+  bf16x8 pf[4];
+  {
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bf16x8 w0 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + s * 1024));
+      const bf16x8 w1 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + (KS + s) * 1024));
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s], acc1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = t * 32 + q * 16 + 8 * half;   // this lane's 8 score columns: 4 (key 0, key 1) pairs
+        const uint32_t cbp = lds0 + (uint32_t)(2 * KS * 1024 + c * 4);
+        f32x4 c0 = rg_lds16<0>(cbp), c1 = rg_lds16<16>(cbp), g0 = rg_lds16<256>(cbp), g1 = rg_lds16<272>(cbp);
+        rg_lgk0(c0, c1, g0, g1);
+        const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        uint32_t w4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a0 = t == 0 ? acc0[8 * q + 2 * k] : acc1[8 * q + 2 * k], a1 = t == 0 ? acc0[8 * q + 2 * k + 1] : acc1[8 * q + 2 * k + 1];
+          const float s0 = __builtin_fmaf(a0, l_sc, __builtin_fmaf(l_mr, gg[2 * k], cc[2 * k])) * a.sm_scale;
+          const float s1 = __builtin_fmaf(a1, l_sc, __builtin_fmaf(l_mr, gg[2 * k + 1], cc[2 * k + 1])) * a.sm_scale;
+          const float mx = fmaxf(s0, s1);
+          const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx);
+          const float inv = 1.0f / (e0 + e1);
+          w4[k] = (c + 2 * k < a.sm_cols) ? pack2bf(e0 * inv, e1 * inv) : 0u;
+        }
+        pf[t * 2 + q] = __builtin_bit_cast(bf16x8, make_uint4(w4[0], w4[1], w4[2], w4[3]));
+      }
+  }
+  rg_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (!active) return;
+  bf16_t* const po = a.out + (long long)m * a.ldo + 8 * half;
+  double sd = 0.0, qd = 0.0;
+#pragma unroll
+  for (int jj = 0; jj < NSUB; ++jj) {
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 w0 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + S0 + ((jj * 2 + 0) * 4 + s) * 1024));
+      const bf16x8 w1 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + S0 + ((jj * 2 + 1) * 4 + s) * 1024));
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, pf[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pf[s], acc1, 0, 0, 0);
+    }
+    float ps = 0.f, pq = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = jj * 64 + t * 32 + q * 16;
+        const uint32_t bp = lds0 + (uint32_t)(S0 + NSUB * 8 * 1024 + (c + 8 * half) * 4);
+        f32x4 b0 = rg_lds16<0>(bp), b1 = rg_lds16<16>(bp);
+        rg_lgk0(b0, b1);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const uint4 r4 = __builtin_bit_cast(uint4, xf[jj * 4 + t * 2 + q]);   // the row's own channels c + 8 half .. + 8
+        const float rr[8] = {bflo(r4.x), bfhi(r4.x), bflo(r4.y), bfhi(r4.y), bflo(r4.z), bfhi(r4.z), bflo(r4.w), bfhi(r4.w)};
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[i] = (t == 0 ? acc0[8 * q + i] : acc1[8 * q + i]) + bb[i] + rr[i];
+          ps += v[i];
+          pq = __builtin_fmaf(v[i], v[i], pq);
+        }
+        uint4 pk;
+        pk.x = cvt_pk_bf16_f32(v[0], v[1]); pk.y = cvt_pk_bf16_f32(v[2], v[3]);
+        pk.z = cvt_pk_bf16_f32(v[4], v[5]); pk.w = cvt_pk_bf16_f32(v[6], v[7]);
+        *(uint4*)(po + c) = pk;
+      }
+    asm volatile("" : "+v"(ps), "+v"(pq));   // taken here (hipcc otherwise sinks the sums into the `if (ln_out)` block and keeps all 320 values alive)
+    sd += (double)ps;
+    qd += (double)pq;
+    __builtin_amdgcn_sched_barrier(0);   // (unrolled for the register-resident residual: keep the sub-stages' fragment reads apart)
+  }
+  if (a.ln_out) {
+    sd += __shfl_xor(sd, 32);
+    qd += __shfl_xor(qd, 32);
     if (half == 0) {
       const double mean = sd * a.inv_n;
       const float var = fmaxf((float)__builtin_fma(qd, a.inv_n, -mean * mean), 0.f);
       a.ln_out[m] = make_float2((float)mean, __builtin_amdgcn_rsqf(var + a.ln_eps));
     }
   }
+}
+
+template <int K, int NW>
+int rg_launch_xattn(const RgXArgs& a, hipStream_t s) {
+  constexpr int LDS = (2 * (K / 16) + 1 + (K / 64) * 8 + 2) * 1024;
+  static bool attr_set = false;
+  auto kern = rowgemm_xattn_kernel<K, NW>;
+  if (!attr_set && !g_dry_run) {
+    MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const int rows = NW * 32;
+  MG_LAUNCH(kern, dim3((a.M + rows - 1) / rows), dim3(NW * 64), LDS, s, a);
+  return 0;
 }
 
 template <int K, int NW, int EPI, bool LN, bool GN, bool RES, bool LNO>
@@ -357,7 +529,22 @@ int mg_launch_rowgemm(const mg_op* op, hipStream_t s) {
     static const int erf_ab = [] { const char* e = getenv("MARIGOLD_GELU_ERF"); return (e && e[0] == '1') ? 1 : 0; }();
     a.gelu_erf = erf_ab;
   }
-  MG_REQUIRE(epi >= RG_BF16 && epi <= RG_QKV, "rowgemm: unknown epilogue %d", epi);
+  MG_REQUIRE(epi >= RG_BF16 && epi <= RG_XATTN, "rowgemm: unknown form %d", epi);
+  if (epi == RG_XATTN) {
+    RgXArgs x;
+    x.x = a.x; x.wp = a.wp; x.out = a.out; x.ln_in = a.ln_in; x.ln_out = a.ln_out;
+    x.M = a.M; x.ldx = a.ldx; x.ldo = op->i[4] > 0 ? op->i[4] : K; x.sm_cols = op->i[11];
+    x.sm_scale = op->f[1]; x.ln_eps = a.ln_eps; x.inv_n = 1.0 / (double)K;
+    MG_REQUIRE(x.x && x.wp && x.out && x.ln_in, "rowgemm: the cross-attention form needs x, packed weights, out and the (mean, rstd) table of x");
+    MG_REQUIRE(K == 320 && a.N == 64, "rowgemm: the cross-attention form is instantiated for K = c2 = 320 and 64 score columns (got K %d, N %d)", K, a.N);
+    MG_REQUIRE(x.M >= 32 && x.M % 32 == 0 && x.ldx >= K && x.ldx % 8 == 0 && x.ldo >= K && x.ldo % 8 == 0, "rowgemm: rows / leading dimensions");
+    MG_REQUIRE(x.sm_cols > 0 && x.sm_cols % 2 == 0 && x.sm_cols <= 64, "rowgemm: score columns (2 per head, <= 64)");
+    MG_REQUIRE((uintptr_t)x.x % 16 == 0 && (uintptr_t)x.wp % 16 == 0 && (uintptr_t)x.out % 16 == 0 && (uintptr_t)x.ln_in % 8 == 0 &&
+               (!x.ln_out || (uintptr_t)x.ln_out % 8 == 0), "rowgemm: alignment");
+    if (nw == 12) return rg_launch_xattn<320, 12>(x, s);
+    if (nw == 8) return rg_launch_xattn<320, 8>(x, s);
+    MG_REQUIRE(false, "rowgemm: %d waves per workgroup is not instantiated for the cross-attention form (8, 12)", nw);
+  }
   MG_REQUIRE(a.x && a.wp && a.out, "rowgemm: null pointer (x, packed weights, out)");
   MG_REQUIRE(K == 320, "rowgemm: K = %d is not instantiated (320)", K);
   MG_REQUIRE(a.M >= 32 && a.M % 32 == 0, "rowgemm: M = %d must be a multiple of 32 (a wave owns 32 whole rows)", a.M);

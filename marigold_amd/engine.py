@@ -187,6 +187,16 @@ class WeightStore:
             return Wm.pack_rowgemm(wp.float(), c, g).to(self.device)
         return self._memo(("rg_gg_ln", name), f)
 
+    def rg_cross_ln(self, prefix, ctx, heads, norm):
+        def f():
+            wqk, vot, npad = Wm.cross_attention_tables(
+                self.sd[f"{prefix}.to_q.weight"], self.sd[f"{prefix}.to_k.weight"],
+                self.sd[f"{prefix}.to_v.weight"], self.sd[f"{prefix}.to_out.0.weight"], ctx, heads)
+            assert npad == 64
+            wp, g, c = Wm.fold_layernorm(wqk, None, *self._ln(norm))
+            return Wm.pack_rowgemm_xattn(wp.float(), c, g, vot, self.sd[f"{prefix}.to_out.0.bias"].float()).to(self.device)
+        return self._memo(("rg_x_ln", prefix), f)
+
     def cross_ln(self, prefix, ctx, heads, norm):
         def f():
             wqk, vot, npad = Wm.cross_attention_tables(
@@ -537,6 +547,12 @@ class Builder:
         """h += attn2(LN(h), ctx) with the 2-token context collapsed into two thin GEMMs and the LayerNorm folded into
         the first one."""
         C, M = h.C, h.M
+        if st is not None and st_out is not None and XATTN_FUSED and 2 * heads <= 64 and self.rowgemm_ok(h):
+            # the same single launch in the row-resident form: the residual stream is read once (registers) and written once
+            self.add(O.rowgemm(h.t, self.ws.rg_cross_ln(prefix, ctx, heads, norm), h.t, M=M, K=C, N=64, form=L.RG_XATTN,
+                               ln_in=self.ln_mean_rstd(st, M, C), ln_out=self.ln_mean_rstd(st_out, M, C),
+                               sm_cols=2 * heads, sm_scale=1.0 / math.sqrt(C // heads)), f"{prefix}.scores+softmax2+blend")
+            return
         if st is not None:
             # ONE launch: scores GEMM with the LayerNorm folded in, the 2-key softmax on its accumulators, the probabilities
             # as the register operand of the blend GEMM (x the context's values pushed through to_out), + bias + residual,

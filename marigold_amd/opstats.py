@@ -45,6 +45,9 @@ def op_cost(op):
         M, K, N, form = i[0], i[1], i[2], i[6]
         flops = 2 * M * N * K
         byts = M * K * 2 + N * K * 2 + M * (N // 2 if form == L.RG_GEGLU else N) * 2 + (M * N * 2 if op.p[3] else 0)
+        if form == L.RG_XATTN:   # + P [M][64] x VO^T [K][64]; x read once, out [M][K] written once
+            flops += 2 * M * K * N
+            byts = 2 * M * K * 2 + 2 * N * K * 2
     elif k == L.OP_CONV3X3:
         B, H, W, C0, C1, N, subpix = (i[j] for j in range(7))
         Cin, par, T = C0 + C1, (4 if subpix else 1), (4 if subpix else 9)

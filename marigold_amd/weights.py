@@ -123,15 +123,14 @@ def _rg_chan():
 def pack_rowgemm(w, cb, lg=None):
     """w [N][K] (rows in the order the kernel's channels take: stage j = rows 64 j .. 64 j + 63, tile 0 its first 32) ->
     uint8 [N/64][(2 K/16 + 1) * 1024]: per stage 2 x K/16 fragments of 1 KB - fragment (tile t, K step s), lane l = 32 g + mm,
-    8 bf16: w[64 j + 32 t + chan(mm)][K/2 g + 8 s + 0..7] (the kernel's permuted reduction order: lane half g owns the
-    contiguous K range [K/2 g, K/2 (g + 1))) - and a 1 KB trailer: fp32 [64] per-channel constants ``cb`` (bias, + the folded
+    8 bf16: w[64 j + 32 t + chan(mm)][16 s + 8 g + 0..7] (the MFMA's own K order) - and a 1 KB trailer: fp32 [64] per-channel constants ``cb`` (bias, + the folded
     LayerNorm's c), fp32 [64] ``lg`` (the folded LayerNorm's g; zeros without), zero padding."""
     n, k = w.shape
     assert n % 64 == 0 and k % 32 == 0
     nst, ks = n // 64, k // 16
     wb = w.detach().float().cpu().to(torch.bfloat16).contiguous()
-    wv = wb.view(nst, 2, 32, 2, ks, 8)[:, :, _rg_chan()]          # [j][t][mm][g][s][i]
-    frag = wv.permute(0, 1, 4, 3, 2, 5).contiguous()              # [j][t][s][g][mm][i] = 1 KB per (j, t, s)
+    wv = wb.view(nst, 2, 32, ks, 2, 8)[:, :, _rg_chan()]          # [j][t][mm][s][g][i]
+    frag = wv.permute(0, 1, 3, 4, 2, 5).contiguous()              # [j][t][s][g][mm][i] = 1 KB per (j, t, s)
     frag = frag.view(torch.uint8).reshape(nst, 2 * ks * 1024)
     trl = torch.zeros(nst, 256, dtype=torch.float32)
     trl[:, :64] = cb.detach().float().cpu().reshape(nst, 64)
@@ -147,3 +146,17 @@ def rowgemm_geglu_order(n2):
     j = torch.arange(h // 32)[:, None]
     r = torch.arange(32)[None, :]
     return torch.cat([32 * j + r, h + 32 * j + r], dim=1).reshape(-1)
+
+
+def pack_rowgemm_xattn(wqk, c, g, vot, bias):
+    """MG_OP_ROWGEMM form RG_XATTN: [scores stage = pack_rowgemm(Wqk with the LayerNorm folded in [64][K], c, g)] followed by the
+    second GEMM's weights VO^T [c2][64] as c2/64 sub-stages of 2 tiles x 4 K steps (fragment (jj, t, s), lane 32 g + mm:
+    vot[64 jj + 32 t + chan(mm)][16 s + 8 g .. + 8]) and 2 KB of fp32 bias [c2]."""
+    c2 = vot.shape[0]
+    assert wqk.shape[0] == 64 and vot.shape[1] == 64 and c2 % 64 == 0 and c2 * 4 <= 2048
+    s0 = pack_rowgemm(wqk, c, g).reshape(-1)
+    vb = vot.detach().float().cpu().to(torch.bfloat16).contiguous()
+    fr = vb.view(c2 // 64, 2, 32, 4, 2, 8)[:, :, _rg_chan()].permute(0, 1, 3, 4, 2, 5).contiguous().view(torch.uint8).reshape(-1)
+    tr = torch.zeros(512, dtype=torch.float32)
+    tr[:c2] = bias.detach().float().cpu()
+    return torch.cat([s0, fr, tr.view(torch.uint8)]).contiguous()

@@ -592,6 +592,38 @@ def test_rowgemm_all_forms(dev, waves):
     assert torch.equal(hid, hid2)
 
 
+@pytest.mark.parametrize("waves", [12, 8])
+def test_rowgemm_fused_cross_attention(dev, waves):
+    """MG_OP_ROWGEMM form RG_XATTN (the collapsed 2-token cross-attention, in place on the residual stream) against the
+    unfused fp32 chain: LayerNorm -> scores -> pair softmax -> x VO^T + bias + residual, and the new rows' statistics."""
+    from marigold_amd import _lib as L, ops, weights as Wm
+    g = torch.Generator().manual_seed(41 + waves)
+    M, C, heads = 2112, 320, 5
+    x = _bf(torch.randn(M, C, generator=g) * 0.9 + 0.3 * torch.randn(M, 1, generator=g))
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    ctx = torch.randn(2, 1024, generator=g)
+    wq, wo = torch.randn(C, C, generator=g) / math.sqrt(C), torch.randn(C, C, generator=g) / math.sqrt(C)
+    wk, wv = torch.randn(C, 1024, generator=g) / 32, torch.randn(C, 1024, generator=g) / 32
+    bo = 0.1 * torch.randn(C, generator=g)
+    # reference: diffusers Attention with the 2-token context, fp32
+    y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    q = (y @ wq.t()).view(M, heads, C // heads)
+    k = (ctx @ wk.t()).view(2, heads, C // heads)
+    v = (ctx @ wv.t()).view(2, heads, C // heads)
+    p = torch.softmax(torch.einsum("mhd,jhd->mhj", q, k) / math.sqrt(C // heads), dim=-1)
+    ref = torch.einsum("mhj,jhd->mhd", p, v).reshape(M, C) @ wo.t() + bo + x
+    wqk, vot, npad = Wm.cross_attention_tables(wq, wk, wv, wo, ctx, heads)
+    wp, lg, lc = Wm.fold_layernorm(wqk, None, gamma, beta)
+    pk = Wm.pack_rowgemm_xattn(wp.float(), lc, lg, vot, bo).to(dev)
+    stx = torch.stack([x.mean(-1), 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5)], dim=-1).to(dev).contiguous()
+    h = x.to(dev, torch.bfloat16).clone()
+    so = torch.full((M, 2), float("nan"), device=dev)
+    _run(ops.rowgemm(h, pk, h, M=M, K=C, N=64, form=L.RG_XATTN, ln_in=stx, ln_out=so, sm_cols=2 * heads,
+                     sm_scale=1.0 / math.sqrt(C // heads), waves=waves))
+    _close(f"rowgemm/xattn/{waves}w", h, ref)
+    _close(f"rowgemm/xattn/stats/{waves}w", so, torch.stack([ref.mean(-1), 1.0 / torch.sqrt(ref.var(-1, unbiased=False) + 1e-5)], -1), tol=2e-3)
+
+
 def test_rowgemm_rejects_shapes_outside_its_contract(dev):
     from marigold_amd import _lib as L, ops, weights as Wm
     x = torch.zeros(64, 320, device=dev, dtype=torch.bfloat16)

@@ -739,7 +739,7 @@ def test_pingpong_gemm_schedule_model():
 
 
 def test_rowgemm_weight_packing():
-    """weights.pack_rowgemm: fragment (stage j, tile t, K step s), lane l = 32 g + mm holds w[64 j + 32 t + chan(mm)][K/2 g + 8 s .. + 8]
+    """weights.pack_rowgemm: fragment (stage j, tile t, K step s), lane l = 32 g + mm holds w[64 j + 32 t + chan(mm)][16 s + 8 g .. + 8]
     (csrc/rowgemm.hip's operand order); the trailer holds the stage's per-channel constants; the GEGLU row order pairs
     32 value rows with their 32 gate rows."""
     import torch
@@ -758,7 +758,7 @@ def test_rowgemm_weight_packing():
         for t in range(2):
             for mm in range(32):
                 for h in range(2):
-                    assert torch.equal(fr[j, t, :, h, mm, :].reshape(-1), wb[64 * j + 32 * t + chan[mm], k // 2 * h: k // 2 * (h + 1)])
+                    assert torch.equal(fr[j, t, :, h, mm, :], wb[64 * j + 32 * t + chan[mm]].view(ks, 2, 8)[:, h])
     tr = pk[:, 2 * ks * 1024:].contiguous().view(torch.float32)
     assert torch.equal(tr[:, :64].reshape(-1), cb) and torch.equal(tr[:, 64:128].reshape(-1), lg) and not tr[:, 128:].any()
     order = Wm.rowgemm_geglu_order(512)

@@ -144,3 +144,32 @@ r = y[:, :H] * torch.nn.functional.gelu(y[:, H:])
 e = err(hid[: xs.shape[0]], r)
 report("geglu+LN", us, us_old, 2 * M * 2 * H * C, (M * C + M * H) * 2, e)
 print(f"             vs igemm: differing {int((hid != hid2).sum())} of {hid.numel()}, max |d| {float((hid.float() - hid2.float()).abs().max()):.3e}")
+
+# ---- collapsed cross-attention, in place --------------------------------------------------------------------------------
+heads = 5
+ctx = rnd(2, 1024)
+wq2, wo2 = rnd(C, C, s=1 / math.sqrt(C)), rnd(C, C, s=1 / math.sqrt(C))
+wk2, wv2 = rnd(C, 1024, s=1 / 32), rnd(C, 1024, s=1 / 32)
+wqk, vot, npad = Wm.cross_attention_tables(wq2, wk2, wv2, wo2, ctx, heads)
+wpx, lgx, lcx = Wm.fold_layernorm(wqk, None, gamma, beta)
+pk = Wm.pack_rowgemm_xattn(wpx.float(), lcx, lgx, vot, bo).to(dev)
+us = {}
+for w in [v for v in WAVES if v in (12, 8)]:
+    hx = xd.clone(); so = torch.zeros(M, 2, device=dev)
+    op = O.rowgemm(hx, pk, hx, M=M, K=C, N=64, form=L.RG_XATTN, ln_in=st, ln_out=so, sm_cols=2 * heads, sm_scale=1 / math.sqrt(C // heads), waves=w)
+    us[w] = t(lambda: O.launch(op))
+hx = xd.clone(); so = torch.zeros(M, 2, device=dev)
+O.launch(O.rowgemm(hx, pk, hx, M=M, K=C, N=64, form=L.RG_XATTN, ln_in=st, ln_out=so, sm_cols=2 * heads, sm_scale=1 / math.sqrt(C // heads), waves=12))
+torch.cuda.synchronize()
+h2 = xd.clone(); so2 = torch.zeros(M, 2, device=dev)
+wpx_d, lgx_d, lcx_d, vot_d = wpx.to(dev), lgx.to(dev), lcx.to(dev), vot.to(dev, torch.bfloat16)
+op_old = O.linear(h2, wpx_d, h2, M=M, K=C, N=64, epi=L.EPI_XATTN2, ln_in=st, ln_g=lgx_d, ln_c=lcx_d, sm_scale=1 / math.sqrt(C // heads),
+                  sm_cols=2 * heads, out2=vot_d, c2=C, ldo=C, bias=bo_d, residual=h2, ldr=C, ln_out=so2)
+O.launch(op_old); torch.cuda.synchronize()
+d = int((hx != h2).sum())
+h3 = xd.clone()
+op_t = O.linear(h3, wpx_d, h3, M=M, K=C, N=64, epi=L.EPI_XATTN2, ln_in=st, ln_g=lgx_d, ln_c=lcx_d, sm_scale=1 / math.sqrt(C // heads),
+                sm_cols=2 * heads, out2=vot_d, c2=C, ldo=C, bias=bo_d, residual=h3, ldr=C, ln_out=so2)
+us_old = t(lambda: O.launch(op_t))
+report("xattn", us, us_old, 2 * M * C * 64 * 2, 2 * M * C * 2, (float("nan"), float("nan")))
+print(f"             vs igemm XATTN2: differing {d} of {hx.numel()}, max |d| {float((hx.float() - h2.float()).abs().max()):.3e}, stats max |d| {float((so - so2).abs().max()):.3e}")
