@@ -94,7 +94,8 @@ enum mg_op_kind {
    *  i: M, K, N, ldx, ldo, ldr, form (0 bias [+ residual] [+ row statistics], 1 GEGLU: stage = 32 value + 32 gate
    *  channels, out [M][N/2], 2 QKV: columns >= i[9] go to V^T in MG_OP_FLASH_ATTN64's permuted key order), i[7] tokens per
    *  image (forms with p[6] / p[7]; % 32 == 0), i[8] ldt, i[9] first V column (% 64 == 0), i[10] waves per workgroup
-   *  (0 = 12; 4 / 8 / 12) ; f[0] LayerNorm eps of p[5].
+   *  (0 = 12; 4 / 8 / 12), i[12] column split (0 / 1 = none; n: the N / 64 stages are shared out over n workgroups per row
+   *  block - few rows, many columns; not with p[5]) ; f[0] LayerNorm eps of p[5].
    *  form 3: the collapsed 2-token cross-attention (as MG_EPI_XATTN2) in place on the residual stream: N = 64 score
    *  columns, i[11] = 2 x heads of them live, f[1] softmax scale; p[1] = weights.pack_rowgemm_xattn (scores stage + VO^T
    *  fragments + bias), p[4] required, out[M][K] = P VO^T + bias + x, p[5] its row statistics; out may alias x. */

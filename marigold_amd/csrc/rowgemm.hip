@@ -52,9 +52,13 @@ struct RgArgs {
   float ln_eps;
   double inv_n;
   int gelu_erf;
+  int prio;
+  int spl;              // stages per workgroup (N / 64 unless the columns are split over gridDim.y)
+  unsigned long long* dbg;   // tuning only: per-wave phase cycles [wave-tiles][4] (wait+barrier, issue, MFMA, epilogue) | NULL
 };
 
-enum { RG_BF16 = 0, RG_GEGLU = 1, RG_QKV = 2, RG_XATTN = 3 };
+enum { RG_BF16 = 0, RG_GEGLU = 1, RG_QKV = 2, RG_XATTN = 3,
+       RG_GEGLU_ERF = 5 /* template value only: GEGLU through the erf form (MARIGOLD_GELU_ERF=1 A/B runs) */ };
 
 // The stage trailer (per-channel constants) is read with hand-placed LDS instructions: hipcc's waitcnt pass makes every LDS
 // load it can see wait for ALL outstanding LDS-DMA (vmcnt(0)) - in the middle of the stage that would drain the weight
@@ -78,6 +82,25 @@ __device__ __forceinline__ void rg_lgk0(f32x4& a, f32x4& b, f32x4& c, f32x4& d) 
 __device__ __forceinline__ void rg_lgk0(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void rg_lgk0(float& a, float& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 
+template <int OFF>
+__device__ __forceinline__ bf16x8 rg_ldsw(uint32_t addr) {   // one weight fragment
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// <= N of this wave's LDS reads still in flight (they return in order); the operands tie their consumers behind the wait
+template <int N>
+__device__ __forceinline__ void rg_lgk(bf16x8& a, bf16x8& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void rg_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    rg_static_for<I + 1, N>(f);
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void rg_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -90,7 +113,8 @@ void rowgemm_kernel(const RgArgs a) {
   // a stage = 2 tiles x KS fragments of 1 KB + one 1 KB trailer: fp32 [64] per-channel constants, [64] folded-LayerNorm g
   constexpr int KS = K / 16, PIECES = 2 * KS + 1, STAGE = PIECES * 1024, NSTAGE = 3, TRL = 2 * KS * 1024;
   constexpr int NWMIN = PIECES / NW, NWREM = PIECES - NWMIN * NW;   // LDS-DMA pieces per wave and stage: NWMIN (+1 for waves < NWREM)
-  constexpr int S = (EPI == RG_GEGLU) ? 2 : 4;             // stores per stage epilogue
+  constexpr bool GEGLU = EPI == RG_GEGLU || EPI == RG_GEGLU_ERF;
+  constexpr int S = GEGLU ? 2 : 4;                         // stores per stage epilogue
   constexpr int XW = NWMIN + S + (RES ? 4 : 0);            // operations younger than stage j's pieces that may stay in flight
   static_assert(K % 32 == 0 && NWMIN >= 1, "geometry");
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -100,7 +124,17 @@ void rowgemm_kernel(const RgArgs a) {
   const bool active = row0 < a.M;
   if (!active) row0 = a.M - 32;
   const int m = row0 + l31;
-  const int nst = a.N >> 6;
+  // this workgroup's stages [j0, nst): all N / 64 of them, or - few rows, many columns - one of gridDim.y column ranges
+  const int j0 = blockIdx.y * a.spl;
+  const int nst = (a.N >> 6) < j0 + a.spl ? (a.N >> 6) : j0 + a.spl;
+  // The three waves of a SIMD (wave, wave + 4, wave + 8) leave every stage barrier together; with equal priority their
+  // MFMA phases interleave and end together, and then all three run their VALU epilogues with the matrix pipe idle.  Fixed,
+  // distinct priorities serialise the MFMA phases instead: the first wave's epilogue runs under the second wave's MFMAs.
+  if (a.prio) {
+    if (wave < 4) __builtin_amdgcn_s_setprio(3);
+    else if (wave < 8) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
+  }
 
   auto issue = [&](int j, int slot) {
     const char* src = a.wp + (long long)j * STAGE + lane * 16;
@@ -109,8 +143,8 @@ void rowgemm_kernel(const RgArgs a) {
     for (int i = 0; i < NWMIN; ++i) glds16(src + (wave + i * NW) * 1024, dst + (wave + i * NW) * 1024);
     if (wave < NWREM) glds16(src + (wave + NWMIN * NW) * 1024, dst + (wave + NWMIN * NW) * 1024);
   };
-  issue(0, 0);
-  if (nst > 1) issue(1, 1);
+  issue(j0, 0);
+  if (j0 + 1 < nst) issue(j0 + 1, 1);
 
   // the wave's 32 rows of x: K step s -> x[m][16 s + 8 half .. + 8] (the MFMA's own K order)
   bf16x8 xf[KS];
@@ -147,7 +181,7 @@ void rowgemm_kernel(const RgArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) rres[g] = *(const uint4*)(pr + j * 64 + g * 16);
   };
-  if constexpr (RES) load_res(0);
+  if constexpr (RES) load_res(j0);
   // V^T: image b, first token of the wave's tile; lane = channel chan(l31) of a tile, registers = tokens
   bf16_t* pvt = nullptr;
   if constexpr (EPI == RG_QKV) {
@@ -162,39 +196,61 @@ void rowgemm_kernel(const RgArgs a) {
   // body with a branch, hipcc hoists the (identical) fragment reads of both arms above it - 160 live registers of fragments.
   auto stage = [&](int j, auto vsec_tag) {
     constexpr bool vsec = decltype(vsec_tag)::value;
+    const unsigned long long d0 = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     if (active) {
       if (j + 1 < nst) rg_wait_vmcnt<XW>(); else rg_wait_vmcnt<XW - NWMIN>();
     } else {   // nothing but weight pieces in this wave's queue
       if (j + 1 < nst) rg_wait_vmcnt<NWMIN>(); else rg_wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
+    const unsigned long long d1 = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     if (j + 2 < nst) issue(j + 2, slot_i);
     if (!active) {
       slot = slot == NSTAGE - 1 ? 0 : slot + 1;
       slot_i = slot_i == NSTAGE - 1 ? 0 : slot_i + 1;
       return;
     }
-    const char* const sb = smem + slot * STAGE + lane * 16;
     // fp32 [64] constants, [64] g of this stage; + this lane's first channel (8 half; the V^T section: chan(l31))
     const uint32_t tcb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + (uint32_t)(slot * STAGE + TRL);
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const bf16x8 w0 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + s * 1024));
-      const bf16x8 w1 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + (KS + s) * 1024));
-      if constexpr (!vsec) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s], acc1, 0, 0, 0);
-      } else {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w1, acc1, 0, 0, 0);
-      }
+    // The fragment reads run PD K steps ahead of their MFMAs, hand-placed with counted lgkmcnt waits: hipcc keeps one or two
+    // in flight, which leaves the phase bound by LDS latency (2 700 cycles for 1 280 cycles of MFMAs: r3_rowgemm_phase_cycles.log)
+    {
+      constexpr int PD = RES ? (LNO ? 1 : 2) : 3, PR = PD + 1;   // (the residual forms hold 16-22 more registers)
+      const uint32_t fb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + (uint32_t)(slot * STAGE + lane * 16);
+      bf16x8 w0[PR], w1[PR];
+      rg_static_for<0, PD>([&](auto it) {
+        constexpr int s = decltype(it)::value;
+        w0[s] = rg_ldsw<s * 1024>(fb);
+        w1[s] = rg_ldsw<(KS + s) * 1024>(fb);
+      });
+      rg_static_for<0, KS>([&](auto it) {
+        constexpr int s = decltype(it)::value;
+        if constexpr (s + PD < KS) {
+          w0[(s + PD) % PR] = rg_ldsw<(s + PD) * 1024>(fb);
+          w1[(s + PD) % PR] = rg_ldsw<(KS + s + PD) * 1024>(fb);
+        }
+        constexpr int ahead = (KS - 1 - s) < PD ? (KS - 1 - s) : PD;
+        rg_lgk<2 * ahead>(w0[s % PR], w1[s % PR]);
+        if constexpr (!vsec) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[s % PR], xf[s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[s % PR], xf[s], acc1, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w0[s % PR], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w1[s % PR], acc1, 0, 0, 0);
+        }
+      });
     }
     // ---- the stage's 32 rows x 64 channels, in registers ----
     __builtin_amdgcn_sched_barrier(0);   // fragment registers are dead before the epilogue's temporaries go live
-    if constexpr (EPI == RG_GEGLU) {
+    unsigned long long d2 = 0ull;
+    if (a.dbg) {
+      asm volatile("s_nop 0" : "+v"(acc0), "+v"(acc1));
+      d2 = __builtin_amdgcn_s_memtime();
+    }
+    if constexpr (GEGLU) {
       // tile 0 = 32 value channels, tile 1 = their gates (weights.pack_rowgemm_geglu); out column = 32 j + channel
       uint4 pk[2];
 #pragma unroll
@@ -212,7 +268,7 @@ void rowgemm_kernel(const RgArgs a) {
           for (int i = 0; i < 8; ++i) {
             const float av = t == 0 ? acc0[8 * q + i] : acc1[8 * q + i];
             const float v = __builtin_fmaf(av, l_sc, LN ? __builtin_fmaf(l_mr, gg[i], cc[i]) : cc[i]);
-            if (t == 1) o[i] = a.gelu_erf ? gelu_erf_f(v) : gelu_poly_f(v);
+            if (t == 1) o[i] = EPI == RG_GEGLU_ERF ? gelu_erf_f(v) : gelu_poly_f(v);
             else o[i] = v * o[i];
           }
         }
@@ -285,15 +341,20 @@ void rowgemm_kernel(const RgArgs a) {
       // the next stage's residual rows: behind this stage's stores, ahead of the next weight prefetch in the vmcnt queue
       if constexpr (RES) { if (j + 1 < nst) load_res(j + 1); }
     }
+    if (a.dbg && lane == 0) {
+      const unsigned long long d3 = __builtin_amdgcn_s_memtime();
+      unsigned long long* o = a.dbg + (long long)(blockIdx.x * NW + wave) * 4;
+      o[0] += d1 - d0; o[1] += d2 - d1; o[2] += d3 - d2; o[3] += 1;
+    }
     slot = slot == NSTAGE - 1 ? 0 : slot + 1;
     slot_i = slot_i == NSTAGE - 1 ? 0 : slot_i + 1;
   };
   if constexpr (EPI == RG_QKV) {
     const int nq = a.trans_stage < nst ? a.trans_stage : nst;
-    for (int j = 0; j < nq; ++j) stage(j, std::false_type{});
-    for (int j = nq; j < nst; ++j) stage(j, std::true_type{});
+    for (int j = j0; j < nq; ++j) stage(j, std::false_type{});
+    for (int j = nq > j0 ? nq : j0; j < nst; ++j) stage(j, std::true_type{});
   } else {
-    for (int j = 0; j < nst; ++j) stage(j, std::false_type{});
+    for (int j = j0; j < nst; ++j) stage(j, std::false_type{});
   }
   if constexpr (LNO) {   // (mean, rstd) of the new rows: the wave holds them whole (fp64 only for E[x^2] - mean^2)
     sd += __shfl_xor(sd, 32);
@@ -474,7 +535,7 @@ int rg_launch(const RgArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int rows = NW * 32;
-  MG_LAUNCH(kern, dim3((a.M + rows - 1) / rows), dim3(NW * 64), LDS, s, a);
+  MG_LAUNCH(kern, dim3((a.M + rows - 1) / rows, ((a.N >> 6) + a.spl - 1) / a.spl), dim3(NW * 64), LDS, s, a);
   return 0;
 }
 
@@ -483,6 +544,7 @@ int rg_dispatch(const RgArgs& a, int epi, hipStream_t s) {
   const bool ln = a.ln_in != nullptr, gn = a.gn_ss != nullptr, res = a.res != nullptr, lno = a.ln_out != nullptr;
   if (epi == RG_GEGLU) {
     MG_REQUIRE(!gn && !res && !lno, "rowgemm: the GEGLU form takes no GroupNorm input / residual / row statistics");
+    if (a.gelu_erf) return ln ? rg_launch<K, NW, RG_GEGLU_ERF, true, false, false, false>(a, s) : rg_launch<K, NW, RG_GEGLU_ERF, false, false, false, false>(a, s);
     return ln ? rg_launch<K, NW, RG_GEGLU, true, false, false, false>(a, s) : rg_launch<K, NW, RG_GEGLU, false, false, false, false>(a, s);
   }
   if (epi == RG_QKV) {
@@ -523,11 +585,20 @@ int mg_launch_rowgemm(const mg_op* op, hipStream_t s) {
   a.ln_out = (float2*)op->p[5];
   a.vt = (bf16_t*)op->p[6];
   a.gn_ss = (const float*)op->p[7];
+  a.dbg = (unsigned long long*)op->p[8];
   a.inv_n = 1.0 / (double)(a.N > 0 ? a.N : 1);
   a.trans_stage = epi == RG_QKV ? trans_from / 64 : (1 << 30);
   {
     static const int erf_ab = [] { const char* e = getenv("MARIGOLD_GELU_ERF"); return (e && e[0] == '1') ? 1 : 0; }();
     a.gelu_erf = erf_ab;
+    static const int prio_ab = [] { const char* e = getenv("MARIGOLD_ROWGEMM_PRIO"); return (e && e[0] == '0') ? 0 : 1; }();
+    a.prio = prio_ab;
+  }
+  {
+    const int nsplit = op->i[12] > 1 ? op->i[12] : 1, nst = a.N >> 6;
+    a.spl = (nst + nsplit - 1) / nsplit;
+    if (a.spl < 2 && nst >= 2) a.spl = 2;   // (the weight ring is primed two stages deep)
+    MG_REQUIRE(nsplit == 1 || !a.ln_out, "rowgemm: row statistics need whole rows in one workgroup (no column split)");
   }
   MG_REQUIRE(epi >= RG_BF16 && epi <= RG_XATTN, "rowgemm: unknown form %d", epi);
   if (epi == RG_XATTN) {

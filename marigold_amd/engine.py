@@ -28,7 +28,7 @@ XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed c
 GN_SLAB = os.environ.get("MARIGOLD_GN_SLAB", "1") != "0"           # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 FLASH_VT_PERM = os.environ.get("MARIGOLD_FLASH_VT_PERM", "1") != "0"   # permuted V^T + generation-3 attention (0: generation 2)
 ROWGEMM = os.environ.get("MARIGOLD_ROWGEMM", "1") != "0"           # row-resident GEMM (MG_OP_ROWGEMM) for the K = 320 token-local layers
-ROWGEMM_MIN_M = int(os.environ.get("MARIGOLD_ROWGEMM_MIN_M", str(120 * 384)))   # below: too few 384-row workgroups for the chip
+ROWGEMM_MIN_M = int(os.environ.get("MARIGOLD_ROWGEMM_MIN_M", "9216"))   # below: the tile GEMM (one 96 x 96 member is 72 128-row workgroups)
 
 
 class Act:
@@ -263,6 +263,21 @@ class Builder:
         keeps 32 rows x 320 channels in 80 registers); whole 32-row tiles inside an image (the V^T section and the folded
         GroupNorm are per image), enough 384-row workgroups for the chip, and the permuted V^T the QKV form writes."""
         return ROWGEMM and FLASH_VT_PERM and x.C == 320 and x.HW % 32 == 0 and x.M >= ROWGEMM_MIN_M
+
+    @staticmethod
+    def rowgemm_cfg(M, N, whole_rows=False, xattn=False):
+        """-> dict(waves=, nsplit=) of an MG_OP_ROWGEMM launch: 12 waves (384 rows) per workgroup when that still gives the
+        chip >= 160 workgroups, else 8, else 4 with the N / 64 column stages shared out over several workgroups per row
+        block (not for the forms that take whole-row statistics) - measured per ensemble size,
+        profiles/r3_rowgemm_small_batch.log."""
+        if M >= 160 * 384:
+            return dict(waves=12)
+        if M >= 120 * 256 or xattn:
+            return dict(waves=8)
+        if whole_rows:
+            return dict(waves=4)
+        nwg = -(-M // 128)
+        return dict(waves=4, nsplit=max(1, min(N // 128, round(300 / nwg))))
 
     def gn_slab_ok(self, srcs, apply):
         """One-launch GroupNorm (MG_OP_GN_SLAB: a workgroup owns whole groups of an image over all rows)?  UNet-sized
@@ -520,7 +535,8 @@ class Builder:
         rg = perm and st is not None and self.rowgemm_ok(h)
         if rg:
             self.add(O.rowgemm(h.t, self.ws.rg_qkv_ln(prefix, norm), qk, M=M, K=C, N=3 * C, form=L.RG_QKV, ldo=2 * C,
-                               ln_in=self.ln_mean_rstd(st, M, C), vt=vt, tokens=T, ldt=ldvt, trans_from=2 * C), f"{prefix}.qkv")
+                               ln_in=self.ln_mean_rstd(st, M, C), vt=vt, tokens=T, ldt=ldvt, trans_from=2 * C,
+                               **self.rowgemm_cfg(M, 3 * C)), f"{prefix}.qkv")
         elif st is not None:
             wqkv, g, c = self.ws.qkv_ln(prefix, norm)
             self.add(O.igemm(h.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, out2=vt,
@@ -537,7 +553,7 @@ class Builder:
         self.free(qk)
         if rg and st_out is not None:
             self.add(O.rowgemm(o.t, self.ws.rg_mat(f"{prefix}.to_out.0"), h.t, M=M, K=C, N=C, residual=h.t,
-                               ln_out=self.ln_mean_rstd(st_out, M, C)), f"{prefix}.to_out")
+                               ln_out=self.ln_mean_rstd(st_out, M, C), **self.rowgemm_cfg(M, C, whole_rows=True)), f"{prefix}.to_out")
         else:
             self.dense(o, self.ws.mat(f"{prefix}.to_out.0"), self.ws.bias(f"{prefix}.to_out.0"), C,
                        residual=h, out=h, label=f"{prefix}.to_out", ln_out=st_out)
@@ -551,7 +567,8 @@ class Builder:
             # the same single launch in the row-resident form: the residual stream is read once (registers) and written once
             self.add(O.rowgemm(h.t, self.ws.rg_cross_ln(prefix, ctx, heads, norm), h.t, M=M, K=C, N=64, form=L.RG_XATTN,
                                ln_in=self.ln_mean_rstd(st, M, C), ln_out=self.ln_mean_rstd(st_out, M, C),
-                               sm_cols=2 * heads, sm_scale=1.0 / math.sqrt(C // heads)), f"{prefix}.scores+softmax2+blend")
+                               sm_cols=2 * heads, sm_scale=1.0 / math.sqrt(C // heads), **self.rowgemm_cfg(M, C, xattn=True)),
+                     f"{prefix}.scores+softmax2+blend")
             return
         if st is not None:
             # ONE launch: scores GEMM with the LayerNorm folded in, the 2-key softmax on its accumulators, the probabilities
@@ -601,7 +618,7 @@ class Builder:
                 ss = self.gn_scale_shift([x], f"{name}.norm", 1e-6)
             h = self.new(x.B, x.H, x.W, C)
             self.add(O.rowgemm(x.t, self.ws.rg_mat(f"{name}.proj_in"), h.t, M=x.M, K=C, N=C, gn_ss=ss, tokens=x.HW,
-                               ln_out=self.ln_mean_rstd(st[0], x.M, C)), f"{name}.proj_in")
+                               ln_out=self.ln_mean_rstd(st[0], x.M, C), **self.rowgemm_cfg(x.M, C, whole_rows=True)), f"{name}.proj_in")
             self.free(ss)
         else:
             g = self.group_norm(x, f"{name}.norm", 1e-6, False)
@@ -614,7 +631,7 @@ class Builder:
         if rg:
             ff = self.new(h.B, h.H, h.W, 4 * C)
             self.add(O.rowgemm(h.t, self.ws.rg_geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3"), ff.t, M=h.M, K=C, N=8 * C,
-                               form=L.RG_GEGLU, ln_in=self.ln_mean_rstd(st[2], h.M, C)), f"{b}.ff.geglu")
+                               form=L.RG_GEGLU, ln_in=self.ln_mean_rstd(st[2], h.M, C), **self.rowgemm_cfg(h.M, 8 * C)), f"{b}.ff.geglu")
         elif FOLD_LN:
             wg, gg, cg = self.ws.geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3")
             ff = self.dense(h, wg, None, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu",
@@ -630,7 +647,8 @@ class Builder:
         self.free(ff)
         # NB: the GEMM input must never alias its output (other column tiles still read it)
         if rg:
-            self.add(O.rowgemm(h.t, self.ws.rg_mat(f"{name}.proj_out"), x.t, M=h.M, K=C, N=C, residual=x.t), f"{name}.proj_out")
+            self.add(O.rowgemm(h.t, self.ws.rg_mat(f"{name}.proj_out"), x.t, M=h.M, K=C, N=C, residual=x.t,
+                               **self.rowgemm_cfg(h.M, C)), f"{name}.proj_out")
             out = x
         else:
             out = self.dense(h, self.ws.mat(f"{name}.proj_out"), self.ws.bias(f"{name}.proj_out"), C,

@@ -69,10 +69,10 @@ def conv3x3(a0, w, out, *, B, H, W, C0, N, a1=None, C1=0, subpix=False, ss=None,
 
 
 def rowgemm(x, wp, out, *, M, K, N, form=L.RG_BF16, ldx=0, ldo=0, ldr=0, residual=None, ln_in=None, ln_out=None, vt=None,
-            gn_ss=None, tokens=0, ldt=0, trans_from=0, waves=0, ln_eps=1e-5, sm_cols=0, sm_scale=0.0):
+            gn_ss=None, tokens=0, ldt=0, trans_from=0, waves=0, ln_eps=1e-5, sm_cols=0, sm_scale=0.0, dbg=None, nsplit=0):
     """Row-resident GEMM (MG_OP_ROWGEMM): ``wp`` from weights.pack_rowgemm (form RG_XATTN: pack_rowgemm_xattn)."""
-    return make_op(L.OP_ROWGEMM, i=[M, K, N, ldx, ldo, ldr, form, tokens, ldt, trans_from, waves, sm_cols], f=[ln_eps, sm_scale],
-                   p=[x, wp, out, residual, ln_in, ln_out, vt, gn_ss])
+    return make_op(L.OP_ROWGEMM, i=[M, K, N, ldx, ldo, ldr, form, tokens, ldt, trans_from, waves, sm_cols, nsplit], f=[ln_eps, sm_scale],
+                   p=[x, wp, out, residual, ln_in, ln_out, vt, gn_ss, dbg])
 
 
 def linear(x, w, out, *, M, K, N, **kw):

@@ -552,6 +552,10 @@ def test_rowgemm_all_forms(dev, waves):
     want_vt = ops.permute_vt_keys(ref[:, 2 * C:].view(B, T, C).transpose(1, 2).contiguous())
     _close(f"rowgemm/qkv/vt/{waves}w", vt[:, :, :T], want_vt, tol=2e-2)
     assert not vt[:, :, T:].any(), "V^T pad columns were written"
+    qk2, vt2 = nan_bf(M, 2 * C), torch.zeros_like(vt)
+    _run(ops.rowgemm(xd, pk, qk2, M=M, K=C, N=3 * C, form=L.RG_QKV, ldo=2 * C, ln_in=stx, vt=vt2, tokens=T, ldt=ldt, trans_from=2 * C,
+                     waves=waves, nsplit=4))
+    assert torch.equal(qk, qk2) and torch.equal(vt, vt2), "QKV with the columns split over 4 workgroups per row block"
 
     # to_out: bias + residual IN PLACE + (mean, rstd) of the new rows
     h0 = _bf(torch.randn(M, C, generator=g))
@@ -586,6 +590,11 @@ def test_rowgemm_all_forms(dev, waves):
     _run(ops.rowgemm(xd, pk, hid, M=M, K=C, N=8 * C, form=L.RG_GEGLU, ln_in=stx, waves=waves))
     u, gt = (y @ wg.t() + bg).chunk(2, dim=-1)
     _close(f"rowgemm/geglu/{waves}w", hid, u * F.gelu(gt), tol=2e-2)
+    # the column stages shared out over 3 / 7 workgroups per row block (few rows, many columns): same bits
+    for nsplit in (3, 7):
+        hs = nan_bf(M, 4 * C)
+        _run(ops.rowgemm(xd, pk, hs, M=M, K=C, N=8 * C, form=L.RG_GEGLU, ln_in=stx, waves=waves, nsplit=nsplit))
+        assert torch.equal(hid, hs), f"column split {nsplit}"
     # run-to-run bit stability (counted waits on the weight stream: a race would show as differing elements)
     hid2 = nan_bf(M, 4 * C)
     _run(ops.rowgemm(xd, pk, hid2, M=M, K=C, N=8 * C, form=L.RG_GEGLU, ln_in=stx, waves=waves))

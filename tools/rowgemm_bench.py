@@ -129,6 +129,14 @@ order = Wm.rowgemm_geglu_order(2 * H)
 wpo, lgo, lco = Wm.fold_layernorm(w1[order], b1[order], gamma, beta)
 pk = Wm.pack_rowgemm(wpo.float(), lco, lgo).to(dev)
 hid = torch.zeros(M, H, device=dev, dtype=torch.bfloat16)
+if os.environ.get("ROWGEMM_DBG"):   # where a wave's time goes, per stage (s_memtime stamps: wait + barrier | MFMA phase | epilogue)
+    for form, nm in ((L.RG_GEGLU, "geglu"),):
+        dbg = torch.zeros(M // 32, 4, device=dev, dtype=torch.int64)
+        O.launch(O.rowgemm(xd, pk, hid, M=M, K=C, N=2 * H, form=form, ln_in=st, dbg=dbg)); torch.cuda.synchronize()
+        d = dbg.cpu().double()
+        n = d[:, 3].clamp_min(1)
+        print(f"   {nm}: per stage and wave, cycles: wait+barrier {float((d[:, 0] / n).mean()):7.0f}  issue+MFMA {float((d[:, 1] / n).mean()):7.0f}  epilogue {float((d[:, 2] / n).mean()):7.0f}"
+              f"   (by wave of the workgroup, wait: {[int(v) for v in (d[:, 0] / n).view(-1, 12).mean(0)]}, MFMA: {[int(v) for v in (d[:, 1] / n).view(-1, 12).mean(0)]}, epi: {[int(v) for v in (d[:, 2] / n).view(-1, 12).mean(0)]})", flush=True)
 us = {}
 for w in WAVES:
     op = O.rowgemm(xd, pk, hid, M=M, K=C, N=2 * H, form=L.RG_GEGLU, ln_in=st, waves=w)
