@@ -366,6 +366,14 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
 //   all with the next tile's LDS-DMA pieces issued between the k-substeps' MFMA groups.
 int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
   if (N <= 32) return 29;
+  {
+    // The 12 x 12 level's 3x3 convolutions (M = 1 440 pixels at E = 10, K = 11 520 / 23 040): with 128 x 64 tiles every one
+    // of the 12 row tiles re-reads the 30-59 MB of weights; 256 x 256 tiles read them 6 times and split-K (30 tiles x 8
+    // splits) fills the chip: 77 -> 68 us (1280 -> 1280), 144 -> 105 us (2560 -> 1280), profiles/r3_deep_conv_tiles.log.
+    // MARIGOLD_DEEP_TILE=<variant> | 0 (off) for A/B runs.
+    static const int deep = [] { const char* e = getenv("MARIGOLD_DEEP_TILE"); return e ? atoi(e) : 62; }();
+    if (deep && !geglu && batch_z == 1 && M >= 1152 && M <= 2048 && K >= 5760 && N % 256 == 0) return deep;   // (E >= 8 at 12 x 12)
+  }
   const long long tm256 = (M + 255) / 256;
   // short K (GEGLU projections, K = C linears): 256x128 with 32-deep K tiles - half the LDS per stage,
   // two 8-wave workgroups per CU (GEGLU 525-780 vs 485-770 for 256x256 and 400-700 for the 64-deep tile)
