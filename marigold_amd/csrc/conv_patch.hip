@@ -24,6 +24,8 @@
 // tap outermost, so sums differ in the last fp32 bits only).
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -58,11 +60,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_patch_kernel(const ConvPAr
   constexpr int NPW = PRMAX / 8;                             // wave-pieces (64 lanes x 16 B = 8 rows) per patch
   constexpr int NSLOT = (NPW + NW - 1) / NW;                 // patch pieces per wave
   constexpr int PATCH = PRMAX * ROWB;
-  constexpr int B_IT = BN * 8 / NT;                          // weight pieces per wave and K step
+  constexpr int B_IT = (BN * 8 + NT - 1) / NT;               // weight pieces per wave and K step (the last one only for
+  constexpr bool B_EVEN = (BN * 8) % NT == 0;                // the first waves when the stage does not divide evenly)
   constexpr int BSTAGE = BN * ROWB;
   constexpr int D = NSTB - 1;
   constexpr int NFIX = (PRMAX * 8 + NT - 1) / NT;            // fix-up vectors per thread
-  static_assert(TW == 16 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0 && (BN * 8) % NT == 0, "tile geometry");
+  static_assert(TW == 16 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0 && (BN * 8) % 64 == 0, "tile geometry");
+  static_assert(B_EVEN || NSTB == 2, "an uneven weight stage needs the complete (vmcnt(0)) waits of the two-stage ring");
   static_assert(NSTB >= 2 && NSTB <= 3, "2 or 3 weight stages");
   static_assert((NT / 8) % 16 == 0, "the fix-up's channel group must not depend on the iteration");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -119,16 +123,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_patch_kernel(const ConvPAr
   };
 
   // ---- weight staging rows of this thread ----
-  const char* b_base[B_IT];
+  // (uneven stages - the 12 / 6-wave 320-channel tiles - keep ONE pointer: piece `it` is NT / 8 weight rows further on, the
+  // swizzle term (r >> 1) & 7 is the same for it * NT / 8 rows later (NT / 8 % 16 == 0), and N % BN == 0 is required)
+  const char* b_base[B_EVEN ? B_IT : 1];
 #pragma unroll
-  for (int it = 0; it < B_IT; ++it) {
+  for (int it = 0; it < (B_EVEN ? B_IT : 1); ++it) {
     const int ci = it * NT + tid;
     const int r = ci >> 3, p = ci & 7;
     const int n = n0 + r;
     b_base[it] = n < a.N ? (const char*)(Wb + (long long)n * a.ldw + (p ^ ((r >> 1) & 7)) * 8) : zero;
   }
+  const long long b_stride = (long long)(NT / 8) * a.ldw * 2;
   auto issue_b_piece = [&](int it, long long koff_bytes, int stage) {
-    glds16(b_base[it] + koff_bytes, ring + stage * BSTAGE + (it * NT + wave * 64) * 16);
+    if (!B_EVEN && it * NT + wave * 64 >= BN * 8) return;   // wave-uniform
+    long long bs = b_stride;
+    if constexpr (!B_EVEN) asm volatile("" : "+s"(bs));   // recomputed at the use: hoisted, the B_IT addresses are spilled (168-register budget)
+    const char* src = B_EVEN ? b_base[it] : b_base[0] + it * bs;
+    glds16(src + koff_bytes, ring + stage * BSTAGE + (it * NT + wave * 64) * 16);
   };
   auto koff_of = [&](int c, int t) { return ((long long)t * a.Cin + c * 64) * 2; };
 
@@ -367,8 +378,14 @@ int launch_patch(const ConvPArgs& a0, hipStream_t s) {
 // 8 waves (wave tile 128 x 64) where N is a multiple of 256 (VAE 512 / 256 channels: 1100-1130); 8 x 16 x 320 / 8 waves
 // (wave tile 32 x 160) for the 320-channel level (930-1050) and the 640-channel sub-pixel convolution; 16 x 16 x 128 /
 // 8 waves / 2 weight stages (wave tile 64 x 64) otherwise (N = 640: 990-1060, N = 128: 830-1020).
-int mg_conv3x3_auto_variant(int N, int subpix) {
+int mg_conv3x3_auto_variant(int N, int subpix, long long tiles12) {
   if (N % 256 == 0) return 1;
+  // (round 3) the 320-channel level on 12 x 16 pixel tiles / 12 waves when that still fills the chip: a K step streams the
+  // same 40 KB of weights for 192 instead of 128 pixels and three waves share a SIMD - 168 vs 198 us (320 -> 320), 311 vs 383
+  // (640 -> 320), 447 vs 524 (960 -> 320), with the fused GroupNorm 187 vs 222 (profiles/r3_conv_patch_12row_tiles.log)
+  static const int n320 = [] { const char* e = getenv("MARIGOLD_PATCH_N320"); return e ? atoi(e) : 0; }();   // A/B: force a variant
+  if (N == 320 && !subpix && n320) return n320;
+  if (N == 320 && !subpix && tiles12 >= 256) return 6;
   if (N == 320 || (subpix && N % 320 == 0)) return 3;
   return 4;
 }
@@ -398,7 +415,7 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
   a.tw = a.subpix ? 2 : 3;
   a.ldw = op->i[12] > 0 ? op->i[12] : a.T * a.Cin;
   a.rv_stride = op->i[13] ? 0 : a.N;
-  const int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N, a.subpix);
+  const int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N, a.subpix, (long long)a.B * ((a.H + 11) / 12) * ((a.W + 15) / 16));
   a.sW = op->l[0];
   a.chunks = a.Cin / 64;
   a.c0t = a.C0 / 64;
@@ -422,6 +439,12 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
     case 3: return launch_patch<8, 16, 320, 4, 2, 2>(a, s);
     case 4: return launch_patch<16, 16, 128, 4, 2, 2>(a, s);
     case 5: return launch_patch<8, 16, 128, 2, 2, 3>(a, s);
+    case 6:   // 192 pixels x 320 channels / 12 waves (wave tile 32 x 160)
+      MG_REQUIRE(a.N % 320 == 0, "conv3x3: tile variant 6 needs N %% 320 == 0");
+      return launch_patch<12, 16, 320, 6, 2, 2>(a, s);
+    case 7:   // 192 pixels x 320 channels / 6 waves (wave tile 64 x 160)
+      MG_REQUIRE(a.N % 320 == 0, "conv3x3: tile variant 7 needs N %% 320 == 0");
+      return launch_patch<12, 16, 320, 3, 2, 2>(a, s);
     default: MG_REQUIRE(false, "conv3x3: unknown tile variant %d", variant);
   }
   return 0;

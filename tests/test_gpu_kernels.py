@@ -213,6 +213,12 @@ PATCH_CASES = [
     ("v5_small", 1, 8, 16, 64, 0, 128, True, True, False, False, 5),
     ("auto_n640", 1, 16, 16, 64, 0, 640, False, False, False, False, 0),
     ("deep_k_fused", 1, 16, 16, 1280, 640, 256, True, True, True, True, 1),
+    # 12 x 16 pixels x 320 channels (12 / 6 waves; the weight stage does not divide evenly over the threads): whole and
+    # ragged tiles, fused norm, second source, time embedding, residual
+    ("v6_320_fused", 2, 24, 32, 320, 0, 320, True, True, True, True, 6),
+    ("v6_320_ragged_concat", 1, 31, 21, 320, 320, 320, True, True, False, True, 6),
+    ("v6_320_plain", 1, 12, 16, 64, 0, 640, False, False, False, False, 6),
+    ("v7_320_fused", 1, 20, 24, 320, 0, 320, True, True, True, False, 7),
 ]
 
 
