@@ -378,14 +378,17 @@ int launch_patch(const ConvPArgs& a0, hipStream_t s) {
 // 8 waves (wave tile 128 x 64) where N is a multiple of 256 (VAE 512 / 256 channels: 1100-1130); 8 x 16 x 320 / 8 waves
 // (wave tile 32 x 160) for the 320-channel level (930-1050) and the 640-channel sub-pixel convolution; 16 x 16 x 128 /
 // 8 waves / 2 weight stages (wave tile 64 x 64) otherwise (N = 640: 990-1060, N = 128: 830-1020).
-int mg_conv3x3_auto_variant(int N, int subpix, long long tiles12) {
+int mg_conv3x3_auto_variant(int N, int subpix, int B, int H, int W) {
   if (N % 256 == 0) return 1;
-  // (round 3) the 320-channel level on 12 x 16 pixel tiles / 12 waves when that still fills the chip: a K step streams the
-  // same 40 KB of weights for 192 instead of 128 pixels and three waves share a SIMD - 168 vs 198 us (320 -> 320), 311 vs 383
-  // (640 -> 320), 447 vs 524 (960 -> 320), with the fused GroupNorm 187 vs 222 (profiles/r3_conv_patch_12row_tiles.log)
-  static const int n320 = [] { const char* e = getenv("MARIGOLD_PATCH_N320"); return e ? atoi(e) : 0; }();   // A/B: force a variant
-  if (N == 320 && !subpix && n320) return n320;
-  if (N == 320 && !subpix && tiles12 >= 256) return 6;
+  const long long par = subpix ? 4 : 1;
+  // (round 3) 12-wave tiles - three waves per SIMD, and a K step's weights serve 1.5x the pixels - where they still fill the
+  // chip (profiles/r3_conv_patch_12row_tiles.log):
+  //   12 x 16 pixels x 320 channels for N = 320 / 640 (320 -> 320 @96: 168 vs 198 us; 640 -> 640 @48: 160 vs 193; the
+  //   sub-pixel 640 -> 640 up-sampling: 296 vs 355), 24 x 16 x 128 for N = 128 (128 -> 128 @768: 378 vs 438)
+  static const int n320 = [] { const char* e = getenv("MARIGOLD_PATCH_N320"); return e ? atoi(e) : 0; }();   // A/B: 3 = the round-2 choice
+  const bool old = n320 == 3;
+  if (N % 320 == 0 && !old && (long long)B * ((H + 11) / 12) * ((W + 15) / 16) * (N / 320) * par >= 200) return 6;
+  if (N % 128 == 0 && !old && (long long)B * ((H + 23) / 24) * ((W + 15) / 16) * (N / 128) * par >= 256) return 8;
   if (N == 320 || (subpix && N % 320 == 0)) return 3;
   return 4;
 }
@@ -415,7 +418,7 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
   a.tw = a.subpix ? 2 : 3;
   a.ldw = op->i[12] > 0 ? op->i[12] : a.T * a.Cin;
   a.rv_stride = op->i[13] ? 0 : a.N;
-  const int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N, a.subpix, (long long)a.B * ((a.H + 11) / 12) * ((a.W + 15) / 16));
+  const int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N, a.subpix, a.B, a.H, a.W);
   a.sW = op->l[0];
   a.chunks = a.Cin / 64;
   a.c0t = a.C0 / 64;
@@ -445,6 +448,9 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
     case 7:   // 192 pixels x 320 channels / 6 waves (wave tile 64 x 160)
       MG_REQUIRE(a.N % 320 == 0, "conv3x3: tile variant 7 needs N %% 320 == 0");
       return launch_patch<12, 16, 320, 3, 2, 2>(a, s);
+    case 8:   // 24 x 16 pixels x 128 channels / 12 waves (wave tile 64 x 64): the VAE's 128-channel 768^2 level
+      MG_REQUIRE(a.N % 128 == 0, "conv3x3: tile variant 8 needs N %% 128 == 0");
+      return launch_patch<24, 16, 128, 6, 2, 2>(a, s);
     default: MG_REQUIRE(false, "conv3x3: unknown tile variant %d", variant);
   }
   return 0;

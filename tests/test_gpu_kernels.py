@@ -219,6 +219,9 @@ PATCH_CASES = [
     ("v6_320_ragged_concat", 1, 31, 21, 320, 320, 320, True, True, False, True, 6),
     ("v6_320_plain", 1, 12, 16, 64, 0, 640, False, False, False, False, 6),
     ("v7_320_fused", 1, 20, 24, 320, 0, 320, True, True, True, False, 7),
+    # 24 x 16 pixels x 128 channels / 12 waves (the VAE's 128-channel level)
+    ("v8_128_fused", 1, 48, 32, 256, 0, 128, True, True, False, True, 8),
+    ("v8_128_ragged", 2, 29, 19, 128, 0, 256, False, False, True, False, 8),
 ]
 
 
@@ -256,7 +259,7 @@ def test_conv3x3_patch(dev, case):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,N,variant", [(2, 16, 16, 64, 256, 1), (1, 9, 21, 192, 128, 2), (2, 24, 24, 320, 320, 3),
-                                                 (1, 48, 48, 640, 640, 0)])
+                                                 (1, 48, 48, 640, 640, 0), (1, 25, 19, 128, 640, 6), (1, 29, 20, 64, 128, 8)])
 def test_conv3x3_patch_subpixel(dev, B, H, W, Cin, N, variant):
     from marigold_amd import ops, weights as Wm
     g = torch.Generator().manual_seed(H + W + Cin)
