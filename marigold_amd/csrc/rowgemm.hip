@@ -111,12 +111,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 void rowgemm_kernel(const RgArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // a stage = 2 tiles x KS fragments of 1 KB + one 1 KB trailer: fp32 [64] per-channel constants, [64] folded-LayerNorm g
-  constexpr int KS = K / 16, PIECES = 2 * KS + 1, STAGE = PIECES * 1024, NSTAGE = 3, TRL = 2 * KS * 1024;
+  // K = 640: a SLOT of the ring holds ONE 32-channel tile (40 fragments) and a 64-channel stage is two consecutive slots
+  // (the second one's trailer carries the stage's constants) - the slot is 41 KB either way
+  constexpr int KS = K / 16, TS = K <= 320 ? 2 : 1, SPS = 2 / TS;   // tiles per slot, slots per stage
+  constexpr int PIECES = TS * KS + 1, STAGE = PIECES * 1024, NSTAGE = 3, TRL = TS * KS * 1024;
   constexpr int NWMIN = PIECES / NW, NWREM = PIECES - NWMIN * NW;   // LDS-DMA pieces per wave and stage: NWMIN (+1 for waves < NWREM)
   constexpr bool GEGLU = EPI == RG_GEGLU || EPI == RG_GEGLU_ERF;
   constexpr int S = GEGLU ? 2 : 4;                         // stores per stage epilogue
   constexpr int XW = NWMIN + S + (RES ? 4 : 0);            // operations younger than stage j's pieces that may stay in flight
-  static_assert(K % 32 == 0 && NWMIN >= 1, "geometry");
+  static_assert((K == 320 || K == 640) && NWMIN >= 1, "geometry");
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   int row0 = blockIdx.x * (NW * 32) + wave * 32;
   // a surplus wave of the last workgroup (M is a multiple of 32, not of the workgroup's rows) only moves its share of the
@@ -143,8 +146,9 @@ void rowgemm_kernel(const RgArgs a) {
     for (int i = 0; i < NWMIN; ++i) glds16(src + (wave + i * NW) * 1024, dst + (wave + i * NW) * 1024);
     if (wave < NWREM) glds16(src + (wave + NWMIN * NW) * 1024, dst + (wave + NWMIN * NW) * 1024);
   };
-  issue(j0, 0);
-  if (j0 + 1 < nst) issue(j0 + 1, 1);
+  const int h0 = j0 * SPS, hend = nst * SPS;   // this workgroup's slots
+  issue(h0, 0);
+  if (h0 + 1 < hend) issue(h0 + 1, 1);
 
   // the wave's 32 rows of x: K step s -> x[m][16 s + 8 half .. + 8] (the MFMA's own K order)
   bf16x8 xf[KS];
@@ -194,55 +198,77 @@ void rowgemm_kernel(const RgArgs a) {
   int slot = 0, slot_i = 2;   // stage j lives in slot j % 3; stage j + 2 goes to slot (j + 2) % 3
   // One stage.  VSEC (the V^T section of the QKV form) is a compile-time tag and the two sections are two loops: as one
   // body with a branch, hipcc hoists the (identical) fragment reads of both arms above it - 160 live registers of fragments.
-  auto stage = [&](int j, auto vsec_tag) {
-    constexpr bool vsec = decltype(vsec_tag)::value;
+  auto advance = [&]() {
+    slot = slot == NSTAGE - 1 ? 0 : slot + 1;
+    slot_i = slot_i == NSTAGE - 1 ? 0 : slot_i + 1;
+  };
+  unsigned long long dwait = 0ull;
+  // slot h has landed for every wave and slot h - 1 is free: request slot h + 2 into it
+  auto head = [&](int h) {
     const unsigned long long d0 = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     if (active) {
-      if (j + 1 < nst) rg_wait_vmcnt<XW>(); else rg_wait_vmcnt<XW - NWMIN>();
+      if (h + 1 < hend) rg_wait_vmcnt<XW>(); else rg_wait_vmcnt<XW - NWMIN>();
     } else {   // nothing but weight pieces in this wave's queue
-      if (j + 1 < nst) rg_wait_vmcnt<NWMIN>(); else rg_wait_vmcnt<0>();
+      if (h + 1 < hend) rg_wait_vmcnt<NWMIN>(); else rg_wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
+    if (a.dbg) dwait += __builtin_amdgcn_s_memtime() - d0;
+    if (h + 2 < hend) issue(h + 2, slot_i);
+  };
+  // The fragment reads run PD K steps ahead of their MFMAs, hand-placed with counted lgkmcnt waits: hipcc keeps one or two
+  // in flight, which leaves the phase bound by LDS latency (2 700 cycles for 1 280 cycles of MFMAs: r3_rowgemm_small_batch.log)
+  constexpr int PD = RES ? (LNO ? 1 : 2) : 3, PR = PD + 1;   // (the residual forms hold 16-22 more registers)
+  auto mfma_slot = [&](auto vsec_tag, f32x16& accA, f32x16& accB) {   // TS == 2: both tiles; TS == 1: the slot's tile into accA
+    constexpr bool vsec = decltype(vsec_tag)::value;
+    const uint32_t fb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + (uint32_t)(slot * STAGE + lane * 16);
+    bf16x8 w0[PR], w1[PR];
+    rg_static_for<0, PD>([&](auto it) {
+      constexpr int s = decltype(it)::value;
+      w0[s] = rg_ldsw<s * 1024>(fb);
+      if constexpr (TS == 2) w1[s] = rg_ldsw<(KS + s) * 1024>(fb);
+    });
+    rg_static_for<0, KS>([&](auto it) {
+      constexpr int s = decltype(it)::value;
+      if constexpr (s + PD < KS) {
+        w0[(s + PD) % PR] = rg_ldsw<(s + PD) * 1024>(fb);
+        if constexpr (TS == 2) w1[(s + PD) % PR] = rg_ldsw<(KS + s + PD) * 1024>(fb);
+      }
+      constexpr int ahead = (KS - 1 - s) < PD ? (KS - 1 - s) : PD;
+      if constexpr (TS == 2) rg_lgk<2 * ahead>(w0[s % PR], w1[s % PR]);
+      else rg_lgk<ahead>(w0[s % PR], w0[s % PR == 0 ? 1 : 0]);
+      if constexpr (!vsec) {
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[s % PR], xf[s], accA, 0, 0, 0);
+        if constexpr (TS == 2) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[s % PR], xf[s], accB, 0, 0, 0);
+      } else {
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w0[s % PR], accA, 0, 0, 0);
+        if constexpr (TS == 2) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w1[s % PR], accB, 0, 0, 0);
+      }
+    });
+  };
+  // One 64-channel stage.  VSEC (the V^T section of the QKV form) is a compile-time tag and the two sections are two loops: as
+  // one body with a branch, hipcc hoists the (identical) fragment reads of both arms above it - 160 live registers of fragments.
+  auto stage = [&](int j, auto vsec_tag) {
+    constexpr bool vsec = decltype(vsec_tag)::value;
     const unsigned long long d1 = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (j + 2 < nst) issue(j + 2, slot_i);
-    if (!active) {
-      slot = slot == NSTAGE - 1 ? 0 : slot + 1;
-      slot_i = slot_i == NSTAGE - 1 ? 0 : slot_i + 1;
-      return;
-    }
-    // fp32 [64] constants, [64] g of this stage; + this lane's first channel (8 half; the V^T section: chan(l31))
-    const uint32_t tcb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + (uint32_t)(slot * STAGE + TRL);
+    const unsigned long long w_before = dwait;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    // The fragment reads run PD K steps ahead of their MFMAs, hand-placed with counted lgkmcnt waits: hipcc keeps one or two
-    // in flight, which leaves the phase bound by LDS latency (2 700 cycles for 1 280 cycles of MFMAs: r3_rowgemm_phase_cycles.log)
-    {
-      constexpr int PD = RES ? (LNO ? 1 : 2) : 3, PR = PD + 1;   // (the residual forms hold 16-22 more registers)
-      const uint32_t fb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + (uint32_t)(slot * STAGE + lane * 16);
-      bf16x8 w0[PR], w1[PR];
-      rg_static_for<0, PD>([&](auto it) {
-        constexpr int s = decltype(it)::value;
-        w0[s] = rg_ldsw<s * 1024>(fb);
-        w1[s] = rg_ldsw<(KS + s) * 1024>(fb);
-      });
-      rg_static_for<0, KS>([&](auto it) {
-        constexpr int s = decltype(it)::value;
-        if constexpr (s + PD < KS) {
-          w0[(s + PD) % PR] = rg_ldsw<(s + PD) * 1024>(fb);
-          w1[(s + PD) % PR] = rg_ldsw<(KS + s + PD) * 1024>(fb);
-        }
-        constexpr int ahead = (KS - 1 - s) < PD ? (KS - 1 - s) : PD;
-        rg_lgk<2 * ahead>(w0[s % PR], w1[s % PR]);
-        if constexpr (!vsec) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[s % PR], xf[s], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[s % PR], xf[s], acc1, 0, 0, 0);
-        } else {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w0[s % PR], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w1[s % PR], acc1, 0, 0, 0);
-        }
-      });
+    if constexpr (TS == 2) {
+      head(j);
+      if (!active) { advance(); return; }
+      mfma_slot(vsec_tag, acc0, acc1);
+    } else {
+      head(2 * j);
+      if (active) mfma_slot(vsec_tag, acc0, acc1);
+      advance();
+      head(2 * j + 1);
+      if (!active) { advance(); return; }
+      mfma_slot(vsec_tag, acc1, acc0);
     }
+    // fp32 [64] constants, [64] g of this stage (K = 640: in the trailer of its second slot); + this lane's first channel
+    // (8 half; the V^T section: chan(l31))
+    const uint32_t tcb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + (uint32_t)(slot * STAGE + TRL);
     // ---- the stage's 32 rows x 64 channels, in registers ----
     __builtin_amdgcn_sched_barrier(0);   // fragment registers are dead before the epilogue's temporaries go live
     unsigned long long d2 = 0ull;
@@ -250,6 +276,7 @@ void rowgemm_kernel(const RgArgs a) {
       asm volatile("s_nop 0" : "+v"(acc0), "+v"(acc1));
       d2 = __builtin_amdgcn_s_memtime();
     }
+    const unsigned long long d0 = d1;   // (stamps: stage start, end of the MFMA phase(s), end of the epilogue; the heads' waits apart)
     if constexpr (GEGLU) {
       // tile 0 = 32 value channels, tile 1 = their gates (weights.pack_rowgemm_geglu); out column = 32 j + channel
       uint4 pk[2];
@@ -344,10 +371,9 @@ void rowgemm_kernel(const RgArgs a) {
     if (a.dbg && lane == 0) {
       const unsigned long long d3 = __builtin_amdgcn_s_memtime();
       unsigned long long* o = a.dbg + (long long)(blockIdx.x * NW + wave) * 4;
-      o[0] += d1 - d0; o[1] += d2 - d1; o[2] += d3 - d2; o[3] += 1;
+      o[0] += dwait - w_before; o[1] += d2 - d0 - (dwait - w_before); o[2] += d3 - d2; o[3] += 1;
     }
-    slot = slot == NSTAGE - 1 ? 0 : slot + 1;
-    slot_i = slot_i == NSTAGE - 1 ? 0 : slot_i + 1;
+    advance();
   };
   if constexpr (EPI == RG_QKV) {
     const int nq = a.trans_stage < nst ? a.trans_stage : nst;
@@ -527,7 +553,7 @@ int rg_launch_xattn(const RgXArgs& a, hipStream_t s) {
 
 template <int K, int NW, int EPI, bool LN, bool GN, bool RES, bool LNO>
 int rg_launch(const RgArgs& a, hipStream_t s) {
-  constexpr int LDS = 3 * (K / 8 + 1) * 1024;
+  constexpr int LDS = 3 * ((K <= 320 ? 2 : 1) * (K / 16) + 1) * 1024;
   static bool attr_set = false;
   auto kern = rowgemm_kernel<K, NW, EPI, LN, GN, RES, LNO>;
   if (!attr_set && !g_dry_run) {
@@ -617,7 +643,7 @@ int mg_launch_rowgemm(const mg_op* op, hipStream_t s) {
     MG_REQUIRE(false, "rowgemm: %d waves per workgroup is not instantiated for the cross-attention form (8, 12)", nw);
   }
   MG_REQUIRE(a.x && a.wp && a.out, "rowgemm: null pointer (x, packed weights, out)");
-  MG_REQUIRE(K == 320, "rowgemm: K = %d is not instantiated (320)", K);
+  MG_REQUIRE(K == 320 || K == 640, "rowgemm: K = %d is not instantiated (320, 640)", K);
   MG_REQUIRE(a.M >= 32 && a.M % 32 == 0, "rowgemm: M = %d must be a multiple of 32 (a wave owns 32 whole rows)", a.M);
   MG_REQUIRE(a.N >= 128 && a.N % 64 == 0, "rowgemm: N = %d must be a multiple of 64, >= 128", a.N);
   MG_REQUIRE(a.ldx >= K && a.ldx % 8 == 0 && a.ldo % 8 == 0 && a.ldo >= (epi == RG_GEGLU ? a.N / 2 : (epi == RG_QKV ? trans_from : a.N)),
@@ -631,6 +657,11 @@ int mg_launch_rowgemm(const mg_op* op, hipStream_t s) {
     MG_REQUIRE(a.vt && trans_from > 0 && trans_from % 64 == 0 && trans_from < a.N && a.T > 0 && a.T % 32 == 0 && a.M % a.T == 0 &&
                a.ldt >= a.T && a.ldt % 8 == 0 && (uintptr_t)a.vt % 16 == 0,
                "rowgemm: the QKV form needs V^T (p[8]), trans_from %% 64 == 0, tokens per image %% 32 == 0, ldt >= tokens");
+  if (K == 640) {   // 160 registers of rows per wave: two waves per SIMD
+    const int nw6 = op->i[10] > 0 ? op->i[10] : 8;
+    if (nw6 == 8) return rg_dispatch<640, 8>(a, epi, s);
+    MG_REQUIRE(false, "rowgemm: K = 640 runs 8 waves per workgroup (got %d)", nw6);
+  }
   if (nw == 12) return rg_dispatch<320, 12>(a, epi, s);
   if (nw == 8) return rg_dispatch<320, 8>(a, epi, s);
   if (nw == 4) return rg_dispatch<320, 4>(a, epi, s);

@@ -28,6 +28,7 @@ XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed c
 GN_SLAB = os.environ.get("MARIGOLD_GN_SLAB", "1") != "0"           # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 FLASH_VT_PERM = os.environ.get("MARIGOLD_FLASH_VT_PERM", "1") != "0"   # permuted V^T + generation-3 attention (0: generation 2)
 ROWGEMM = os.environ.get("MARIGOLD_ROWGEMM", "1") != "0"           # row-resident GEMM (MG_OP_ROWGEMM) for the K = 320 token-local layers
+ROWGEMM_WIDE = os.environ.get("MARIGOLD_ROWGEMM_WIDE", "1") != "0"   # ... and its K = 640 form for the 640-channel level's QKV / GEGLU
 ROWGEMM_MIN_M = int(os.environ.get("MARIGOLD_ROWGEMM_MIN_M", "9216"))   # below: the tile GEMM (one 96 x 96 member is 72 128-row workgroups)
 
 
@@ -265,7 +266,22 @@ class Builder:
         return ROWGEMM and FLASH_VT_PERM and x.C == 320 and x.HW % 32 == 0 and x.M >= ROWGEMM_MIN_M
 
     @staticmethod
-    def rowgemm_cfg(M, N, whole_rows=False, xattn=False):
+    def rowgemm_wide_ok(x):
+        """The 640-channel level: MG_OP_ROWGEMM's K = 640 form (8 waves x 32 rows x 640 channels in 160 registers each) pays
+        only where the columns can be split over two workgroups per 256-row block - the QKV projection (97 -> 80 us) and GEGLU
+        (216 -> 194 us); the whole-row-statistics layers stay on the tile GEMM (90 workgroups: 64 vs 49 us),
+        profiles/r3_rowgemm_k640.log."""
+        return ROWGEMM and ROWGEMM_WIDE and FLASH_VT_PERM and x.C == 640 and x.HW % 32 == 0 and x.M >= 60 * 256
+
+    @staticmethod
+    def rowgemm_cfg(M, N, whole_rows=False, xattn=False, K=320):
+        if K == 640:
+            nb = -(-M // 256)
+            return dict(waves=8, nsplit=max(1, min(N // 128, 256 // nb)))
+        return Builder._rowgemm_cfg320(M, N, whole_rows, xattn)
+
+    @staticmethod
+    def _rowgemm_cfg320(M, N, whole_rows=False, xattn=False):
         """-> dict(waves=, nsplit=) of an MG_OP_ROWGEMM launch: 12 waves (384 rows) per workgroup when that still gives the
         chip >= 160 workgroups, else 8, else 4 with the N / 64 column stages shared out over several workgroups per row
         block (not for the forms that take whole-row statistics) - measured per ensemble size,
@@ -533,10 +549,10 @@ class Builder:
         # the attention kernel (generation 3) its v_permlane32_swap - a format private to this producer / consumer pair
         perm = FLASH_VT_PERM and T % 16 == 0
         rg = perm and st is not None and self.rowgemm_ok(h)
-        if rg:
+        if rg or (perm and st is not None and self.rowgemm_wide_ok(h)):
             self.add(O.rowgemm(h.t, self.ws.rg_qkv_ln(prefix, norm), qk, M=M, K=C, N=3 * C, form=L.RG_QKV, ldo=2 * C,
                                ln_in=self.ln_mean_rstd(st, M, C), vt=vt, tokens=T, ldt=ldvt, trans_from=2 * C,
-                               **self.rowgemm_cfg(M, 3 * C)), f"{prefix}.qkv")
+                               **self.rowgemm_cfg(M, 3 * C, K=C)), f"{prefix}.qkv")
         elif st is not None:
             wqkv, g, c = self.ws.qkv_ln(prefix, norm)
             self.add(O.igemm(h.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, out2=vt,
@@ -628,10 +644,10 @@ class Builder:
         b = f"{name}.transformer_blocks.0"
         self.self_attention(h, st[0], f"{b}.attn1", f"{b}.norm1", heads, st[1])
         self.cross_attention2(h, st[1], f"{b}.attn2", f"{b}.norm2", heads, ctx, st[2])
-        if rg:
+        if rg or (FOLD_LN and self.rowgemm_wide_ok(h)):
             ff = self.new(h.B, h.H, h.W, 4 * C)
             self.add(O.rowgemm(h.t, self.ws.rg_geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3"), ff.t, M=h.M, K=C, N=8 * C,
-                               form=L.RG_GEGLU, ln_in=self.ln_mean_rstd(st[2], h.M, C), **self.rowgemm_cfg(h.M, 8 * C)), f"{b}.ff.geglu")
+                               form=L.RG_GEGLU, ln_in=self.ln_mean_rstd(st[2], h.M, C), **self.rowgemm_cfg(h.M, 8 * C, K=C)), f"{b}.ff.geglu")
         elif FOLD_LN:
             wg, gg, cg = self.ws.geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3")
             ff = self.dense(h, wg, None, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu",

@@ -122,21 +122,28 @@ def _rg_chan():
 
 def pack_rowgemm(w, cb, lg=None):
     """w [N][K] (rows in the order the kernel's channels take: stage j = rows 64 j .. 64 j + 63, tile 0 its first 32) ->
-    uint8 [N/64][(2 K/16 + 1) * 1024]: per stage 2 x K/16 fragments of 1 KB - fragment (tile t, K step s), lane l = 32 g + mm,
-    8 bf16: w[64 j + 32 t + chan(mm)][16 s + 8 g + 0..7] (the MFMA's own K order) - and a 1 KB trailer: fp32 [64] per-channel constants ``cb`` (bias, + the folded
-    LayerNorm's c), fp32 [64] ``lg`` (the folded LayerNorm's g; zeros without), zero padding."""
+    uint8 [slots][41 * 1024].  A slot of the kernel's LDS ring is 40 fragments of 1 KB + a 1 KB trailer; fragment (tile t, K step
+    s), lane l = 32 g + mm, 8 bf16: w[64 j + 32 t + chan(mm)][16 s + 8 g + 0..7] (the MFMA's own K order).
+      K = 320: one slot per stage - [tile 0: 20 fragments][tile 1: 20 fragments][trailer];
+      K = 640: two slots per stage - [tile 0: 40 fragments][unused trailer], [tile 1: 40 fragments][trailer].
+    Trailer: fp32 [64] per-channel constants ``cb`` (bias, + the folded LayerNorm's c), fp32 [64] ``lg`` (the folded LayerNorm's g;
+    zeros without), zero padding."""
     n, k = w.shape
-    assert n % 64 == 0 and k % 32 == 0
+    assert n % 64 == 0 and k in (320, 640)
     nst, ks = n // 64, k // 16
     wb = w.detach().float().cpu().to(torch.bfloat16).contiguous()
     wv = wb.view(nst, 2, 32, ks, 2, 8)[:, :, _rg_chan()]          # [j][t][mm][s][g][i]
     frag = wv.permute(0, 1, 3, 4, 2, 5).contiguous()              # [j][t][s][g][mm][i] = 1 KB per (j, t, s)
-    frag = frag.view(torch.uint8).reshape(nst, 2 * ks * 1024)
+    frag = frag.view(torch.uint8).reshape(nst, 2, ks * 1024)
     trl = torch.zeros(nst, 256, dtype=torch.float32)
     trl[:, :64] = cb.detach().float().cpu().reshape(nst, 64)
     if lg is not None:
         trl[:, 64:128] = lg.detach().float().cpu().reshape(nst, 64)
-    return torch.cat([frag, trl.view(torch.uint8).reshape(nst, 1024)], dim=1).contiguous()
+    trl = trl.view(torch.uint8).reshape(nst, 1024)
+    if k == 320:
+        return torch.cat([frag[:, 0], frag[:, 1], trl], dim=1).contiguous()
+    zero = torch.zeros_like(trl)
+    return torch.stack([torch.cat([frag[:, 0], zero], dim=1), torch.cat([frag[:, 1], trl], dim=1)], dim=1).reshape(2 * nst, 41 * 1024).contiguous()
 
 
 def rowgemm_geglu_order(n2):

@@ -761,6 +761,20 @@ def test_rowgemm_weight_packing():
                     assert torch.equal(fr[j, t, :, h, mm, :], wb[64 * j + 32 * t + chan[mm]].view(ks, 2, 8)[:, h])
     tr = pk[:, 2 * ks * 1024:].contiguous().view(torch.float32)
     assert torch.equal(tr[:, :64].reshape(-1), cb) and torch.equal(tr[:, 64:128].reshape(-1), lg) and not tr[:, 128:].any()
+    # K = 640: two slots per stage, one 32-channel tile each; the constants ride in the second slot's trailer
+    k = 640
+    w = torch.randn(128, k, generator=g)
+    pk = Wm.pack_rowgemm(w, cb[:128], lg[:128])
+    assert pk.shape == (4, 41 * 1024)
+    fr = pk[:, :40 * 1024].contiguous().view(torch.bfloat16).view(2, 2, 40, 2, 32, 8)   # [j][t = slot parity][s][g][mm][i]
+    wb = w.to(torch.bfloat16)
+    for j in range(2):
+        for t in range(2):
+            for mm in range(32):
+                for h in range(2):
+                    assert torch.equal(fr[j, t, :, h, mm, :], wb[64 * j + 32 * t + chan[mm]].view(40, 2, 8)[:, h])
+    tr = pk[:, 40 * 1024:].contiguous().view(torch.float32).view(2, 2, 256)
+    assert not tr[:, 0].any() and torch.equal(tr[:, 1, :64].reshape(-1), cb[:128]) and torch.equal(tr[:, 1, 64:128].reshape(-1), lg[:128])
     order = Wm.rowgemm_geglu_order(512)
     assert sorted(order.tolist()) == list(range(512))
     assert order[:32].tolist() == list(range(32)) and order[32:64].tolist() == list(range(256, 288)) and order[64] == 32

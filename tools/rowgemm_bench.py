@@ -11,7 +11,9 @@ dev = torch.device("cuda:0")
 L.init(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 WAVES = [int(v) for v in sys.argv[2:]] or [12, 8]
-T, C = 9216, 320
+NS = int(os.environ.get("ROWGEMM_NSPLIT", "0"))   # column split of the forms without row statistics
+C = int(os.environ.get("ROWGEMM_C", "320"))
+T = 9216 if C == 320 else 2304
 M = B * T
 g = torch.Generator().manual_seed(3)
 
@@ -60,7 +62,7 @@ qk = torch.zeros(M, 2 * C, device=dev, dtype=torch.bfloat16)
 vt = torch.zeros(B, C, ldt, device=dev, dtype=torch.bfloat16)
 us = {}
 for w in WAVES:
-    op = O.rowgemm(xd, pk, qk, M=M, K=C, N=3 * C, form=L.RG_QKV, ldo=2 * C, ln_in=st, vt=vt, tokens=T, ldt=ldt, trans_from=2 * C, waves=w)
+    op = O.rowgemm(xd, pk, qk, M=M, K=C, N=3 * C, form=L.RG_QKV, ldo=2 * C, ln_in=st, vt=vt, tokens=T, ldt=ldt, trans_from=2 * C, waves=w, nsplit=NS)
     us[w] = t(lambda: O.launch(op))
 qk2 = torch.zeros_like(qk); vt2 = torch.zeros_like(vt)
 wp_d, lg_d, lc_d = wp.to(dev), lg.to(dev), lc.to(dev)      # (ops keep raw pointers: the tensors must outlive them)
@@ -139,7 +141,7 @@ if os.environ.get("ROWGEMM_DBG"):   # where a wave's time goes, per stage (s_mem
               f"   (by wave of the workgroup, wait: {[int(v) for v in (d[:, 0] / n).view(-1, 12).mean(0)]}, MFMA: {[int(v) for v in (d[:, 1] / n).view(-1, 12).mean(0)]}, epi: {[int(v) for v in (d[:, 2] / n).view(-1, 12).mean(0)]})", flush=True)
 us = {}
 for w in WAVES:
-    op = O.rowgemm(xd, pk, hid, M=M, K=C, N=2 * H, form=L.RG_GEGLU, ln_in=st, waves=w)
+    op = O.rowgemm(xd, pk, hid, M=M, K=C, N=2 * H, form=L.RG_GEGLU, ln_in=st, waves=w, nsplit=NS)
     us[w] = t(lambda: O.launch(op))
 wg, bg = Wm.pack_geglu(w1, b1)
 wpg, lgg, lcg = Wm.fold_layernorm(wg, bg, gamma, beta)
@@ -154,6 +156,8 @@ report("geglu+LN", us, us_old, 2 * M * 2 * H * C, (M * C + M * H) * 2, e)
 print(f"             vs igemm: differing {int((hid != hid2).sum())} of {hid.numel()}, max |d| {float((hid.float() - hid2.float()).abs().max()):.3e}")
 
 # ---- collapsed cross-attention, in place --------------------------------------------------------------------------------
+if C != 320:
+    sys.exit(0)
 heads = 5
 ctx = rnd(2, 1024)
 wq2, wo2 = rnd(C, C, s=1 / math.sqrt(C)), rnd(C, C, s=1 / math.sqrt(C))
