@@ -379,14 +379,16 @@ int launch_patch(const ConvPArgs& a0, hipStream_t s) {
 // (wave tile 32 x 160) for the 320-channel level (930-1050) and the 640-channel sub-pixel convolution; 16 x 16 x 128 /
 // 8 waves / 2 weight stages (wave tile 64 x 64) otherwise (N = 640: 990-1060, N = 128: 830-1020).
 int mg_conv3x3_auto_variant(int N, int subpix, int B, int H, int W) {
-  if (N % 256 == 0) return 1;
+  static const int n320 = [] { const char* e = getenv("MARIGOLD_PATCH_N320"); return e ? atoi(e) : 0; }();   // A/B: 3 = the round-2 choice
+  const bool old = n320 == 3;
+  // N = 256 / 512 (VAE): 12 x 16 x 256 on 12 waves (wave tile 64 x 64) where the GroupNorm is fused / the map is large
+  // (512 -> 512 @192 with the fused norm: 668 vs 758 us; 256 -> 256 @384: 712 vs 741; plain @96: equal); the sub-pixel forms stay
+  if (N % 256 == 0) return (!subpix && !old && (long long)B * ((H + 11) / 12) * ((W + 15) / 16) * (N / 256) >= 256) ? 9 : 1;
   const long long par = subpix ? 4 : 1;
   // (round 3) 12-wave tiles - three waves per SIMD, and a K step's weights serve 1.5x the pixels - where they still fill the
   // chip (profiles/r3_conv_patch_12row_tiles.log):
   //   12 x 16 pixels x 320 channels for N = 320 / 640 (320 -> 320 @96: 168 vs 198 us; 640 -> 640 @48: 160 vs 193; the
   //   sub-pixel 640 -> 640 up-sampling: 296 vs 355), 24 x 16 x 128 for N = 128 (128 -> 128 @768: 378 vs 438)
-  static const int n320 = [] { const char* e = getenv("MARIGOLD_PATCH_N320"); return e ? atoi(e) : 0; }();   // A/B: 3 = the round-2 choice
-  const bool old = n320 == 3;
   if (N % 320 == 0 && !old && (long long)B * ((H + 11) / 12) * ((W + 15) / 16) * (N / 320) * par >= 200) return 6;
   if (N % 128 == 0 && !old && (long long)B * ((H + 23) / 24) * ((W + 15) / 16) * (N / 128) * par >= 256) return 8;
   if (N == 320 || (subpix && N % 320 == 0)) return 3;
@@ -451,6 +453,9 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
     case 8:   // 24 x 16 pixels x 128 channels / 12 waves (wave tile 64 x 64): the VAE's 128-channel 768^2 level
       MG_REQUIRE(a.N % 128 == 0, "conv3x3: tile variant 8 needs N %% 128 == 0");
       return launch_patch<24, 16, 128, 6, 2, 2>(a, s);
+    case 9:   // 12 x 16 pixels x 256 channels / 12 waves (wave tile 64 x 64)
+      MG_REQUIRE(a.N % 256 == 0, "conv3x3: tile variant 9 needs N %% 256 == 0");
+      return launch_patch<12, 16, 256, 3, 4, 2>(a, s);
     default: MG_REQUIRE(false, "conv3x3: unknown tile variant %d", variant);
   }
   return 0;

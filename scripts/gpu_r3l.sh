@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, session l: 12 x 16 pixel conv_patch tiles for the 320-channel level - kernel parity, pipeline A/B (forced variant 3 vs auto), pipeline parity
+# round 3, session l: 12-wave conv_patch tiles (variants 6, 8, 9) - kernel parity, pipeline A/B (MARIGOLD_PATCH_N320=3: the round-2 tiles), pipeline parity
 export PYTHONUNBUFFERED=1
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out

@@ -222,6 +222,8 @@ PATCH_CASES = [
     # 24 x 16 pixels x 128 channels / 12 waves (the VAE's 128-channel level)
     ("v8_128_fused", 1, 48, 32, 256, 0, 128, True, True, False, True, 8),
     ("v8_128_ragged", 2, 29, 19, 128, 0, 256, False, False, True, False, 8),
+    ("v9_256_fused", 1, 36, 32, 128, 128, 512, True, True, True, True, 9),
+    ("v9_256_ragged", 1, 13, 17, 64, 0, 256, False, False, False, False, 9),
 ]
 
 
