@@ -551,6 +551,148 @@ int rg_launch_xattn(const RgXArgs& a, hipStream_t s) {
   return 0;
 }
 
+// ---- the collapsed cross-attention on the DEEP levels (K = c2 = 640 / 1 280 channels, a few thousand rows): K-split form ----
+// The tile-GEMM form (MG_EPI_XATTN2) walks 20 K steps and 40 column blocks serially in 45-180 workgroups: 42-82 us for a few
+// MFLOP.  Here a workgroup is 32 rows x 4 waves and BOTH reductions are cut four ways: wave w holds the K / 4 channels
+// [K/4 w, K/4 (w+1)) of the rows in registers, computes the partial 32 x 64 scores over them (weight fragments straight from
+// global / L2, pre-packed per wave: weights.pack_rowgemm_xattn_ksplit), the partials meet in LDS, every wave forms the
+// probabilities, and wave w then produces the output channels of ITS slice - whose residual it already holds.  M / 32
+// workgroups (180 at the 24 x 24 level), each a chain of ~100 loads and 100 MFMAs.
+struct RgXkArgs {
+  const bf16_t* x;
+  const char* wp;      // [4 waves][2 tiles][K/64 steps] score fragments, [4][K/128 tiles][4 steps] VO^T fragments, fp32 cb[64] lg[64] bias[K]
+  bf16_t* out;
+  const float2* ln_in;
+  float2* ln_out;
+  int M, ldx, ldo, sm_cols;
+  float sm_scale, ln_eps;
+  double inv_n;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void rowgemm_xattn_ksplit_kernel(const RgXkArgs a) {
+  constexpr int KQ = K / 4, KSQ = KQ / 16, NT2 = KQ / 32;
+  constexpr int WQK_BYTES = 4 * 2 * KSQ * 1024, VOT_BYTES = 4 * NT2 * 4 * 1024;
+  __shared__ __attribute__((aligned(16))) float part[4][32][64];   // partial score accumulators [wave][register][lane]
+  __shared__ double rstat[4][32][2];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int m = blockIdx.x * 32 + l31;
+  bf16x8 xf[KSQ];
+  {
+    const bf16_t* px = a.x + (long long)m * a.ldx + KQ * wave + 8 * half;
+#pragma unroll
+    for (int s = 0; s < KSQ; ++s) xf[s] = *(const bf16x8*)(px + 16 * s);
+  }
+  const float2 st = a.ln_in[m];
+  const float l_sc = st.y, l_mr = -st.y * st.x;
+  // ---- partial scores over this wave's K quarter ----
+  {
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const char* wq = a.wp + (long long)wave * (2 * KSQ * 1024) + lane * 16;
+#pragma unroll
+    for (int s = 0; s < KSQ; ++s) {
+      const bf16x8 w0 = *(const bf16x8*)(wq + s * 1024);
+      const bf16x8 w1 = *(const bf16x8*)(wq + (KSQ + s) * 1024);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { part[wave][r][lane] = acc0[r]; part[wave][16 + r][lane] = acc1[r]; }
+  }
+  __syncthreads();
+  bf16x8 pf[4];
+  {
+    const float* cbp = (const float*)(a.wp + WQK_BYTES + VOT_BYTES);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = t * 32 + q * 16 + 8 * half;
+        const float4 c0 = *(const float4*)(cbp + c), c1 = *(const float4*)(cbp + c + 4);
+        const float4 g0 = *(const float4*)(cbp + 64 + c), g1 = *(const float4*)(cbp + 64 + c + 4);
+        const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        float sv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = t * 16 + q * 8 + i;
+          const float av = (part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane]);
+          sv[i] = __builtin_fmaf(av, l_sc, __builtin_fmaf(l_mr, gg[i], cc[i])) * a.sm_scale;
+        }
+        uint32_t w4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float mx = fmaxf(sv[2 * k], sv[2 * k + 1]);
+          const float e0 = __expf(sv[2 * k] - mx), e1 = __expf(sv[2 * k + 1] - mx);
+          const float inv = 1.0f / (e0 + e1);
+          w4[k] = (c + 2 * k < a.sm_cols) ? pack2bf(e0 * inv, e1 * inv) : 0u;
+        }
+        pf[t * 2 + q] = __builtin_bit_cast(bf16x8, make_uint4(w4[0], w4[1], w4[2], w4[3]));
+      }
+  }
+  // ---- this wave's output channels [KQ wave, KQ (wave + 1)): P VO^T + bias + x ----
+  const char* wv = a.wp + WQK_BYTES + (long long)wave * (NT2 * 4 * 1024) + lane * 16;
+  const float* pb = (const float*)(a.wp + WQK_BYTES + VOT_BYTES) + 128 + KQ * wave + 8 * half;
+  bf16_t* const po = a.out + (long long)m * a.ldo + KQ * wave + 8 * half;
+  float ps = 0.f, pq = 0.f;
+  double sd = 0.0, qd = 0.0;
+#pragma unroll
+  for (int tt = 0; tt < NT2; ++tt) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 w = *(const bf16x8*)(wv + (tt * 4 + s) * 1024);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, pf[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float4 b0 = *(const float4*)(pb + tt * 32 + q * 16), b1 = *(const float4*)(pb + tt * 32 + q * 16 + 4);
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const uint4 r4 = __builtin_bit_cast(uint4, xf[tt * 2 + q]);
+      const float rr[8] = {bflo(r4.x), bfhi(r4.x), bflo(r4.y), bfhi(r4.y), bflo(r4.z), bfhi(r4.z), bflo(r4.w), bfhi(r4.w)};
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] = acc[8 * q + i] + bb[i] + rr[i];
+        ps += v[i];
+        pq = __builtin_fmaf(v[i], v[i], pq);
+      }
+      uint4 pk;
+      pk.x = cvt_pk_bf16_f32(v[0], v[1]); pk.y = cvt_pk_bf16_f32(v[2], v[3]);
+      pk.z = cvt_pk_bf16_f32(v[4], v[5]); pk.w = cvt_pk_bf16_f32(v[6], v[7]);
+      *(uint4*)(po + tt * 32 + q * 16) = pk;
+    }
+    if ((tt & 1) == 1 || tt == NT2 - 1) {   // fp32 partials of <= 64 values, then fp64 (as the tile GEMM's statistics)
+      asm volatile("" : "+v"(ps), "+v"(pq));
+      sd += (double)ps; qd += (double)pq;
+      ps = 0.f; pq = 0.f;
+    }
+  }
+  if (a.ln_out) {   // (mean, rstd) of the new rows: the four waves' channel quarters meet in LDS, summed in wave order
+    sd += __shfl_xor(sd, 32);
+    qd += __shfl_xor(qd, 32);
+    if (half == 0) { rstat[wave][l31][0] = sd; rstat[wave][l31][1] = qd; }
+    __syncthreads();
+    if (wave == 0 && half == 0) {
+      const double s4 = (rstat[0][l31][0] + rstat[1][l31][0]) + (rstat[2][l31][0] + rstat[3][l31][0]);
+      const double q4 = (rstat[0][l31][1] + rstat[1][l31][1]) + (rstat[2][l31][1] + rstat[3][l31][1]);
+      const double mean = s4 * a.inv_n;
+      const float var = fmaxf((float)__builtin_fma(q4, a.inv_n, -mean * mean), 0.f);
+      a.ln_out[m] = make_float2((float)mean, __builtin_amdgcn_rsqf(var + a.ln_eps));
+    }
+  }
+}
+
+template <int K>
+int rg_launch_xattn_ksplit(const RgXkArgs& a, hipStream_t s) {
+  MG_LAUNCH(rowgemm_xattn_ksplit_kernel<K>, dim3(a.M / 32), dim3(256), 0, s, a);
+  return 0;
+}
+
 template <int K, int NW, int EPI, bool LN, bool GN, bool RES, bool LNO>
 int rg_launch(const RgArgs& a, hipStream_t s) {
   constexpr int LDS = 3 * ((K <= 320 ? 2 : 1) * (K / 16) + 1) * 1024;
@@ -627,6 +769,18 @@ int mg_launch_rowgemm(const mg_op* op, hipStream_t s) {
     MG_REQUIRE(nsplit == 1 || !a.ln_out, "rowgemm: row statistics need whole rows in one workgroup (no column split)");
   }
   MG_REQUIRE(epi >= RG_BF16 && epi <= RG_XATTN, "rowgemm: unknown form %d", epi);
+  if (epi == RG_XATTN && (K == 640 || K == 1280)) {
+    RgXkArgs x;
+    x.x = a.x; x.wp = a.wp; x.out = a.out; x.ln_in = a.ln_in; x.ln_out = a.ln_out;
+    x.M = a.M; x.ldx = a.ldx; x.ldo = op->i[4] > 0 ? op->i[4] : K; x.sm_cols = op->i[11];
+    x.sm_scale = op->f[1]; x.ln_eps = a.ln_eps; x.inv_n = 1.0 / (double)K;
+    MG_REQUIRE(x.x && x.wp && x.out && x.ln_in, "rowgemm: the cross-attention form needs x, packed weights, out and the (mean, rstd) table of x");
+    MG_REQUIRE(a.N == 64 && x.M >= 32 && x.M % 32 == 0 && x.ldx >= K && x.ldx % 8 == 0 && x.ldo >= K && x.ldo % 8 == 0, "rowgemm: rows / leading dimensions");
+    MG_REQUIRE(x.sm_cols > 0 && x.sm_cols % 2 == 0 && x.sm_cols <= 64, "rowgemm: score columns (2 per head, <= 64)");
+    MG_REQUIRE((uintptr_t)x.x % 16 == 0 && (uintptr_t)x.wp % 16 == 0 && (uintptr_t)x.out % 16 == 0 && (uintptr_t)x.ln_in % 8 == 0 &&
+               (!x.ln_out || (uintptr_t)x.ln_out % 8 == 0), "rowgemm: alignment");
+    return K == 640 ? rg_launch_xattn_ksplit<640>(x, s) : rg_launch_xattn_ksplit<1280>(x, s);
+  }
   if (epi == RG_XATTN) {
     RgXArgs x;
     x.x = a.x; x.wp = a.wp; x.out = a.out; x.ln_in = a.ln_in; x.ln_out = a.ln_out;
@@ -643,7 +797,7 @@ int mg_launch_rowgemm(const mg_op* op, hipStream_t s) {
     MG_REQUIRE(false, "rowgemm: %d waves per workgroup is not instantiated for the cross-attention form (8, 12)", nw);
   }
   MG_REQUIRE(a.x && a.wp && a.out, "rowgemm: null pointer (x, packed weights, out)");
-  MG_REQUIRE(K == 320 || K == 640, "rowgemm: K = %d is not instantiated (320, 640)", K);
+  MG_REQUIRE(K == 320 || K == 640 || (K == 1280 && epi == RG_XATTN), "rowgemm: K = %d is not instantiated (320, 640; 1280 for the cross-attention form)", K);
   MG_REQUIRE(a.M >= 32 && a.M % 32 == 0, "rowgemm: M = %d must be a multiple of 32 (a wave owns 32 whole rows)", a.M);
   MG_REQUIRE(a.N >= 128 && a.N % 64 == 0, "rowgemm: N = %d must be a multiple of 64, >= 128", a.N);
   MG_REQUIRE(a.ldx >= K && a.ldx % 8 == 0 && a.ldo % 8 == 0 && a.ldo >= (epi == RG_GEGLU ? a.N / 2 : (epi == RG_QKV ? trans_from : a.N)),

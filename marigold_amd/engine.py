@@ -28,6 +28,7 @@ XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed c
 GN_SLAB = os.environ.get("MARIGOLD_GN_SLAB", "1") != "0"           # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 FLASH_VT_PERM = os.environ.get("MARIGOLD_FLASH_VT_PERM", "1") != "0"   # permuted V^T + generation-3 attention (0: generation 2)
 ROWGEMM = os.environ.get("MARIGOLD_ROWGEMM", "1") != "0"           # row-resident GEMM (MG_OP_ROWGEMM) for the K = 320 token-local layers
+XATTN_KSPLIT = os.environ.get("MARIGOLD_XATTN_KSPLIT", "1") != "0"   # deep-level collapsed cross-attention as the K-split kernel
 ROWGEMM_WIDE = os.environ.get("MARIGOLD_ROWGEMM_WIDE", "1") != "0"   # ... and its K = 640 form for the 640-channel level's QKV / GEGLU
 ROWGEMM_MIN_M = int(os.environ.get("MARIGOLD_ROWGEMM_MIN_M", "9216"))   # below: the tile GEMM (one 96 x 96 member is 72 128-row workgroups)
 
@@ -195,7 +196,8 @@ class WeightStore:
                 self.sd[f"{prefix}.to_v.weight"], self.sd[f"{prefix}.to_out.0.weight"], ctx, heads)
             assert npad == 64
             wp, g, c = Wm.fold_layernorm(wqk, None, *self._ln(norm))
-            return Wm.pack_rowgemm_xattn(wp.float(), c, g, vot, self.sd[f"{prefix}.to_out.0.bias"].float()).to(self.device)
+            pack = Wm.pack_rowgemm_xattn if wqk.shape[1] == 320 else Wm.pack_rowgemm_xattn_ksplit
+            return pack(wp.float(), c, g, vot, self.sd[f"{prefix}.to_out.0.bias"].float()).to(self.device)
         return self._memo(("rg_x_ln", prefix), f)
 
     def cross_ln(self, prefix, ctx, heads, norm):
@@ -579,6 +581,13 @@ class Builder:
         """h += attn2(LN(h), ctx) with the 2-token context collapsed into two thin GEMMs and the LayerNorm folded into
         the first one."""
         C, M = h.C, h.M
+        if (st is not None and st_out is not None and XATTN_FUSED and XATTN_KSPLIT and ROWGEMM and 2 * heads <= 64 and C in (640, 1280)
+                and M % 32 == 0):
+            # the deep levels: 32-row workgroups whose four waves split K (scores) and the output channels (blend)
+            self.add(O.rowgemm(h.t, self.ws.rg_cross_ln(prefix, ctx, heads, norm), h.t, M=M, K=C, N=64, form=L.RG_XATTN,
+                               ln_in=self.ln_mean_rstd(st, M, C), ln_out=self.ln_mean_rstd(st_out, M, C),
+                               sm_cols=2 * heads, sm_scale=1.0 / math.sqrt(C // heads)), f"{prefix}.scores+softmax2+blend")
+            return
         if st is not None and st_out is not None and XATTN_FUSED and 2 * heads <= 64 and self.rowgemm_ok(h):
             # the same single launch in the row-resident form: the residual stream is read once (registers) and written once
             self.add(O.rowgemm(h.t, self.ws.rg_cross_ln(prefix, ctx, heads, norm), h.t, M=M, K=C, N=64, form=L.RG_XATTN,

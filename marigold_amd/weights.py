@@ -167,3 +167,21 @@ def pack_rowgemm_xattn(wqk, c, g, vot, bias):
     tr = torch.zeros(512, dtype=torch.float32)
     tr[:c2] = bias.detach().float().cpu()
     return torch.cat([s0, fr, tr.view(torch.uint8)]).contiguous()
+
+
+def pack_rowgemm_xattn_ksplit(wqk, c, g, vot, bias):
+    """MG_OP_ROWGEMM form RG_XATTN at K = c2 = 640 / 1280 (csrc/rowgemm.hip::rowgemm_xattn_ksplit_kernel): wave w of a 32-row
+    workgroup owns the channels [K/4 w, K/4 (w + 1)) on both sides.  [score fragments [w][tile t][K step s][lane 32 g + mm][8]:
+    wqk[32 t + chan(mm)][K/4 w + 16 s + 8 g + i]] [VO^T fragments [w][tile tt][step s'][lane][8]: vot[K/4 w + 32 tt + chan(mm)]
+    [16 s' + 8 g + i]] [fp32 c[64], g[64] of the folded LayerNorm, bias[K]]."""
+    k = wqk.shape[1]
+    assert wqk.shape[0] == 64 and vot.shape == (k, 64) and k in (640, 1280)
+    kq = k // 4
+    ksq, nt2 = kq // 16, kq // 32
+    ch = _rg_chan()
+    wb = wqk.detach().float().cpu().to(torch.bfloat16).contiguous()
+    f1 = wb.view(2, 32, 4, ksq, 2, 8)[:, ch].permute(2, 0, 3, 4, 1, 5).contiguous().view(torch.uint8).reshape(-1)     # [w][t][s][g][mm][i]
+    vb = vot.detach().float().cpu().to(torch.bfloat16).contiguous()
+    f2 = vb.view(4, nt2, 32, 4, 2, 8)[:, :, ch].permute(0, 1, 3, 4, 2, 5).contiguous().view(torch.uint8).reshape(-1)   # [w][tt][s'][g][mm][i]
+    fl = torch.cat([c.detach().float().cpu().reshape(64), g.detach().float().cpu().reshape(64), bias.detach().float().cpu().reshape(k)])
+    return torch.cat([f1, f2, fl.contiguous().view(torch.uint8)]).contiguous()

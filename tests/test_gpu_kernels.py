@@ -612,13 +612,13 @@ def test_rowgemm_all_forms(dev, C, waves):
     assert torch.equal(hid, hid2)
 
 
-@pytest.mark.parametrize("waves", [12, 8])
-def test_rowgemm_fused_cross_attention(dev, waves):
+@pytest.mark.parametrize("C,heads,waves", [(320, 5, 12), (320, 5, 8), (640, 10, 0), (1280, 20, 0)])
+def test_rowgemm_fused_cross_attention(dev, C, heads, waves):
     """MG_OP_ROWGEMM form RG_XATTN (the collapsed 2-token cross-attention, in place on the residual stream) against the
     unfused fp32 chain: LayerNorm -> scores -> pair softmax -> x VO^T + bias + residual, and the new rows' statistics."""
     from marigold_amd import _lib as L, ops, weights as Wm
-    g = torch.Generator().manual_seed(41 + waves)
-    M, C, heads = 2112, 320, 5
+    g = torch.Generator().manual_seed(41 + waves + C)
+    M = 2112
     x = _bf(torch.randn(M, C, generator=g) * 0.9 + 0.3 * torch.randn(M, 1, generator=g))
     gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
     ctx = torch.randn(2, 1024, generator=g)
@@ -634,14 +634,14 @@ def test_rowgemm_fused_cross_attention(dev, waves):
     ref = torch.einsum("mhj,jhd->mhd", p, v).reshape(M, C) @ wo.t() + bo + x
     wqk, vot, npad = Wm.cross_attention_tables(wq, wk, wv, wo, ctx, heads)
     wp, lg, lc = Wm.fold_layernorm(wqk, None, gamma, beta)
-    pk = Wm.pack_rowgemm_xattn(wp.float(), lc, lg, vot, bo).to(dev)
+    pk = (Wm.pack_rowgemm_xattn if C == 320 else Wm.pack_rowgemm_xattn_ksplit)(wp.float(), lc, lg, vot, bo).to(dev)
     stx = torch.stack([x.mean(-1), 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5)], dim=-1).to(dev).contiguous()
     h = x.to(dev, torch.bfloat16).clone()
     so = torch.full((M, 2), float("nan"), device=dev)
     _run(ops.rowgemm(h, pk, h, M=M, K=C, N=64, form=L.RG_XATTN, ln_in=stx, ln_out=so, sm_cols=2 * heads,
                      sm_scale=1.0 / math.sqrt(C // heads), waves=waves))
-    _close(f"rowgemm/xattn/{waves}w", h, ref)
-    _close(f"rowgemm/xattn/stats/{waves}w", so, torch.stack([ref.mean(-1), 1.0 / torch.sqrt(ref.var(-1, unbiased=False) + 1e-5)], -1), tol=2e-3)
+    _close(f"rowgemm/xattn/C{C}/{waves}w", h, ref)
+    _close(f"rowgemm/xattn/stats/C{C}/{waves}w", so, torch.stack([ref.mean(-1), 1.0 / torch.sqrt(ref.var(-1, unbiased=False) + 1e-5)], -1), tol=2e-3)
 
 
 def test_rowgemm_rejects_shapes_outside_its_contract(dev):
