@@ -805,6 +805,60 @@ def test_conv_patch_and_flash_bit_stable_at_scale(dev):
     assert torch.isfinite(first.float()).all()
 
 
+def test_rowgemm_bit_stable_at_scale_and_equal_to_tile_gemm(dev):
+    """MG_OP_ROWGEMM at the benchmark's shapes (92 160 rows x 320 channels; 240 workgroups x 12 waves on hand-counted vmcnt /
+    lgkmcnt waits: a race would show as launches that differ): QKV with the folded LayerNorm six times - and bit-identical to
+    the tile GEMM's output, whose reduction order it keeps - the in-place cross-attention and its K-split form at 1 280
+    channels, six launches each from the same input."""
+    from marigold_amd import _lib as L, ops, weights as Wm
+    g = torch.Generator().manual_seed(12)
+    B, T, C, heads = 10, 9216, 320, 5
+    M = B * T
+    x = (torch.randn(M, C, generator=g) * 0.8).to(torch.bfloat16)
+    xd = x.to(dev)
+    st = torch.stack([x.float().mean(1), (x.float().var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous().to(dev)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    wq = torch.randn(3 * C, C, generator=g) / math.sqrt(C)
+    wp, lg, lc = Wm.fold_layernorm(wq, None, gamma, beta)
+    pk = Wm.pack_rowgemm(wp.float(), lc, lg).to(dev)
+    first = None
+    for _ in range(6):
+        qk = torch.full((M, 2 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+        vt = torch.zeros(B, C, T, device=dev, dtype=torch.bfloat16)
+        _run(ops.rowgemm(xd, pk, qk, M=M, K=C, N=3 * C, form=L.RG_QKV, ldo=2 * C, ln_in=st, vt=vt, tokens=T, ldt=T, trans_from=2 * C))
+        if first is None:
+            first = (qk.clone(), vt.clone())
+        assert torch.equal(first[0], qk) and torch.equal(first[1], vt), "rowgemm QKV: launches differ"
+    wpd, lgd, lcd = wp.to(dev), lg.to(dev), lc.to(dev)
+    qk2 = torch.full((M, 2 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+    vt2 = torch.zeros(B, C, T, device=dev, dtype=torch.bfloat16)
+    _run(ops.igemm(xd, wpd, qk2, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, out2=vt2, trans_from=2 * C, ldt=T,
+                   ln_in=st, ln_g=lgd, ln_c=lcd, trans_perm=True))
+    assert torch.equal(first[0], qk2) and torch.equal(first[1], vt2), "rowgemm QKV differs from the tile GEMM"
+    # cross-attention, in place: row-resident (K = 320) and K-split (K = 1280, the 24 x 24 level's 5 760 rows)
+    for (Cx, hx, Mx) in ((320, 5, M), (1280, 20, 5760)):
+        xx = (torch.randn(Mx, Cx, generator=g) * 0.8).to(torch.bfloat16)
+        stx = torch.stack([xx.float().mean(1), (xx.float().var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous().to(dev)
+        ga, be = 1 + 0.2 * torch.randn(Cx, generator=g), 0.1 * torch.randn(Cx, generator=g)
+        ctx = torch.randn(2, 1024, generator=g)
+        wq2, wo2 = torch.randn(Cx, Cx, generator=g) / math.sqrt(Cx), torch.randn(Cx, Cx, generator=g) / math.sqrt(Cx)
+        wk2, wv2 = torch.randn(Cx, 1024, generator=g) / 32, torch.randn(Cx, 1024, generator=g) / 32
+        wqk, vot, _ = Wm.cross_attention_tables(wq2, wk2, wv2, wo2, ctx, hx)
+        wpx, lgx, lcx = Wm.fold_layernorm(wqk, None, ga, be)
+        pack = Wm.pack_rowgemm_xattn if Cx == 320 else Wm.pack_rowgemm_xattn_ksplit
+        pkx = pack(wpx.float(), lcx, lgx, vot, 0.1 * torch.randn(Cx, generator=g)).to(dev)
+        first = None
+        for _ in range(6):
+            h = xx.to(dev).clone()
+            so = torch.full((Mx, 2), float("nan"), device=dev)
+            _run(ops.rowgemm(h, pkx, h, M=Mx, K=Cx, N=64, form=L.RG_XATTN, ln_in=stx, ln_out=so, sm_cols=2 * hx,
+                             sm_scale=1.0 / math.sqrt(Cx // hx)))
+            if first is None:
+                first = (h.clone(), so.clone())
+            assert torch.equal(first[0], h) and torch.equal(first[1], so), f"rowgemm cross-attention (C = {Cx}): launches differ"
+        assert torch.isfinite(first[0].float()).all() and torch.isfinite(first[1]).all()
+
+
 def test_igemm_row_statistics_bit_stable_at_scale(dev):
     """In-place Linear + residual with row statistics at benchmark sizes, on the tiles that share a CU between two
     workgroups: every launch must give the same bits (outputs and (mean, rstd)), and the statistics must match fp32.
