@@ -175,8 +175,20 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_patch_kernel(const ConvPAr
       if (r < PR && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) fix_mask |= 1u << it;
     }
   }
+  // SSL (the 12-wave 320-channel tile, 168 registers per lane): the image's scale / shift vectors live in LDS behind the
+  // weight ring and are read at the use - held in registers across the K steps they cost 16 of the budget (18 spilled
+  // registers, 7 scratch reloads per K step before)
+  constexpr bool SSL = FIX && TH == 12 && BN == 320;
+  float* const ssl = (float*)(smem + 2 * PATCH + NSTB * BSTAGE);   // [2][Cin]
+  if constexpr (SSL) {
+    const float* src = a.ss + (long long)img * 2 * a.Cin;
+    for (int i = tid; i < 2 * a.Cin; i += NT) ssl[i] = src[i];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // published by the barrier ahead of the first fix-up
+  }
   float fsc[8], fsh[8];
+  int fix_c = 0;   // SSL: channel tile the next fix_vec calls belong to
   auto fix_load = [&](int c) {
+    if constexpr (SSL) { fix_c = c; return; }
     const float* scp = a.ss + (long long)img * 2 * a.Cin + c * 64 + fix_j8;
     const float4 s0 = *(const float4*)scp, s1 = *(const float4*)(scp + 4);
     const float4 h0 = *(const float4*)(scp + a.Cin), h1 = *(const float4*)(scp + a.Cin + 4);
@@ -188,6 +200,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_patch_kernel(const ConvPAr
     uint4* p = (uint4*)(patch0 + pb * PATCH + (it * NT + tid) * 16);
     const uint4 u = *p;
     float v[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
+    if constexpr (SSL) {
+      const float* scp = ssl + fix_c * 64 + fix_j8;
+      const float4 s0 = *(const float4*)scp, s1 = *(const float4*)(scp + 4);
+      const float4 h0 = *(const float4*)(scp + a.Cin), h1 = *(const float4*)(scp + a.Cin + 4);
+      fsc[0] = s0.x; fsc[1] = s0.y; fsc[2] = s0.z; fsc[3] = s0.w; fsc[4] = s1.x; fsc[5] = s1.y; fsc[6] = s1.z; fsc[7] = s1.w;
+      fsh[0] = h0.x; fsh[1] = h0.y; fsh[2] = h0.z; fsh[3] = h0.w; fsh[4] = h1.x; fsh[5] = h1.y; fsh[6] = h1.z; fsh[7] = h1.w;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       v[j] = __builtin_fmaf(v[j], fsc[j], fsh[j]);
@@ -352,7 +371,7 @@ template <int TH, int TW, int BN, int WGM, int WGN, int NSTB>
 int launch_patch(const ConvPArgs& a0, hipStream_t s) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int PRMAX = ((TH + 2) * (TW + 2) + 7) / 8 * 8;
-  constexpr int LDS = 2 * PRMAX * 128 + NSTB * BN * 128;
+  constexpr int LDS = 2 * PRMAX * 128 + NSTB * BN * 128 + ((TH == 12 && BN == 320) ? 8192 : 0);   // + scale / shift [2][Cin <= 1024] (SSL)
   static_assert(LDS <= 160 * 1024, "LDS budget exceeds 160 KiB");
   ConvPArgs a = a0;
   a.tiles_x = (a.W + TW - 1) / TW;
@@ -420,7 +439,8 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
   a.tw = a.subpix ? 2 : 3;
   a.ldw = op->i[12] > 0 ? op->i[12] : a.T * a.Cin;
   a.rv_stride = op->i[13] ? 0 : a.N;
-  const int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N, a.subpix, a.B, a.H, a.W);
+  int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N, a.subpix, a.B, a.H, a.W);
+  if (!op->i[14] && variant == 6 && a.ss && a.C0 + C1 > 1024) variant = 3;   // (variant 6 keeps the fused norm's [2][Cin] vectors in 8 KB of LDS)
   a.sW = op->l[0];
   a.chunks = a.Cin / 64;
   a.c0t = a.C0 / 64;
@@ -445,7 +465,7 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
     case 4: return launch_patch<16, 16, 128, 4, 2, 2>(a, s);
     case 5: return launch_patch<8, 16, 128, 2, 2, 3>(a, s);
     case 6:   // 192 pixels x 320 channels / 12 waves (wave tile 32 x 160)
-      MG_REQUIRE(a.N % 320 == 0, "conv3x3: tile variant 6 needs N %% 320 == 0");
+      MG_REQUIRE(a.N % 320 == 0 && (!a.ss || a.Cin <= 1024), "conv3x3: tile variant 6 needs N %% 320 == 0 (and Cin <= 1024 with the fused norm)");
       return launch_patch<12, 16, 320, 6, 2, 2>(a, s);
     case 7:   // 192 pixels x 320 channels / 6 waves (wave tile 64 x 160)
       MG_REQUIRE(a.N % 320 == 0, "conv3x3: tile variant 7 needs N %% 320 == 0");
