@@ -83,10 +83,11 @@ enum mg_op_kind {
    *  i: B, HW, C, C0 (with x1), groups, silu ; f[0] eps.  The normalised form keeps the rows in registers: H x W x window
    *  <= 48 rows per thread of a 1024-thread workgroup (the UNet's 96^2 ... 12^2 levels at any width). */
   MG_OP_GN_SLAB = 9,
-  /* Row-resident GEMM for the token-local Linear layers at K = 320 (the widest transformer level): out[M][N] =
+  /* Row-resident GEMM for the token-local Linear layers at K = 320 / 640 (the two widest transformer levels): out[M][N] =
    * epilogue(x[M][K] W[N][K]^T).  A wave keeps 32 whole rows of x in registers for the launch and the weights stream past
    * it in 64-column stages, pre-packed in MFMA fragment order with a per-stage trailer of per-channel constants
-   * (marigold_amd/weights.py::pack_rowgemm; csrc/rowgemm.hip).  M % 32 == 0, N % 64 == 0, N >= 128.
+   * (marigold_amd/weights.py::pack_rowgemm; csrc/rowgemm.hip).  M % 32 == 0, N % 64 == 0, N >= 128; K = 640 runs 8 waves
+   * per workgroup (i[10] = 0 | 8), K = 320 4 / 8 / 12.
    *  p[0] x bf16 [M][ldx]  p[1] packed weights  p[2] out bf16 [M][ldo]  p[3] residual bf16 [M][ldr] | NULL (may alias out)
    *  p[4] (mean, rstd) f32 [M][2] of the rows of x | NULL: LayerNorm folded (the packed trailer holds its g and c vectors)
    *  p[5] (mean, rstd) f32 [M][2] of the OUTPUT rows | NULL  p[6] V^T bf16 [B][N - i[9]][ldt] (QKV form)
@@ -98,7 +99,9 @@ enum mg_op_kind {
    *  block - few rows, many columns; not with p[5]) ; f[0] LayerNorm eps of p[5].
    *  form 3: the collapsed 2-token cross-attention (as MG_EPI_XATTN2) in place on the residual stream: N = 64 score
    *  columns, i[11] = 2 x heads of them live, f[1] softmax scale; p[1] = weights.pack_rowgemm_xattn (scores stage + VO^T
-   *  fragments + bias), p[4] required, out[M][K] = P VO^T + bias + x, p[5] its row statistics; out may alias x. */
+   *  fragments + bias), p[4] required, out[M][K] = P VO^T + bias + x, p[5] its row statistics; out may alias x.  K = 640 /
+   *  1280 (the deeper levels): the K-split kernel - 32-row workgroups whose four waves split K and the output channels,
+   *  p[1] = weights.pack_rowgemm_xattn_ksplit.  p[8] (tuning only): per-wave phase cycle stamps | NULL. */
   MG_OP_ROWGEMM = 10,
   /* LayerNorm over the last dim. p[0] x bf16 [M][C] p[1] gamma f32 p[2] beta f32 p[3] out;
    * i: M,C ; f[0] eps */

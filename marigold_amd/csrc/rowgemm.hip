@@ -1,4 +1,4 @@
-// MG_OP_ROWGEMM: row-resident GEMM for the token-local Linear layers of the widest transformer level (gfx950 only).
+// MG_OP_ROWGEMM: row-resident GEMM for the token-local Linear layers of the two widest transformer levels (gfx950 only).
 //
 //   out[M][N] = epilogue( x[M][K] W[N][K]^T ),  K = 320 (the 96 x 96-token level of the SD2 UNet), M = B * tokens = 92 160
 //
@@ -278,7 +278,7 @@ void rowgemm_kernel(const RgArgs a) {
     }
     const unsigned long long d0 = d1;   // (stamps: stage start, end of the MFMA phase(s), end of the epilogue; the heads' waits apart)
     if constexpr (GEGLU) {
-      // tile 0 = 32 value channels, tile 1 = their gates (weights.pack_rowgemm_geglu); out column = 32 j + channel
+      // tile 0 = 32 value channels, tile 1 = their gates (weights.rowgemm_geglu_order); out column = 32 j + channel
       uint4 pk[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
