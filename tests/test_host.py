@@ -778,3 +778,65 @@ def test_rowgemm_weight_packing():
     order = Wm.rowgemm_geglu_order(512)
     assert sorted(order.tolist()) == list(range(512))
     assert order[:32].tolist() == list(range(32)) and order[32:64].tolist() == list(range(256, 288)) and order[64] == 32
+
+
+def test_rowgemm_cross_attention_packing():
+    """weights.pack_rowgemm_xattn (K = 320: scores stage + VO^T sub-stages + bias) and pack_rowgemm_xattn_ksplit (K = 640 / 1280:
+    per-wave K quarters) lay the fragments out as csrc/rowgemm.hip reads them."""
+    import torch
+    from marigold_amd import weights as Wm
+    g = torch.Generator().manual_seed(9)
+    chan = [(m & 0x13) | ((m & 4) << 1) | ((m & 8) >> 1) for m in range(32)]
+    # K = 320
+    k = 320
+    wqk, c, gg = torch.randn(64, k, generator=g), torch.randn(64, generator=g), torch.randn(64, generator=g)
+    vot, bias = torch.randn(k, 64, generator=g), torch.randn(k, generator=g)
+    pk = Wm.pack_rowgemm_xattn(wqk, c, gg, vot, bias)
+    assert pk.numel() == (41 + 40 + 2) * 1024
+    assert torch.equal(pk[:41 * 1024], Wm.pack_rowgemm(wqk, c, gg).reshape(-1))
+    fr = pk[41 * 1024: 81 * 1024].view(torch.bfloat16).view(k // 64, 2, 4, 2, 32, 8)    # [jj][t][s][g][mm][i]
+    vb = vot.to(torch.bfloat16)
+    for jj in range(k // 64):
+        for t in range(2):
+            for mm in range(32):
+                assert torch.equal(fr[jj, t, :, :, mm, :].reshape(-1), vb[64 * jj + 32 * t + chan[mm]])
+    tr = pk[81 * 1024:].view(torch.float32)
+    assert torch.equal(tr[:k], bias) and not tr[k:].any()
+    # K = 1280: wave w owns channels [320 w, 320 (w + 1)) on both sides
+    k = 1280
+    wqk, vot, bias = torch.randn(64, k, generator=g), torch.randn(k, 64, generator=g), torch.randn(k, generator=g)
+    pk = Wm.pack_rowgemm_xattn_ksplit(wqk, c, gg, vot, bias)
+    kq, ksq, nt2 = k // 4, k // 64, k // 128
+    n1, n2 = 4 * 2 * ksq * 1024, 4 * nt2 * 4 * 1024
+    assert pk.numel() == n1 + n2 + (128 + k) * 4
+    f1 = pk[:n1].view(torch.bfloat16).view(4, 2, ksq, 2, 32, 8)        # [w][t][s][g][mm][i]
+    f2 = pk[n1:n1 + n2].view(torch.bfloat16).view(4, nt2, 4, 2, 32, 8)   # [w][tt][s'][g][mm][i]
+    wb, vb = wqk.to(torch.bfloat16), vot.to(torch.bfloat16)
+    for w in range(4):
+        for t in range(2):
+            for mm in (0, 5, 12, 31):
+                assert torch.equal(f1[w, t, :, :, mm, :].reshape(-1), wb[32 * t + chan[mm], kq * w: kq * (w + 1)])
+        for tt in (0, nt2 - 1):
+            for mm in (0, 9, 31):
+                assert torch.equal(f2[w, tt, :, :, mm, :].reshape(-1), vb[kq * w + 32 * tt + chan[mm]])
+    fl = pk[n1 + n2:].view(torch.float32)
+    assert torch.equal(fl[:64], c) and torch.equal(fl[64:128], gg) and torch.equal(fl[128:], bias)
+
+
+def test_rowgemm_launch_shape_per_row_count():
+    """engine.Builder.rowgemm_cfg: 12 waves while 384-row workgroups still fill the chip, then 8, then 4 with the column stages
+    shared out (never for the whole-row-statistics forms); the K = 640 form always 8 waves with the columns split so that
+    workgroups <= CUs."""
+    from marigold_amd.engine import Builder
+    T = 9216
+    assert Builder.rowgemm_cfg(10 * T, 960) == dict(waves=12)
+    assert Builder.rowgemm_cfg(7 * T, 960) == dict(waves=12)
+    assert Builder.rowgemm_cfg(5 * T, 960) == dict(waves=8)
+    c1 = Builder.rowgemm_cfg(1 * T, 960)
+    assert c1["waves"] == 4 and c1["nsplit"] == 4          # 72 row blocks x 4 = 288 workgroups
+    assert Builder.rowgemm_cfg(1 * T, 320, whole_rows=True) == dict(waves=4)
+    assert Builder.rowgemm_cfg(2 * T, 320, xattn=True) == dict(waves=8)
+    w = Builder.rowgemm_cfg(10 * 2304, 1920, K=640)
+    assert w == dict(waves=8, nsplit=2)                    # 90 blocks x 2
+    w = Builder.rowgemm_cfg(5 * 2304, 5120, K=640)
+    assert w["waves"] == 8 and 45 * w["nsplit"] <= 256 and w["nsplit"] >= 4
