@@ -108,14 +108,27 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
       if (vc >= cv) break;
       const bf16_t* col = xb + vc * 8;
       int r = r0 + ty;
-      for (; r + 3 * tyn < r1; r += 4 * tyn) {  // 4 independent 16-byte loads in flight (8 measured slower)
-        const uint4 u0 = *(const uint4*)(col + (long long)r * C);
-        const uint4 u1 = *(const uint4*)(col + (long long)(r + tyn) * C);
-        const uint4 u2 = *(const uint4*)(col + (long long)(r + 2 * tyn) * C);
-        const uint4 u3 = *(const uint4*)(col + (long long)(r + 3 * tyn) * C);
-        acc8(v, u0); acc8(v, u1); acc8(v, u2); acc8(v, u3);
+      for (; r + 7 * tyn < r1; r += 8 * tyn) {  // 8 independent 16-byte loads in flight
+        uint4 u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = *(const uint4*)(col + (long long)(r + i * tyn) * C);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc8(v, u[i]);
       }
-      for (; r < r1; r += tyn) acc8(v, *(const uint4*)(col + (long long)r * C));
+      if (r < r1) {   // the tail as ONE batch (round 3): up to 7 loads in flight from clamped rows, zeroed past the chunk - as a
+                      // loop of single loads it was up to 7 serial HBM round trips (of ~2 us) at the end of every workgroup
+        uint4 u[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          const int ri = r + i * tyn;
+          u[i] = *(const uint4*)(col + (long long)(ri < r1 ? ri : r1 - 1) * C);
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          if (r + i * tyn >= r1) u[i] = make_uint4(0, 0, 0, 0);
+          acc8(v, u[i]);
+        }
+      }
     }
 #pragma unroll
     for (int v = 0; v < GN_NV; ++v) {

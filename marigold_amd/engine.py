@@ -339,11 +339,13 @@ class Builder:
             return self.gn_slab(srcs, name, eps, False, False)[0]
         B, HW = srcs[0].B, srcs[0].HW
         C = sum(x.C for x in srcs)
-        # ~768 (chunk, image) blocks: covers the 256 CUs three times over while keeping the
-        # second-level reduction (gn_finalize) short; >= 32 rows per chunk
-        chunks = max(1, min(HW // 32, max(16, 768 // B)))
-        # (round 2: splitting finer - 8 rows per thread on every level, or on the deep levels only - measured +5.6 ms per
-        # map / no change: profiles/r2_ab_gn_chunks_lost.log)
+        # ~288 (chunk, image) blocks - about one per CU - of >= 32 rows: with eight row loads in flight per thread and the
+        # chunk's tail fetched as one batch (round 3) a block streams its rows in 2-4 round trips, and the cost that is left
+        # grows with the NUMBER of blocks (tickets, the last block's table reduction): 59 MB at E = 10 takes 16.3 us with 24-32
+        # chunks per image against 23.5 with the 76 of round 2 (28.7 before the tail fix), profiles/r3_gn_stats_chunks.log
+        chunks = max(1, min(HW // 32, 64, max(8, 288 // B)))
+        if os.environ.get("MARIGOLD_GN_CHUNKS_R2") == "1":   # A/B: the round-2 rule
+            chunks = max(1, min(HW // 32, max(16, 768 // B)))
         slots = chunks * len(srcs)
         part = self.raw(B * slots * self.groups * 2 * 4)
         ss = self.raw(B * 2 * C * 4)
