@@ -263,6 +263,20 @@ int mg_ensemble_normals(const float* normals, float* out, float* unc, int E, int
  * No device work; fp64; summation order = numpy's (bit-identical to the numpy form it replaces). */
 int mg_ens_align_cost_grad(int E, const double* s, const double* t, const double* mean, const double* C,
                            double* cost, double* gs, double* gt);
+/* scipy.optimize.minimize(fn, x, jac=True, method="BFGS", tol=gtol, options={"maxiter": maxiter}) restated natively
+ * (scipy 1.15: _minimize_bfgs, DCSRCH line search with the Wolfe-2 fall-back, one objective evaluation per distinct point;
+ * csrc/bfgs.hip).  fn(user, n, x, &f, g) returns 0.  x in / out; status = scipy's warnflag (0 converged, 1 maxiter,
+ * 2 precision loss, 3 NaN).  n <= 256. */
+int mg_bfgs_minimize(int (*fn)(void* user, int n, const double* x, double* f, double* g), void* user, int n, double* x,
+                     double gtol, int maxiter, double* fval, int* nit, int* nfev, int* status);
+/* The whole alignment of ensemble_depth (marigold/util/ensemble.py:154-173: compute_param + scipy BFGS) as one call: the
+ * objective of mg_ens_align_cost_grad + the regulariser from one device pass per evaluation - reg_op, an
+ * MG_OP_ENS_DEPTH_MEDIAN op whose scale / shift input st_host [2E] and (min, max, member values) output mm_host [2 + 2E]
+ * live in host-mapped memory - times the forward-difference survival factor of the reference's fp32 parameter cast.
+ * affine: scale + shift (n = 2E) or scale only; reduction 0 median / 1 mean; lam = regulariser strength. */
+int mg_ens_align_minimize(const mg_op* reg_op, void* stream, int E, int affine, int reduction, double lam, const double* mean,
+                          const double* C, float* st_host, const float* mm_host, double* x, double gtol, int maxiter,
+                          double* fval, int* nit, int* nfev, int* status);
 
 /* HIP-event timing helpers for bench.py (the kernels run on the caller's stream). */
 void* mg_event_create(void);

@@ -33,7 +33,7 @@ EXPORTS = [
     "mg_abi_version", "mg_last_error", "mg_init", "mg_geglu_interleave", "mg_device_info", "mg_launch",
     "mg_program_create", "mg_program_num_ops", "mg_program_run", "mg_program_validate", "mg_program_run_range",
     "mg_program_capture", "mg_program_profile", "mg_program_destroy", "mg_conv2d_igemm", "mg_conv3x3",
-    "mg_sched_step", "mg_ensemble_normals", "mg_ens_align_cost_grad", "mg_event_create", "mg_event_record",
+    "mg_sched_step", "mg_ensemble_normals", "mg_ens_align_cost_grad", "mg_bfgs_minimize", "mg_ens_align_minimize", "mg_event_create", "mg_event_record",
     "mg_event_elapsed_ms", "mg_event_destroy",
 ]
 
@@ -72,6 +72,11 @@ def load():
     lib.mg_program_create.argtypes = [ctypes.POINTER(MgOp), ctypes.c_int]
     lib.mg_program_num_ops.argtypes = [ctypes.c_void_p]
     lib.mg_ens_align_cost_grad.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 7
+    lib.mg_bfgs_minimize.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.mg_ens_align_minimize.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.mg_program_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.mg_program_validate.argtypes = [ctypes.c_void_p]
     lib.mg_program_run_range.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]

@@ -30,6 +30,8 @@ How it runs on the device
   evaluation instead of 2E+1 cost evaluations x (E(E-1)/2 + 2) host syncs;
 * final align -> median (+MAD) -> normalise never leaves the device.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -39,6 +41,7 @@ _SCRATCH_BYTES = 12288
 _FD_STEP = 1.4901161193847656e-08   # scipy's forward-difference step (sqrt(eps)), absolute
 
 
+NATIVE_BFGS = os.environ.get("MARIGOLD_ENS_NATIVE_BFGS", "1") != "0"   # 0: scipy drives the alignment (A/B, parity of the native optimiser)
 MAX_ENSEMBLE_SIZE = 128   # depth / IID selection kernels: <= 32 members in registers, 33 ... 128 in LDS (csrc/ensemble.hip)
 
 
@@ -212,6 +215,22 @@ class DepthAligner:
     def cost(self, p):
         return self.cost_and_grad(p)[0]
 
+    def minimize_native(self, p0, tol, max_iter):
+        """scipy.optimize.minimize(self.reference_fd_objective, p0, jac=True, method="BFGS", tol=tol, maxiter=max_iter) as ONE
+        library call (mg_ens_align_minimize): -> (parameters, cost, iterations)."""
+        import ctypes
+        k = self._consts()
+        b = self.backend
+        x = np.array(p0, dtype=np.float64).copy()
+        fval, nit, nfev, status = ctypes.c_double(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        stream = torch.cuda.current_stream(b.d.device).cuda_stream
+        L.check(L.load().mg_ens_align_minimize(ctypes.addressof(b._reg_op), ctypes.c_void_p(stream), self.E, int(self.affine), int(self.red),
+                                               float(self.lam), k["mean_p"], k["C_p"], b._st_np.ctypes.data, b._mm_np.ctypes.data,
+                                               x.ctypes.data, float(tol), int(max_iter), ctypes.byref(fval), ctypes.byref(nit),
+                                               ctypes.byref(nfev), ctypes.byref(status)), "mg_ens_align_minimize")
+        self.n_eval += nfev.value
+        return x, fval.value, nit.value
+
     def reference_fd_objective(self, p):
         """(f, g) as the reference's scipy call sees them: g_i = analytic gradient x the share of the
         forward-difference step that survives the fp32 parameter cast."""
@@ -240,12 +259,18 @@ def ensemble_depth(depth, scale_invariant=True, shift_invariant=True, output_unc
             d_align = resize(d, (int(H * f), int(W * f)), InterpolationMode.NEAREST_EXACT)
         al = DepthAligner(d_align, scale_invariant, shift_invariant, reduction, regularizer_strength)
         p0 = al.init_param()
-        res = scipy.optimize.minimize(al.reference_fd_objective, p0, jac=True, method="BFGS", tol=tol,
-                                      options={"maxiter": max_iter, "disp": False})
-        p = res.x
+        if NATIVE_BFGS and isinstance(al.backend, HipStatsBackend):
+            # the optimiser and its objective run natively (csrc/bfgs.hip: scipy's BFGS + line searches restated operation for
+            # operation; tests/test_host.py compares iterates and evaluation counts with scipy's): an evaluation is the device
+            # pass + ~2 us instead of + 60-75 us of Python
+            p, cost, nit = al.minimize_native(p0, tol, max_iter)
+        else:
+            res = scipy.optimize.minimize(al.reference_fd_objective, p0, jac=True, method="BFGS", tol=tol,
+                                          options={"maxiter": max_iter, "disp": False})
+            p, cost, nit = res.x, float(res.fun), int(res.nit)
         s, t = al._split(p)
         st = torch.from_numpy(np.concatenate([s, t]).astype(np.float32)).to(dev)
-        info = dict(param=p, cost=float(res.fun), n_eval=al.n_eval, n_iter=int(res.nit), aligner=al)
+        info = dict(param=p, cost=cost, n_eval=al.n_eval, n_iter=nit, aligner=al)
     med = torch.empty(HW, dtype=torch.float32, device=dev)
     unc = torch.empty(HW, dtype=torch.float32, device=dev) if output_uncertainty else None
     mm = torch.empty(2 + 2 * E, dtype=torch.float32, device=dev)

@@ -840,3 +840,80 @@ def test_rowgemm_launch_shape_per_row_count():
     assert w == dict(waves=8, nsplit=2)                    # 90 blocks x 2
     w = Builder.rowgemm_cfg(5 * 2304, 5120, K=640)
     assert w["waves"] == 8 and 45 * w["nsplit"] <= 256 and w["nsplit"] >= 4
+
+
+def test_native_bfgs_follows_scipy():
+    """csrc/bfgs.hip restates scipy 1.15's BFGS (+ DCSRCH / Wolfe-2 line searches, one evaluation per distinct point): on smooth,
+    non-smooth and the alignment objective itself (a host stand-in for the device pass) the iterates agree to rounding and the
+    iteration / evaluation counts are equal - except where a run ends in scipy's "precision loss" branch, whose last step
+    depends on the last bit of a dot product (BLAS summation order)."""
+    import ctypes
+    import torch
+    from scipy.optimize import minimize
+    from marigold_amd import _lib as L, ensemble as E
+    lib = L.load()
+    CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                          ctypes.POINTER(ctypes.c_double))
+
+    def native(fun, x0, tol, maxiter):
+        def cb(user, n_, xp, fp, gp):
+            f, g = fun(np.ctypeslib.as_array(xp, (n_,)).copy())
+            fp[0] = f
+            for i in range(n_):
+                gp[i] = g[i]
+            return 0
+        c = CB(cb)
+        x = np.array(x0, dtype=np.float64).copy()
+        fval, nit, nfev, st = ctypes.c_double(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        L.check(lib.mg_bfgs_minimize(ctypes.cast(c, ctypes.c_void_p), None, len(x), x.ctypes.data, tol, maxiter, ctypes.byref(fval),
+                                     ctypes.byref(nit), ctypes.byref(nfev), ctypes.byref(st)), "mg_bfgs_minimize")
+        return x, fval.value, nit.value, nfev.value, st.value
+
+    def ref(fun, x0, tol, maxiter):
+        cnt = [0]
+
+        def f(x):
+            cnt[0] += 1
+            return fun(x)
+        r = minimize(f, x0, jac=True, method="BFGS", tol=tol, options={"maxiter": maxiter})
+        return r.x, float(r.fun), r.nit, cnt[0], r.status
+
+    def rosen(x):
+        f = np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2)
+        g = np.zeros_like(x)
+        g[:-1] += -400 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+        g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+        return f, g
+
+    a, b = native(rosen, np.array([-1.2, 1, 0.5, -0.3, 2.0]), 1e-6, 50), ref(rosen, np.array([-1.2, 1, 0.5, -0.3, 2.0]), 1e-6, 50)
+    assert a[2:] == b[2:] and np.allclose(a[0], b[0], rtol=1e-9, atol=1e-12) and abs(a[1] - b[1]) <= 1e-9 * abs(b[1])
+    kink = lambda x: (np.abs(x).sum() + 0.5 * (x ** 2).sum(), np.sign(x) + x)      # noqa: E731 - non-smooth: the Wolfe-2 fall-back, precision loss
+    a, b = native(kink, np.array([0.3, -0.7, 1.1]), 1e-6, 50), ref(kink, np.array([0.3, -0.7, 1.1]), 1e-6, 50)
+    assert a[2:] == b[2:] and np.allclose(a[0], b[0], atol=1e-12)
+
+    class FakeBackend:
+        def __init__(self, n, seed):
+            self.n, self.rng = n, np.random.default_rng(seed)
+
+        def stats(self):
+            n, r = self.n, self.rng
+            A = r.normal(size=(n, n))
+            self.dmn, self.dmx = r.uniform(0.0, 0.3, n), r.uniform(0.7, 1.0, n)
+            return r.uniform(0, 0.05, n), r.uniform(0.9, 1.1, n), r.normal(size=n) * 0.05 + 0.5, A @ A.T / n * 0.01 + np.eye(n) * 0.002
+
+        def regulariser(self, s32, t32):
+            a, b = self.dmn.astype(np.float32) * s32 + t32, self.dmx.astype(np.float32) * s32 + t32
+            k = (self.n - 1) // 2
+            return (float(np.sort(a)[k]), float(np.sort(b)[k]), self.dmn.astype(np.float32).astype(np.float64),
+                    self.dmx.astype(np.float32).astype(np.float64))
+
+    same = total = 0
+    for seed in range(6):
+        for n in (10, 4, 20):
+            al = E.DepthAligner(torch.zeros(n, 1, 4, 4), True, True, "median", 0.02, backend=FakeBackend(n, seed))
+            p0 = al.init_param()
+            a, b = native(al.reference_fd_objective, p0, 1e-6, 50), ref(al.reference_fd_objective, p0, 1e-6, 50)
+            assert np.allclose(a[0], b[0], rtol=1e-7, atol=1e-10) and a[2] == b[2] and abs(a[3] - b[3]) <= 2, (seed, n, a[1:], b[1:])
+            total += 1
+            same += a[2:] == b[2:]
+    assert same >= total - 2, (same, total)
