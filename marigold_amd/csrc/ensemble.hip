@@ -15,6 +15,8 @@
 // Normals (ensemble_normals :199-249): one fused per-pixel kernel (mean -> normalise -> cosine
 // -> arccos mean / pi -> argmax -> gather).
 // All HBM-bound streaming kernels: E*HW*4 B read per pass, coalesced over pixels.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -131,6 +133,30 @@ __device__ __forceinline__ float select_rank(const float (&a)[E_], int E, int k)
   return res;
 }
 
+// The benchmark's ensemble size: k-th smallest of <= 10 values through the 29-comparator sorting network (Knuth, TAOCP 3, n = 10;
+// 58 min / max against ~300 compare / add of the rank count above).  Entries past E are +inf; the VALUE of rank k under
+// (value, index) order is the k-th order statistic, whichever way ties are broken.
+__device__ __forceinline__ float select_kth10(const float (&v)[10], int E, int k) {
+  float a[10];
+#pragma unroll
+  for (int e = 0; e < 10; ++e) a[e] = e < E ? v[e] : __builtin_inff();
+#define MG_CE(i, j) { const float lo = fminf(a[i], a[j]), hi = fmaxf(a[i], a[j]); a[i] = lo; a[j] = hi; }
+  MG_CE(4, 9) MG_CE(3, 8) MG_CE(2, 7) MG_CE(1, 6) MG_CE(0, 5) MG_CE(1, 4) MG_CE(6, 9) MG_CE(0, 3) MG_CE(5, 8) MG_CE(0, 2)
+  MG_CE(3, 6) MG_CE(7, 9) MG_CE(0, 1) MG_CE(2, 4) MG_CE(5, 7) MG_CE(8, 9) MG_CE(1, 2) MG_CE(4, 6) MG_CE(7, 8) MG_CE(3, 5)
+  MG_CE(2, 5) MG_CE(6, 8) MG_CE(1, 3) MG_CE(4, 7) MG_CE(2, 3) MG_CE(6, 7) MG_CE(3, 4) MG_CE(5, 6) MG_CE(4, 5)
+#undef MG_CE
+  float r = a[0];
+#pragma unroll
+  for (int e = 1; e < 10; ++e)
+    if (e == k) r = a[e];
+  return r;
+}
+template <int E_>
+__device__ __forceinline__ float select_kth(const float (&a)[E_], int E, int k) {
+  if constexpr (E_ == 10) return select_kth10(a, E, k);
+  else return select_rank<E_>(a, E, k);
+}
+
 // E_ = compile-time upper bound of E (registers); st = [s[E], t[E]] fp32; reduction 0 median 1 mean
 template <int E_>
 __global__ __launch_bounds__(256) void depth_median_kernel(const float* __restrict__ d, const float* __restrict__ st,
@@ -149,24 +175,19 @@ __global__ __launch_bounds__(256) void depth_median_kernel(const float* __restri
   }
   float mn = 3.0e38f, mx = -3.0e38f;
   const int k = (E - 1) >> 1;  // torch.median: lower middle
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+  auto pixel = [&](const float (&raw)[E_], long long p, float& pred, float& unc) {
     float a[E_];
 #pragma unroll
-    for (int e = 0; e < E_; ++e) {
-      if (e < E) {
-        const float v = d[(long long)e * HW + p];
-        // reference: depth * s + t as two separately rounded fp32 ops (ensemble.py:112)
-        a[e] = aligned ? __fadd_rn(__fmul_rn(v, sc[e]), sh[e]) : v;
-      } else a[e] = 0.f;
-    }
-    float pred, unc = 0.f;
+    for (int e = 0; e < E_; ++e)   // reference: depth * s + t as two separately rounded fp32 ops (ensemble.py:112)
+      a[e] = e < E ? (aligned ? __fadd_rn(__fmul_rn(raw[e], sc[e]), sh[e]) : raw[e]) : 0.f;
+    unc = 0.f;
     if (reduction == 0) {
-      pred = select_rank<E_>(a, E, k);
+      pred = select_kth<E_>(a, E, k);
       if (mad) {
         float dv[E_];
 #pragma unroll
         for (int e = 0; e < E_; ++e) dv[e] = fabsf(__fsub_rn(a[e], pred));
-        unc = select_rank<E_>(dv, E, k);
+        unc = select_kth<E_>(dv, E, k);
       }
     } else {
       float s = 0.f;
@@ -182,10 +203,35 @@ __global__ __launch_bounds__(256) void depth_median_kernel(const float* __restri
         unc = sqrtf(q / (float)(E > 1 ? E - 1 : 1));  // torch.std: unbiased
       }
     }
-    if (med) med[p] = pred;
-    if (mad) mad[p] = unc;
     if (pred < mn) { mn = pred; pmn = p; }
     if (pred > mx) { mx = pred; pmx = p; }
+  };
+  // four consecutive pixels per thread and pass (16-byte loads, E of them in flight): the optimiser calls this pass ~100 times
+  // per map and as one pixel per thread it was 4-5 dependent HBM round trips long (19 us for 23.6 MB; round 3)
+  const long long HW4 = (HW & 3) == 0 && (((uintptr_t)d | (uintptr_t)med | (uintptr_t)mad) & 15) == 0 ? HW : 0;
+  for (long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; p < HW4; p += (long long)gridDim.x * 1024) {
+    float4 v[E_];
+#pragma unroll
+    for (int e = 0; e < E_; ++e) v[e] = e < E ? *(const float4*)(d + (long long)e * HW + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float pr[4], un[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float raw[E_];
+#pragma unroll
+      for (int e = 0; e < E_; ++e) raw[e] = i == 0 ? v[e].x : (i == 1 ? v[e].y : (i == 2 ? v[e].z : v[e].w));
+      pixel(raw, p + i, pr[i], un[i]);
+    }
+    if (med) *(float4*)(med + p) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+    if (mad) *(float4*)(mad + p) = make_float4(un[0], un[1], un[2], un[3]);
+  }
+  for (long long p = HW4 + (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+    float raw[E_];
+#pragma unroll
+    for (int e = 0; e < E_; ++e) raw[e] = e < E ? d[(long long)e * HW + p] : 0.f;
+    float pred, unc;
+    pixel(raw, p, pred, unc);
+    if (med) med[p] = pred;
+    if (mad) mad[p] = unc;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -414,6 +460,8 @@ int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
       else if (E <= 10) launch_median<10>(op, nblk, s);
       else if (E <= 16) launch_median<16>(op, nblk, s);
       else launch_median<EMAX>(op, nblk, s);
+      // (round 3: finishing the reduction in the median kernel's last-arriving block instead - fence + ticket per block - measured
+      // SLOWER than this 5 us launch: 40-41 vs 34-36 us per pass, profiles/r3_ab_native_bfgs_alignment.log)
       MG_LAUNCH(minmax_final_kernel, dim3(1), dim3(64), 0, s, (const float*)op->p[5],
                          (const long long*)((char*)op->p[5] + 8 * ENS_BLOCKS), (const float*)op->p[0],
                          (float*)op->p[4], nblk, E, HW);
