@@ -190,6 +190,17 @@ def calibration(dev):
         ms = min(timeit(lambda: dst.copy_(src), 5) for _ in range(3))
         out["copy_1gib_gbs"] = round(2.0 * (1 << 30) / ms / 1e6, 1)   # bytes read + written
         del src, dst
+        # the shader clock this box sustains under matrix-core load, measured IN the kernel (s_memtime against the 100 MHz
+        # s_memrealtime around a fixed MFMA chain, one wave per SIMD on every CU; csrc/runtime.hip::mg_clock_probe) - the
+        # sysfs sensors do not answer on every box of the pool (round 3: constant idle values through the run)
+        import ctypes
+        from marigold_amd import _lib as L
+        mhz, tf = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for key, zero in (("shader_mhz_under_mfma_load", 0), ("shader_mhz_under_mfma_load_zero_operands", 1)):
+            if L.load().mg_clock_probe(stream, zero, ctypes.byref(mhz), ctypes.byref(tf)) == 0:
+                out[key] = round(mhz.value, 1)
+                out[key.replace("shader_mhz", "mfma_chain_tflops")] = round(tf.value, 1)
         torch.cuda.empty_cache()
         out["device"] = torch.cuda.get_device_name(dev)
         out["idle"] = GpuTelemetry(dev.index or 0).sample()
@@ -374,17 +385,12 @@ def main():
                 prog.seq.capture()
         torch.cuda.synchronize()
         out = pipe(img, **kw)
-    telemetry = GpuTelemetry(dev.index or 0) if rank == 0 else None
     barrier()
-    if telemetry:
-        telemetry.start()
     t1 = time.perf_counter()
     for _ in range(args.steps):
         out = pipe(img, **kw)
     barrier()
     dt = time.perf_counter() - t1
-    if telemetry and calib is not None:
-        calib["timed_region"] = telemetry.stop()
     tt = torch.tensor([dt], device="cpu" if (world > 1 and dist.get_backend() == "gloo") else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 2
+#define MG_ABI_VERSION 3
 
 enum mg_op_kind {
   /* conv3x3 / conv1x1 / Linear / batched GEMM as ONE implicit-GEMM bf16 MFMA kernel.
@@ -277,6 +277,12 @@ int mg_bfgs_minimize(int (*fn)(void* user, int n, const double* x, double* f, do
 int mg_ens_align_minimize(const mg_op* reg_op, void* stream, int E, int affine, int reduction, double lam, const double* mean,
                           const double* C, float* st_host, const float* mm_host, double* x, double gtol, int maxiter,
                           double* fval, int* nit, int* nfev, int* status);
+
+/* Shader clock under matrix-core load, for bench.py's calibration block (the sysfs sensors do not answer on every box): one
+ * workgroup per CU (one wave per SIMD) runs a fixed chain of v_mfma_f32_32x32x16_bf16 on random (zero_operands = 0) or zero
+ * operands for ~2 ms and times it with s_memtime (shader cycles) against s_memrealtime (100 MHz).  mhz = mean over the
+ * workgroups; tflops = the chain's rate (the clock-limited MFMA roof of this box on this data).  Synchronises the stream. */
+int mg_clock_probe(void* stream, int zero_operands, double* mhz, double* tflops);
 
 /* HIP-event timing helpers for bench.py (the kernels run on the caller's stream). */
 void* mg_event_create(void);

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MARIGOLD_HIP_LIB") or os.path.join(_HERE, "libmarigold_hip.so")   # (override: same-box A/B of two builds)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enum mg_op_kind
 OP_IGEMM, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_LAYERNORM = 1, 2, 3, 4, 5
@@ -34,7 +34,7 @@ EXPORTS = [
     "mg_program_create", "mg_program_num_ops", "mg_program_run", "mg_program_validate", "mg_program_run_range",
     "mg_program_capture", "mg_program_profile", "mg_program_destroy", "mg_conv2d_igemm", "mg_conv3x3",
     "mg_sched_step", "mg_ensemble_normals", "mg_ens_align_cost_grad", "mg_bfgs_minimize", "mg_ens_align_minimize", "mg_event_create", "mg_event_record",
-    "mg_event_elapsed_ms", "mg_event_destroy",
+    "mg_event_elapsed_ms", "mg_event_destroy", "mg_clock_probe",
 ]
 
 
@@ -88,6 +88,7 @@ def load():
     lib.mg_ensemble_normals.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
     lib.mg_device_info.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                    ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_int]
+    lib.mg_clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     lib.mg_event_create.restype = ctypes.c_void_p
     lib.mg_event_record.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.mg_event_elapsed_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]

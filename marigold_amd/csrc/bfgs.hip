@@ -17,6 +17,14 @@
 // one device pass per evaluation (the caller's MG_OP_ENS_DEPTH_MEDIAN op writing into host-mapped memory), and the
 // forward-difference survival factor of the reference's fp32 parameter cast.
 // Built with -ffp-contract=off (Makefile) like ensemble.hip: no fused multiply-adds where numpy has none.
+//
+// The control flow restated here is scipy's (not the reference's): SciPy is BSD-3-Clause,
+//   Copyright (c) 2001-2002 Enthought, Inc. 2003, SciPy Developers.  All rights reserved.
+//   Redistribution and use in source and binary forms, with or without modification, are permitted provided that the
+//   conditions of the BSD 3-Clause licence are met (THIRD_PARTY_LICENSES.md at the repository root carries its full text;
+//   DCSRCH / dcstep are the MINPACK-2 line search by More' and Thuente as translated in scipy/optimize/_dcsrch.py).
+// The parity test pins the version this file follows: tests/test_host.py::test_native_bfgs_follows_scipy skips unless scipy
+// is 1.15.x.
 #include <math.h>
 #include <string.h>
 

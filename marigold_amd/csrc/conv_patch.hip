@@ -468,7 +468,7 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
       MG_REQUIRE(a.N % 320 == 0 && (!a.ss || a.Cin <= 1024), "conv3x3: tile variant 6 needs N %% 320 == 0 (and Cin <= 1024 with the fused norm)");
       return launch_patch<12, 16, 320, 6, 2, 2>(a, s);
     case 7:   // 192 pixels x 320 channels / 6 waves (wave tile 64 x 160)
-      MG_REQUIRE(a.N % 320 == 0, "conv3x3: tile variant 7 needs N %% 320 == 0");
+      MG_REQUIRE(a.N % 320 == 0 && (!a.ss || a.Cin <= 1024), "conv3x3: tile variant 7 needs N %% 320 == 0 (and Cin <= 1024 with the fused norm)");
       return launch_patch<12, 16, 320, 3, 2, 2>(a, s);
     case 8:   // 24 x 16 pixels x 128 channels / 12 waves (wave tile 64 x 64): the VAE's 128-channel 768^2 level
       MG_REQUIRE(a.N % 128 == 0, "conv3x3: tile variant 8 needs N %% 128 == 0");

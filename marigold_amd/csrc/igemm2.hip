@@ -174,6 +174,13 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
       if constexpr (!TRANS) return launch2<256, 256, 2, 2, 2, false, true, false, 0, 64, -1, 1>(a, batch_z, s);
       else MG_REQUIRE(false, "igemm: tile variant 71 has no transposed section");
       return 0;
+    case 72:   // the same tile, K loop placed by hand (LOOP == 3): offsets are 32-bit, relative to the operand bases
+      if constexpr (!TRANS) {
+        MG_REQUIRE((long long)(a.M / a.rows_per_img) * a.H * a.W * max(a.lda, a.lda1) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30),
+                   "igemm: tile variant 72 addresses its operands with 31-bit byte offsets");
+        return launch2<256, 256, 2, 2, 2, false, false, false, 0, 64, -1, 2>(a, batch_z, s);
+      } else MG_REQUIRE(false, "igemm: tile variant 72 has no transposed section");
+      return 0;
     case 46: return launch2<128, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);   // full-width tiles for N = 320
     case 47:   // (no transposed instantiation: 160 accumulators + the token-major epilogue do not fit 256 VGPRs)
       if constexpr (!TRANS) return launch2<256, 320, 4, 2, 2, false, true>(a, batch_z, s);
@@ -234,7 +241,10 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.up2 = (a.Hu == 2 * a.H) && (a.Wu == 2 * a.W);
   a.tw = a.taps == 9 ? 3 : (a.taps == 4 ? 2 : 1);
   a.subpix = a.taps == 4;
-  a.splits = variant ? -1 : 0;   // split-K only under the automatic tile choice
+  {   // split-K only under the automatic tile choice (tuning sweeps: MARIGOLD_IGEMM_SPLITK_ANY=1 lets a forced tile split too)
+    static const int any = [] { const char* e = getenv("MARIGOLD_IGEMM_SPLITK_ANY"); return (e && e[0] == '1') ? 1 : 0; }();
+    a.splits = (variant && !any) ? -1 : 0;
+  }
   a.ln_out = (float2*)op->p[8];
   a.ln_in = (const float2*)op->p[9];
   a.ln_g = (const float*)op->p[10];

@@ -6,6 +6,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "igemm2_k4w.inc"
 
 namespace {
 
@@ -89,7 +90,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // eight MFMAs).
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, int LOOP, int ABL, int BK, int PPOPT = 0>
 __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
-  constexpr bool PF = LOOP == 1, PP = LOOP == 2;
+  constexpr bool PF = LOOP == 1, PP = LOOP == 2, K4 = LOOP == 3;
+  static_assert(!K4 || (BM == 256 && BN == 256 && WGM == 2 && WGN == 2 && NSTAGE == 2 && BK == 64 && ABL == 0 && !TRANS),
+                "the hand-placed one-wave-per-SIMD schedule is written for the 256x256 / 4-wave / 2-buffer tile");
   static_assert(!PP || (BM == 256 && BN == 256 && WGM == 2 && WGN == 4 && NSTAGE == 2 && BK == 64 && ABL == 0),
                 "the ping-pong schedule is written for the 256x256 / 8-wave / 2-stage tile");
   constexpr int NT = WGM * WGN * 64;
@@ -270,12 +273,12 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) rowB[ni] = PP ? ni * 128 + wn * 32 + l31 : wn * TN + ni * 32 + l31;
 
-  if constexpr (!PP) {
+  if constexpr (!PP && !K4) {
 #pragma unroll
     for (int d = 0; d < D; ++d)
       if (d < KT) issue(d);
   }
-  if constexpr (!PP) {
+  if constexpr (!PP && !K4) {
     ln_publish();
     zero_acc();
   }
@@ -324,7 +327,180 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
       }
   };
 
-  if constexpr (PP) {
+  if constexpr (K4) {
+    // ---- LOOP == 3: 256 x 256 tile on FOUR waves (one per SIMD, 128 x 128 wave tile, accumulators in AGPRs), the K tile's
+    // instruction stream placed by hand (gen_k4w.py -> igemm2_k4w.inc; schedule and its reasons in the generator's header).
+    // Staging differs from the other loops in two ways that take every VALU instruction out of the steady state:
+    //   * LDS-DMA through BUFFER loads: a wave-uniform resource (base in SGPRs, advanced by SALU adds - 128 bytes per K
+    //     tile) + a per-lane 32-bit byte offset that only changes with the tap / source; padding rows carry an offset beyond
+    //     num_records (2 GiB), for which the buffer load writes zeros - no zero page, no per-lane 64-bit pointer arithmetic;
+    //   * fragment reads at immediate offsets from eight address registers (one per k-step and operand), the buffer
+    //     selected by XOR 0x8000.
+    // LDS: pixel rows of buffer 0 / 1 at 0 / 32768, weight rows at 65536 / 98304, 128-byte rows, 16-byte chunks XOR-swizzled
+    // as in the other loops (the DMA source address carries the swizzle).
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(A_IT == 8 && B_IT == 8 && MI == 4 && NI == 4 && KS == 4, "k4w geometry");
+    unsigned va[8], vb[8];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int ci = it * NT + tid;
+      const int r = ci / CPR, p = ci % CPR;
+      const int n = n0 + r;
+      vb[it] = n < a.n_end ? (unsigned)(n * a.ldw + swz(p, r) * 8) * 2u : OOB;
+    }
+    // Operand bases live in SGPRs as (lo, hi) halves (readfirstlane'd: hipcc otherwise keeps a 64-bit induction variable in
+    // VGPRs and hands the asm a VGPR tuple for its "s" operand).
+    auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    unsigned loA = 0, hiA = 0, loB, hiB;
+    {
+      const unsigned long long b = (unsigned long long)(uintptr_t)Wb + (unsigned long long)kt0 * ROWB;
+      loB = sgpr((unsigned)b);
+      hiB = sgpr((unsigned)(b >> 32));
+    }
+    auto add_base = [](unsigned& lo, unsigned& hi, unsigned bytes) {
+      const unsigned n = lo + bytes;
+      hi += n < lo ? 1u : 0u;
+      lo = n;
+    };
+    auto tap_setup4 = [&](int tap, bool second) {
+      int dy = 0, dx = 0;
+      const int ld = second ? a.lda1 : a.lda;
+      const unsigned long long b = (unsigned long long)(uintptr_t)(second ? A1b : Ab);
+      loA = sgpr((unsigned)b);
+      hiA = sgpr((unsigned)(b >> 32));
+      if (a.lin) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) va[it] = a_by[it] >= 0 ? (unsigned)(a_by[it] * ld + a_qoff[it]) * 2u : OOB;
+        return;
+      }
+      if (a.tw > 1) { dy = a.tw == 3 ? (tap * 11) >> 5 : tap >> 1; dx = tap - dy * a.tw; }
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) {
+        int iy = a_by[it] + dy, ix = a_bx[it] + dx;
+        const bool ok = (unsigned)iy < (unsigned)hb && (unsigned)ix < (unsigned)wb;
+        if (a.Hu) {
+          if (a.up2) { iy >>= 1; ix >>= 1; }
+          else { iy = ok ? (iy * a.H) / a.Hu : 0; ix = ok ? (ix * a.W) / a.Wu : 0; }
+        }
+        va[it] = ok ? (unsigned)((a_img[it] + iy * a.W + ix) * ld + a_qoff[it]) * 2u : OOB;
+      }
+    };
+    // The K tiles are staged in SEGMENTS (one tap of one source): inside a segment the per-lane offsets are fixed and a tile
+    // costs two SALU adds; (j_tap, j_c) = the next tile to stage, seg_left = tiles left in its segment.
+    int j_tap = kt0 ? fdiv(kt0, a.fd_cpt) : 0, j_c = kt0 - j_tap * a.cpt;
+    int seg_left;
+    {
+      const bool second = j_c >= a.c0t;
+      tap_setup4(j_tap, second);
+      add_base(loA, hiA, (unsigned)(second ? j_c - a.c0t : j_c) * ROWB);
+      seg_left = second ? a.cpt - j_c : a.c0t - j_c;
+    }
+    auto next_segment = [&]() {   // called with seg_left == 0 and at least one more tile to stage
+      if (j_c == a.cpt) {
+        j_c = 0;
+        ++j_tap;
+        tap_setup4(j_tap, false);
+        seg_left = a.c0t;
+      } else {
+        tap_setup4(j_tap, true);
+        seg_left = a.cpt - a.c0t;
+      }
+    };
+    auto srd_of = [](unsigned lo, unsigned hi) {
+      const i32x4 r = {(int)lo, (int)(hi & 0xffffu), (int)OOB, 0x00020000};
+      return r;
+    };
+    const int sw = (l31 >> 1) & 7;
+    int la[KS], lb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int q = (((2 * ks + half) ^ sw) << 4) + l31 * ROWB;
+      la[ks] = wm * (TM * ROWB) + q;
+      lb[ks] = NSTAGE * BM * ROWB + wn * (TN * ROWB) + q;
+    }
+    int ma = wave * 1024;   // LDS address of this wave's first pixel-side piece in the buffer being filled
+    int staged = 0;         // tiles staged so far
+    auto stage_tile = [&]() {   // prologue only: the steady state stages from inside the hand-placed stream
+      const i32x4 sa = srd_of(loA, hiA), sb = srd_of(loB, hiB);
+#pragma unroll
+      for (int it = 0; it < 8; ++it)
+        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                     :: "v"(va[it]), "s"(sa), "s"(ma), "n"(it * 4096) : "memory", "scc");
+#pragma unroll
+      for (int it = 0; it < 8; ++it)
+        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                     :: "v"(vb[it]), "s"(sb), "s"(ma), "n"(NSTAGE * BM * ROWB + it * 4096) : "memory", "scc");
+      add_base(loA, hiA, ROWB);
+      add_base(loB, hiB, ROWB);
+      ma ^= BM * ROWB;
+      ++staged;
+      ++j_c;
+      if (--seg_left == 0 && staged < KT) next_segment();
+    };
+    bf16x8 fa4[KS][MI], fb4[KS][NI];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa4[ks][i] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+        fb4[ks][i] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+      }
+    }
+    stage_tile();                 // tile 0 -> buffer 0
+    if (KT > 1) stage_tile();     // tile 1 -> buffer 1
+    ln_publish();
+    zero_acc();
+    if (KT > 1) wait_vmcnt<16>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+#define K4W_C(ni, mi) [c##ni##mi] "+a"(acc[ni][mi])
+#define K4W_A(ks, i) [a##ks##i] "+v"(fa4[ks][i])
+#define K4W_B(ks, i) [b##ks##i] "+v"(fb4[ks][i])
+#define K4W_OUT                                                                                                             \
+  K4W_C(0, 0), K4W_C(0, 1), K4W_C(0, 2), K4W_C(0, 3), K4W_C(1, 0), K4W_C(1, 1), K4W_C(1, 2), K4W_C(1, 3), K4W_C(2, 0),      \
+  K4W_C(2, 1), K4W_C(2, 2), K4W_C(2, 3), K4W_C(3, 0), K4W_C(3, 1), K4W_C(3, 2), K4W_C(3, 3),                                \
+  K4W_A(0, 0), K4W_A(0, 1), K4W_A(0, 2), K4W_A(0, 3), K4W_A(1, 0), K4W_A(1, 1), K4W_A(1, 2), K4W_A(1, 3), K4W_A(2, 0),      \
+  K4W_A(2, 1), K4W_A(2, 2), K4W_A(2, 3), K4W_A(3, 0), K4W_A(3, 1), K4W_A(3, 2), K4W_A(3, 3),                                \
+  K4W_B(0, 0), K4W_B(0, 1), K4W_B(0, 2), K4W_B(0, 3), K4W_B(1, 0), K4W_B(1, 1), K4W_B(1, 2), K4W_B(1, 3), K4W_B(2, 0),      \
+  K4W_B(2, 1), K4W_B(2, 2), K4W_B(2, 3), K4W_B(3, 0), K4W_B(3, 1), K4W_B(3, 2), K4W_B(3, 3),                                \
+  [la0] "+v"(la[0]), [la1] "+v"(la[1]), [la2] "+v"(la[2]), [la3] "+v"(la[3]),                                              \
+  [lb0] "+v"(lb[0]), [lb1] "+v"(lb[1]), [lb2] "+v"(lb[2]), [lb3] "+v"(lb[3])
+#define K4W_IN                                                                                                              \
+  [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [va3] "v"(va[3]), [va4] "v"(va[4]), [va5] "v"(va[5]),              \
+  [va6] "v"(va[6]), [va7] "v"(va[7]), [vb0] "v"(vb[0]), [vb1] "v"(vb[1]), [vb2] "v"(vb[2]), [vb3] "v"(vb[3]),              \
+  [vb4] "v"(vb[4]), [vb5] "v"(vb[5]), [vb6] "v"(vb[6]), [vb7] "v"(vb[7]), [sa] "s"(sa), [sb] "s"(sb), [ma] "s"(ma)
+    {
+      const i32x4 sa = srd_of(loA, hiA), sb = srd_of(loB, hiB);
+      asm volatile(K4W_ASM_PROLOGUE : K4W_OUT : K4W_IN : "memory", "scc");
+    }
+    // steady state: while tile t is computed, tile t + 2 is staged into the buffer it is read from - one stream per tile,
+    // grouped by the segment of the STAGED tile (the computed tile needs no addressing state at all)
+    while (staged < KT) {
+      const int n = min(seg_left, KT - staged);
+      for (int i = 0; i < n; ++i) {
+        const i32x4 sa = srd_of(loA, hiA), sb = srd_of(loB, hiB);
+        asm volatile(K4W_ASM_FULL : K4W_OUT : K4W_IN : "memory", "scc");
+        add_base(loA, hiA, ROWB);
+        add_base(loB, hiB, ROWB);
+        ma ^= BM * ROWB;
+      }
+      staged += n;
+      j_c += n;
+      seg_left -= n;
+      if (seg_left == 0 && staged < KT) next_segment();
+    }
+    {
+      const i32x4 sa = srd_of(loA, hiA), sb = srd_of(loB, hiB);
+      if (KT > 1) asm volatile(K4W_ASM_NODMA : K4W_OUT : K4W_IN : "memory", "scc");
+      asm volatile(K4W_ASM_LAST : K4W_OUT : K4W_IN : "memory", "scc");
+    }
+#undef K4W_C
+#undef K4W_A
+#undef K4W_B
+#undef K4W_OUT
+#undef K4W_IN
+  } else if constexpr (PP) {
     // Half tiles of K tile t (each 128 LDS rows = two DMA pieces per wave), in consumption order:
     //   H0 = A rows {mi 0,1}  H1 = B rows {ni 0}  H2 = B rows {ni 1}  H3 = A rows {mi 2,3}
     // Phase p of tile t:  P1 reads H0+H1 -> acc(mi 0,1 x ni 0)   P2 reads H2 -> acc(mi 0,1 x ni 1)

@@ -229,6 +229,12 @@ class DepthAligner:
                                                x.ctypes.data, float(tol), int(max_iter), ctypes.byref(fval), ctypes.byref(nit),
                                                ctypes.byref(nfev), ctypes.byref(status)), "mg_ens_align_minimize")
         self.n_eval += nfev.value
+        self.status = status.value   # scipy's warnflag: 0 converged, 1 maxiter, 2 precision loss, 3 NaN
+        if status.value == 3 or not np.all(np.isfinite(x)):
+            import warnings
+            warnings.warn("ensemble_depth: the alignment optimiser ended on non-finite parameters (status "
+                          f"{status.value}); the alignment falls back to its starting point")
+            return np.array(p0, dtype=np.float64), float("nan"), nit.value
         return x, fval.value, nit.value
 
     def reference_fd_objective(self, p):
@@ -270,7 +276,7 @@ def ensemble_depth(depth, scale_invariant=True, shift_invariant=True, output_unc
             p, cost, nit = res.x, float(res.fun), int(res.nit)
         s, t = al._split(p)
         st = torch.from_numpy(np.concatenate([s, t]).astype(np.float32)).to(dev)
-        info = dict(param=p, cost=cost, n_eval=al.n_eval, n_iter=nit, aligner=al)
+        info = dict(param=p, cost=cost, n_eval=al.n_eval, n_iter=nit, aligner=al, status=getattr(al, "status", None))
     med = torch.empty(HW, dtype=torch.float32, device=dev)
     unc = torch.empty(HW, dtype=torch.float32, device=dev) if output_uncertainty else None
     mm = torch.empty(2 + 2 * E, dtype=torch.float32, device=dev)
