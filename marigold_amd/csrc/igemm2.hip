@@ -111,6 +111,7 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   if (!TRANS && a.splits == 0 && batch_z == 1 && a.epi == MG_EPI_BF16 && a.n_begin == 0 && a.n_end == a.N &&
       tiles < 160 && b.KT >= 32 && g_splitk_ws) {   // (a wider window, < 256 tiles, measured no gain)
     int sp = (int)min((long long)8, (320 + tiles - 1) / tiles);
+    if constexpr (BIG == 2) sp = (int)min((long long)8, max(1ll, 256 / tiles));   // one workgroup per CU: a single round of <= 256
     sp = min(sp, b.KT / 12);
     while (sp > 1 && (long long)sp * a.M * a.N * 4 > MG_SPLITK_WS_BYTES) --sp;
     if (sp > 1) {
@@ -336,7 +337,9 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
     m.N = nmain;
     m.n_begin = 0;
     m.n_end = nmain;
-    const int v = variant ? variant : mg_igemm_auto_variant(m.M, m.n_end, K, batch_z, geglu);
+    int v = variant ? variant : mg_igemm_auto_variant(m.M, m.n_end, K, batch_z, geglu);
+    if (!variant && v == 72 && !((long long)(a.M / a.rows_per_img) * a.H * a.W * max(a.lda, a.lda1) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30)))
+      v = 62;   // operands beyond the hand-placed loop's 31-bit byte offsets
     rc = dispatch_tile<false>(m, batch_z, v, s);
     if (rc) return rc;
   }
@@ -358,7 +361,8 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
     tns.rowvec = nullptr;
     tns.res = nullptr;
     tns.epi = MG_EPI_BF16;
-    const int v = variant ? variant : mg_igemm_auto_variant(tns.M, tns.N, K, batch_z, 0);
+    int v = variant ? variant : mg_igemm_auto_variant(tns.M, tns.N, K, batch_z, 0);
+    if (!variant && v == 72) v = 62;   // (the hand-placed loop has no transposed instantiation)
     rc = dispatch_tile<true>(tns, batch_z, v, s);
   }
   return rc;
@@ -381,8 +385,17 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
     // of the 12 row tiles re-reads the 30-59 MB of weights; 256 x 256 tiles read them 6 times and split-K (30 tiles x 8
     // splits) fills the chip: 77 -> 68 us (1280 -> 1280), 144 -> 105 us (2560 -> 1280), profiles/r3_deep_conv_tiles.log.
     // MARIGOLD_DEEP_TILE=<variant> | 0 (off) for A/B runs.
-    static const int deep = [] { const char* e = getenv("MARIGOLD_DEEP_TILE"); return e ? atoi(e) : 62; }();
+    static const int deep = [] { const char* e = getenv("MARIGOLD_DEEP_TILE"); return e ? atoi(e) : 72; }();
     if (deep && !geglu && batch_z == 1 && M >= 1152 && M <= 2048 && K >= 5760 && N % 256 == 0) return deep;   // (E >= 8 at 12 x 12)
+  }
+  {
+    // Round 4: the hand-placed four-wave K loop (variant 72: one wave per SIMD, 128 x 128 wave tile) for the long-K convolutions
+    // whose tile count fits its ONE workgroup per CU - the 24 x 24 level (M = 5 760 at E = 10: 23 x 5 tiles x 2 K splits) and
+    // the sub-pixel up-sampling convolutions (4 parities): 2560 -> 1280: 1 237 vs 981 TFLOP/s, 1280 -> 1280: 976 vs 957 with
+    // three splits (profiles/r4_k4w_sweep.log).  MARIGOLD_K4W=0 switches it off (A/B).
+    static const int k4w = [] { const char* e = getenv("MARIGOLD_K4W"); return e ? atoi(e) : 1; }();
+    const long long t = ((M + 255) / 256) * (N / 256) * batch_z;
+    if (k4w && !geglu && N % 256 == 0 && K >= 4608 && ((batch_z == 1 && t >= 64 && t <= 128) || (t >= 400 && t <= 512) || t >= 720)) return 72;
   }
   const long long tm256 = (M + 255) / 256;
   // short K (GEGLU projections, K = C linears): 256x128 with 32-deep K tiles - half the LDS per stage,

@@ -25,6 +25,7 @@ USE_PATCH = os.environ.get("MARIGOLD_PATCH_CONV", "1") != "0"      # patch-resid
 FUSE_GN = os.environ.get("MARIGOLD_FUSE_GN", "auto")               # auto | all | none: GroupNorm apply inside the conv
 FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"
 XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)
+VAE_ATTN_CHUNK_BYTES = int(os.environ.get("MARIGOLD_VAE_ATTN_CHUNK_MB", "192")) << 20   # fp32 scores per launch group (0: one batched launch)
 GN_SLAB = os.environ.get("MARIGOLD_GN_SLAB", "1") != "0"           # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 FLASH_VT_PERM = os.environ.get("MARIGOLD_FLASH_VT_PERM", "1") != "0"   # permuted V^T + generation-3 attention (0: generation 2)
 ROWGEMM = os.environ.get("MARIGOLD_ROWGEMM", "1") != "0"           # row-resident GEMM (MG_OP_ROWGEMM) for the K = 320 token-local layers
@@ -695,17 +696,33 @@ class Builder:
         self.add(O.igemm(g.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, bias=bqkv,
                          out2=vt, trans_from=2 * C, ldt=ldp), f"{name}.qkv")
         self.free(g)
-        s = self.raw(B * T * ldp * 4)
-        self.add(O.igemm(qk, qk.data_ptr() + C * 2, s, B=1, H=T, W=1, Cin=C, Ho=T, Wo=1, N=Tn,
-                         epi=L.EPI_F32, ldo=ldp, lda=2 * C, ldw=2 * C, batch_z=B, n_alg=T,
-                         zstrides=(T * 2 * C, T * 2 * C, T * ldp, 0), scale=1.0 / math.sqrt(C)), f"{name}.scores")
-        self.free(qk)
-        p = self.raw(B * T * ldp * 2)
-        self.add(O.softmax_rows(s, p, R=B * T, ncols=T, lds=ldp, ldp=ldp), f"{name}.softmax")
-        self.free(s)
         o = self.new(x.B, x.H, x.W, C)
-        self.add(O.igemm(p, vt, o.t, B=1, H=T, W=1, Cin=ldp, Ho=T, Wo=1, N=C, lda=ldp, ldw=ldp, batch_z=B,
-                         zstrides=(T * ldp, C * ldp, T * C, 0)), f"{name}.pv")
+        # The fp32 score matrix of ONE image is T x T x 4 bytes (340 MB at 96 x 96 latent pixels, 3.4 GB for ten members): as
+        # one batched launch per stage it crosses HBM three times.  Round 4: the stages run per CHUNK of query rows whose
+        # scores (<= 192 MB) stay in the 256 MB Infinity Cache between the GEMM that writes them, the softmax and the P V
+        # GEMM - the same two workspace buffers are reused by every chunk, so the lines are overwritten in cache.
+        rows = T
+        while VAE_ATTN_CHUNK_BYTES and rows * ldp * 4 > VAE_ATTN_CHUNK_BYTES and rows % 2 == 0 and (rows // 2) % 256 == 0:
+            rows //= 2
+        if not VAE_ATTN_CHUNK_BYTES or (rows == T and B * T * ldp * 4 <= VAE_ATTN_CHUNK_BYTES):
+            chunks = [(0, T, B)]            # everything in one batched launch (small maps)
+        else:
+            chunks = [(b * T + r0, rows, 1) for b in range(B) for r0 in range(0, T, rows)]
+        nb = max(c[2] for c in chunks)
+        nr = max(c[1] for c in chunks)
+        s = self.raw(nb * nr * ldp * 4)
+        p = self.raw(nb * nr * ldp * 2)
+        for (row0, nrow, bz) in chunks:
+            b0 = row0 // T
+            tag = "" if len(chunks) == 1 else f"[{row0}]"
+            self.add(O.igemm(qk.data_ptr() + row0 * 2 * C * 2, qk.data_ptr() + b0 * T * 2 * C * 2 + C * 2, s, B=1, H=nrow, W=1,
+                             Cin=C, Ho=nrow, Wo=1, N=Tn, epi=L.EPI_F32, ldo=ldp, lda=2 * C, ldw=2 * C, batch_z=bz, n_alg=T,
+                             zstrides=(T * 2 * C, T * 2 * C, T * ldp, 0), scale=1.0 / math.sqrt(C)), f"{name}.scores{tag}")
+            self.add(O.softmax_rows(s, p, R=bz * nrow, ncols=T, lds=ldp, ldp=ldp), f"{name}.softmax{tag}")
+            self.add(O.igemm(p, vt.data_ptr() + b0 * C * ldp * 2, o.t.data_ptr() + row0 * C * 2, B=1, H=nrow, W=1, Cin=ldp, Ho=nrow,
+                             Wo=1, N=C, lda=ldp, ldw=ldp, batch_z=bz, zstrides=(T * ldp, C * ldp, T * C, 0)), f"{name}.pv{tag}")
+        self.free(qk)
+        self.free(s)
         self.free(p)
         out = self.dense(o, self.ws.mat(f"{name}.to_out.0"), self.ws.bias(f"{name}.to_out.0"), C,
                          residual=x, label=f"{name}.to_out")
