@@ -27,23 +27,10 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "conv_patch_args.h"
 
 namespace {
 
-struct ConvPArgs {
-  const bf16_t* A0;
-  const bf16_t* A1;
-  const bf16_t* Wt;
-  bf16_t* out;
-  const float* bias;
-  const float* rowvec;
-  const bf16_t* res;
-  const float* ss;       // fused GroupNorm: [B][2][Cin] fp32 (scale, shift) or nullptr
-  const void* zero;
-  int B, H, W, C0, Cin, N, lda0, lda1, ldo, ldr, ldw, rv_stride, silu, subpix;
-  int tiles_x, tiles_y, tiles_n, chunks, c0t, T, tw;
-  long long sW;
-};
 
 template <int N>
 __device__ __forceinline__ void cp_wait_vmcnt() {
@@ -397,7 +384,22 @@ int launch_patch(const ConvPArgs& a0, hipStream_t s) {
 // 8 waves (wave tile 128 x 64) where N is a multiple of 256 (VAE 512 / 256 channels: 1100-1130); 8 x 16 x 320 / 8 waves
 // (wave tile 32 x 160) for the 320-channel level (930-1050) and the 640-channel sub-pixel convolution; 16 x 16 x 128 /
 // 8 waves / 2 weight stages (wave tile 64 x 64) otherwise (N = 640: 990-1060, N = 128: 830-1020).
-int mg_conv3x3_auto_variant(int N, int subpix, int B, int H, int W) {
+int mg_conv3x3_auto_variant(int N, int subpix, int B, int H, int W, int has_ss, int Cin, int allow4w) {
+  {
+    // Round 4: the four-wave hand-placed kernels (conv_patch4w.hip, one workgroup per CU) where their tile count fills the chip
+    // (profiles/r4_conv_patch4w.log, TFLOP/s at E = 10): 12 x 16 x 320 for the plain N = 320 / 640 convolutions (640 -> 640
+    // @48: 1 147 vs 1 016, 1280 -> 640: 1 267 vs 1 102) and for the fused-norm ones from 640 input channels (960 -> 320 @96:
+    // 1 141 vs 1 078; at 320 -> 320 the in-stream fix-up costs what the schedule gains); 16 x 16 x 256 for the plain
+    // N = 256 k convolutions (512 -> 512 @96: 1 202 vs 1 050) and the 512-channel sub-pixel up-sampling (1 104 vs 1 031).
+    // MARIGOLD_CP4W=0 switches them off (A/B).
+    static const int cp4 = [] { const char* e = getenv("MARIGOLD_CP4W"); return e ? atoi(e) : 1; }();
+    const long long par = subpix ? 4 : 1;
+    if (cp4 && allow4w && N % 320 == 0 && !subpix && (long long)B * ((H + 11) / 12) * ((W + 15) / 16) * (N / 320) >= 200 &&
+        (!has_ss || (Cin >= 640 && Cin <= 1024)))
+      return 11;
+    if (cp4 && allow4w && N % 256 == 0 && !has_ss && (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * (N / 256) * par >= 512 && (!subpix || N >= 512))
+      return 10;
+  }
   static const int n320 = [] { const char* e = getenv("MARIGOLD_PATCH_N320"); return e ? atoi(e) : 0; }();   // A/B: 3 = the round-2 choice
   const bool old = n320 == 3;
   // N = 256 / 512 (VAE): 12 x 16 x 256 on 12 waves (wave tile 64 x 64) where the GroupNorm is fused / the map is large
@@ -439,7 +441,10 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
   a.tw = a.subpix ? 2 : 3;
   a.ldw = op->i[12] > 0 ? op->i[12] : a.T * a.Cin;
   a.rv_stride = op->i[13] ? 0 : a.N;
-  int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N, a.subpix, a.B, a.H, a.W);
+  // (the four-wave kernels: SiLU with the fused norm, 31-bit byte offsets into the operands)
+  const int allow4w = (!a.ss || a.silu) && (long long)a.B * a.H * a.W * (a.lda0 > a.lda1 ? a.lda0 : a.lda1) < (1ll << 30) &&
+                      (long long)a.N * (op->i[12] > 0 ? op->i[12] : (a.subpix ? 4 : 9) * (a.C0 + C1)) < (1ll << 30);
+  int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N, a.subpix, a.B, a.H, a.W, a.ss != nullptr, a.C0 + C1, allow4w);
   if (!op->i[14] && variant == 6 && a.ss && a.C0 + C1 > 1024) variant = 3;   // (variant 6 keeps the fused norm's [2][Cin] vectors in 8 KB of LDS)
   a.sW = op->l[0];
   a.chunks = a.Cin / 64;
@@ -476,6 +481,10 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
     case 9:   // 12 x 16 pixels x 256 channels / 12 waves (wave tile 64 x 64)
       MG_REQUIRE(a.N % 256 == 0, "conv3x3: tile variant 9 needs N %% 256 == 0");
       return launch_patch<12, 16, 256, 3, 4, 2>(a, s);
+    case 10:   // four waves, one per SIMD, hand-placed streams (conv_patch4w.hip): 16 x 16 pixels x 256 channels
+      return mg_launch_conv_patch4w(a, 0, s);
+    case 11:   //   12 x 16 pixels x 320 channels
+      return mg_launch_conv_patch4w(a, 1, s);
     default: MG_REQUIRE(false, "conv3x3: unknown tile variant %d", variant);
   }
   return 0;

@@ -26,6 +26,7 @@ FUSE_GN = os.environ.get("MARIGOLD_FUSE_GN", "auto")               # auto | all 
 FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"
 XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)
 VAE_ATTN_CHUNK_BYTES = int(os.environ.get("MARIGOLD_VAE_ATTN_CHUNK_MB", "192")) << 20   # fp32 scores per launch group (0: one batched launch)
+IGEMM72_VAE = os.environ.get("MARIGOLD_IGEMM72_VAE", "1") != "0"    # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
 GN_SLAB = os.environ.get("MARIGOLD_GN_SLAB", "1") != "0"           # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 FLASH_VT_PERM = os.environ.get("MARIGOLD_FLASH_VT_PERM", "1") != "0"   # permuted V^T + generation-3 attention (0: generation 2)
 ROWGEMM = os.environ.get("MARIGOLD_ROWGEMM", "1") != "0"           # row-resident GEMM (MG_OP_ROWGEMM) for the K = 320 token-local layers
@@ -435,7 +436,11 @@ class Builder:
             Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
         if out is None:
             out = self.new(x.B, Ho, Wo, cout)
-        if USE_PATCH and stride == 1 and pad == 1 and self.patch_eligible(x.H, x.W, x.B, cout, up is not None):
+        # (round 4) plain 512-channel VAE convolutions with >= 720 tiles of 256 x 256: the hand-placed implicit-GEMM tile
+        # (variant 72, picked by the library) runs them at 1 284 TFLOP/s against 1 202 / 1 050 for the patch kernels
+        big_gemm = (IGEMM72_VAE and up is None and stride == 1 and pad == 1 and cout % 256 == 0 and x.C >= 512 and
+                    -(-x.M // 256) * (cout // 256) >= 720)
+        if USE_PATCH and not big_gemm and stride == 1 and pad == 1 and self.patch_eligible(x.H, x.W, x.B, cout, up is not None):
             if up is None:
                 return self.conv3x3p([x], name, cout, rowvec=rowvec, residual=residual, out=out)
             if up == (2 * x.H, 2 * x.W) and rowvec is None and residual is None:

@@ -230,6 +230,17 @@ PATCH_CASES = [
     ("v8_128_ragged", 2, 29, 19, 128, 0, 256, False, False, True, False, 8),
     ("v9_256_fused", 1, 36, 32, 128, 128, 512, True, True, True, True, 9),
     ("v9_256_ragged", 1, 13, 17, 64, 0, 256, False, False, False, False, 9),
+    # four waves, one per SIMD, hand-placed streams (conv_patch4w.hip): 16 x 16 x 256 (variant 10) and 12 x 16 x 320 (11) -
+    # whole / ragged tiles, one and several channel tiles (patch double buffer, in-stream fix-up), second source, epilogue terms
+    ("v10_256_plain_1tile", 1, 16, 16, 64, 0, 256, False, False, False, False, 10),
+    ("v10_256_plain", 2, 32, 32, 192, 0, 512, False, False, True, True, 10),
+    ("v10_256_fused", 1, 36, 32, 128, 128, 512, True, True, True, True, 10),
+    ("v10_256_fused_ragged", 2, 13, 17, 320, 0, 256, True, True, False, True, 10),
+    ("v10_256_fused_1tile", 1, 16, 16, 64, 0, 256, True, True, False, False, 10),
+    ("v11_320_plain_1tile", 1, 12, 16, 64, 0, 320, False, False, False, False, 11),
+    ("v11_320_plain_concat", 1, 31, 21, 320, 320, 640, False, False, True, True, 11),
+    ("v11_320_fused", 2, 24, 32, 320, 0, 320, True, True, True, True, 11),
+    ("v11_320_fused_ragged_concat", 1, 31, 21, 320, 320, 320, True, True, False, True, 11),
 ]
 
 
@@ -267,6 +278,7 @@ def test_conv3x3_patch(dev, case):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,N,variant", [(2, 16, 16, 64, 256, 1), (1, 9, 21, 192, 128, 2), (2, 24, 24, 320, 320, 3),
+                                                 (2, 16, 16, 64, 256, 10), (1, 19, 21, 192, 512, 10), (2, 24, 24, 320, 320, 11), (1, 13, 9, 128, 640, 11),
                                                  (1, 48, 48, 640, 640, 0), (1, 25, 19, 128, 640, 6), (1, 29, 20, 64, 128, 8)])
 def test_conv3x3_patch_subpixel(dev, B, H, W, Cin, N, variant):
     from marigold_amd import ops, weights as Wm

@@ -52,7 +52,7 @@ def case(name, B, HW, Cin, N, subpix=False):
                      zstrides=(0, N * 4 * Cin, 0, 0))
         fns["igemm"] = lambda: O.launch(ig)
         for v in PV:
-            if (v in (3, 6, 7) and N % 320) or (v in (1, 9) and N % 256) or (v == 8 and N % 128):
+            if (v in (3, 6, 7, 11) and N % 320) or (v in (1, 9, 10) and N % 256) or (v == 8 and N % 128):
                 continue
             op = O.conv3x3(x, w, out, B=B, H=HW, W=HW, C0=Cin, N=N, subpix=True, bias=bias, wz=N * 4 * Cin, variant=v)
             fns[f"p{v}"] = (lambda op=op: O.launch(op))
@@ -63,7 +63,7 @@ def case(name, B, HW, Cin, N, subpix=False):
         fns["igemm"] = lambda: O.launch(ig)
         fns["apply+igemm"] = lambda: (O.launch(ap), O.launch(ig2))
         for v in PV:
-            if (v in (3, 6, 7) and N % 320) or (v in (1, 9) and N % 256) or (v == 8 and N % 128):
+            if (v in (3, 6, 7, 11) and N % 320) or (v in (1, 9, 10) and N % 256) or (v == 8 and N % 128):
                 continue
             op = O.conv3x3(x, w, out, B=B, H=HW, W=HW, C0=Cin, N=N, bias=bias, variant=v)
             opf = O.conv3x3(x, w, out, B=B, H=HW, W=HW, C0=Cin, N=N, bias=bias, ss=ss, silu=True, variant=v)
