@@ -476,7 +476,10 @@ constexpr float FA3_THR = 3.0f;         // log2 units: the running max is raised
 // 134 registers: three 4-wave workgroups per CU.
 typedef __attribute__((ext_vector_type(2))) float fa_f32x2;
 
-template <int NW, bool PERM>
+// SUMM (round 4): the row sums come off the matrix pipe - a third P V MFMA per 16 keys against a fragment of ones (every
+// element of its accumulator is the lane's query's sum over the wave tile's keys) replaces the 17 v_pk_add_f32 per tile:
+// the kernel is VALU-issue-bound (~750 issue cycles per tile and wave beside 512 MFMA cycles), the pipe has the room.
+template <int NW, bool PERM, bool SUMM = false>
 __global__ __launch_bounds__(NW * 64) void flash_attn64_v25_kernel(const FaArgs a) {
   constexpr int NT = NW * 64;
   constexpr int QB = NW * 32;
@@ -542,10 +545,11 @@ __global__ __launch_bounds__(NW * 64) void flash_attn64_v25_kernel(const FaArgs 
     i_k0 += FA_KB;
   };
 
-  f32x16 o[2], negm;
+  f32x16 o[2], negm, osum;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; osum[r] = 0.f; }
   fa_f32x2 l2 = {0.f, 0.f};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 
   const int nkt = (a.Ntok + FA_KB - 1) / FA_KB;
   const bool ragged_end = (a.Ntok & (FA_KB - 1)) != 0;
@@ -599,7 +603,8 @@ __global__ __launch_bounds__(NW * 64) void flash_attn64_v25_kernel(const FaArgs 
       const float d = FIRST ? mx : fmaxf(mx, 0.f);
       const float alpha = __builtin_amdgcn_exp2f(-d);
       if constexpr (!FIRST) {
-        l2 *= alpha;
+        if constexpr (SUMM) osum[0] *= alpha;   // (only element 0 is read at the end; the others run on unscaled, unused)
+        else l2 *= alpha;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
       }
@@ -616,9 +621,9 @@ __global__ __launch_bounds__(NW * 64) void flash_attn64_v25_kernel(const FaArgs 
         p2.y = __builtin_amdgcn_exp2f(s[t2][r + 1]);
         s[t2][r] = p2.x;
         s[t2][r + 1] = p2.y;
-        ps += p2;   // v_pk_add_f32
+        if constexpr (!SUMM) ps += p2;   // v_pk_add_f32
       }
-    l2 += ps;
+    if constexpr (!SUMM) l2 += ps;
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
 #pragma unroll
@@ -643,6 +648,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn64_v25_kernel(const FaArgs 
           const uint4 vw = *(const uint4*)(sV + row * 128 + ((c0 ^ ((row >> 1) & 7)) << 4));
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
         }
+        if constexpr (SUMM) osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, osum, 0, 0, 0);
       }
     }
   };
@@ -665,10 +671,15 @@ __global__ __launch_bounds__(NW * 64) void flash_attn64_v25_kernel(const FaArgs 
     for (; kt + 2 < nkt; ++kt) { tile(kt, st_c, st_i, T{}, F{}, F{}); rot(); }
     for (; kt < nkt; ++kt) { tile(kt, st_c, st_i, F{}, T{}, F{}); rot(); }
   }
-  float l0, l1;
-  const float l_lane = l2.x + l2.y;
-  half_swap(l_lane, l_lane, l0, l1);
-  const float inv = 1.0f / (l0 + l1);
+  float inv;
+  if constexpr (SUMM) {
+    inv = 1.0f / osum[0];   // the MFMA summed over both key halves already
+  } else {
+    float l0, l1;
+    const float l_lane = l2.x + l2.y;
+    half_swap(l_lane, l_lane, l0, l1);
+    inv = 1.0f / (l0 + l1);
+  }
   bf16_t* orow = a.O + (long long)b * a.sO + (long long)q_row * a.ldo + h * 64;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -1124,7 +1135,7 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       const bool v2ok = (a.ldo % 8 == 0) && ((uintptr_t)a.O % 16 == 0) && (a.sO % 8 == 0);
       const int var = v2ok ? op->i[6] : 1;
       const bool vt_perm = op->i[7] != 0;   // V^T keys permuted inside every group of 16: [0-3, 8-11, 4-7, 12-15]
-      MG_REQUIRE(vt_perm == (var >= 13 && var <= 20) || var == 0, "flash_attn64: variant %d and the V^T key order (i[7] = %d) do not match", var, op->i[7]);
+      MG_REQUIRE(vt_perm == ((var >= 13 && var <= 20) || var == 22 || var == 23) || var == 0, "flash_attn64: variant %d and the V^T key order (i[7] = %d) do not match", var, op->i[7]);
       MG_REQUIRE(!vt_perm || a.Ntok % 16 == 0, "flash_attn64: the permuted V^T layout needs Ntok %% 16 == 0");
       const long long g4 = (long long)((a.Ntok + 127) / 128) * a.heads * a.B;
       const long long g8 = (long long)((a.Ntok + 255) / 256) * a.heads * a.B;
@@ -1140,6 +1151,9 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
         case 19: MG_LAUNCH((flash_attn64_v25_kernel<4, true>), dim3((unsigned)g4), dim3(256), 0, s, a); break;   // generation 2.5, vt_perm
         case 20: MG_LAUNCH((flash_attn64_v25_kernel<8, true>), dim3((unsigned)g8), dim3(512), 0, s, a); break;
         case 21: MG_LAUNCH((flash_attn64_v25_kernel<4, false>), dim3((unsigned)g4), dim3(256), 0, s, a); break;  // natural V^T
+        case 22: MG_LAUNCH((flash_attn64_v25_kernel<4, true, true>), dim3((unsigned)g4), dim3(256), 0, s, a); break;   // + row sums on the matrix pipe
+        case 23: MG_LAUNCH((flash_attn64_v25_kernel<8, true, true>), dim3((unsigned)g8), dim3(512), 0, s, a); break;
+        case 24: MG_LAUNCH((flash_attn64_v25_kernel<4, false, true>), dim3((unsigned)g4), dim3(256), 0, s, a); break;
         case 17: MG_LAUNCH((flash_attn64_v2_kernel<true, 4, 3>), dim3((unsigned)g4), dim3(256), 0, s, a); break;   // vt_perm
         case 18: MG_LAUNCH((flash_attn64_v2_kernel<true, 8, 3>), dim3((unsigned)g8), dim3(512), 0, s, a); break;
         // generation 3: 9 / 10 = 8 / 4 waves, natural V^T; 11 / 12 = + row sums on the matrix pipe; 13-16 = the same four with
@@ -1156,7 +1170,10 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
           // round 3 (profiles/r3_flash_variants*.log, TFLOP/s at E = 10): generation 2.5 on 4-wave workgroups (three per CU)
           // is ahead at every sequence length - 9216 tokens 903 (generation 3 860-890, generation 2 827-853), 2304: 798
           // (782 / 748), 576: 562 (538 / 403), 144: 119 (122 / 109) - with either V^T order
-          if (vt_perm) MG_LAUNCH((flash_attn64_v25_kernel<4, true>), dim3((unsigned)g4), dim3(256), 0, s, a);
+          // round 4: row sums on the matrix pipe (SUMM) where it measured ahead - 2304 tokens 828 vs 800, 9216: 945 vs 960
+          // (profiles/r4_flash_rowsum_mfma.log)
+          if (vt_perm && a.Ntok >= 1024 && a.Ntok <= 4096) MG_LAUNCH((flash_attn64_v25_kernel<4, true, true>), dim3((unsigned)g4), dim3(256), 0, s, a);
+          else if (vt_perm) MG_LAUNCH((flash_attn64_v25_kernel<4, true>), dim3((unsigned)g4), dim3(256), 0, s, a);
           else MG_LAUNCH((flash_attn64_v25_kernel<4, false>), dim3((unsigned)g4), dim3(256), 0, s, a);
           break;
       }
