@@ -18,44 +18,53 @@ first MFMA, and a gap carries at most two non-MFMA issues (MI355X_MICROARCH.md: 
 Waits are counted (vmcnt retires in order; the LDS-DMA is only ordered against ds_read by vmcnt + barrier).
 
 Operand names (bound in igemm2_body.h): c<ni><mi> accumulators, a<ks><mi> / b<ks><ni> fragments (pixel / weight side),
-la<ks> / lb<ks> LDS byte addresses of the fragment reads (buffer toggled by XOR 0x8000), va<i> / vb<i> per-lane byte offsets of
-the 8 + 8 DMA pieces, sa / sb buffer resources, ma = LDS address of this wave's first A piece in the buffer being filled.
+la<ks> / lb<ks> LDS byte addresses of the fragment reads, xa<ks> / xb<ks> their buffer toggles (XOR), va<i> / vb<i> per-lane byte
+offsets of the DMA pieces, sa / sb buffer resources, ma / mb = LDS addresses of this wave's first pixel / weight piece in the
+buffers being filled.
 """
 import sys
 
-A_BUF = 0          # LDS map: A buffers at 0 / 32768, B buffers at 65536 / 98304
-B_BUF = 65536
+# Geometry (set by main): MI x NI 32 x 32 fragments per wave (2 x 2 waves): 4 x 4 = the 256 x 256 tile (prefix K4W), 3 x 5 = the
+# 192 x 320 tile (prefix K4WB: full-width tiles for the N = 320 k layers).  LDS: pixel-row buffers, then weight-row buffers;
+# a read address toggles between an operand's two buffers by XOR with a per-register constant (xa<ks> / xb<ks>), the DMA bases
+# (ma / mb) are toggled by the caller.
+MI, NI = 4, 4
+
+
+def GS():
+    return MI * NI
 
 
 def mfma(g):
-    ks, ni, mi = g // 16, (g % 16) // 4, g % 4
+    ks, ni, mi = g // GS(), (g % GS()) // MI, g % MI
     return f"v_mfma_f32_32x32x16_bf16 %[c{ni}{mi}], %[b{ks}{ni}], %[a{ks}{mi}], %[c{ni}{mi}]"
 
 
 def reads(ks):
-    """the eight fragment reads of k-step ks, pixel side first"""
-    return ([f"ds_read_b128 %[a{ks}{i}], %[la{ks}] offset:{i * 4096}" for i in range(4)] +
-            [f"ds_read_b128 %[b{ks}{i}], %[lb{ks}] offset:{i * 4096}" for i in range(4)])
+    """the fragment reads of k-step ks, pixel side first"""
+    return ([f"ds_read_b128 %[a{ks}{i}], %[la{ks}] offset:{i * 4096}" for i in range(MI)] +
+            [f"ds_read_b128 %[b{ks}{i}], %[lb{ks}] offset:{i * 4096}" for i in range(NI)])
 
 
 def toggles(ks):
-    return [f"v_xor_b32 %[la{ks}], 0x8000, %[la{ks}]", f"v_xor_b32 %[lb{ks}], 0x8000, %[lb{ks}]"]
+    return [f"v_xor_b32 %[la{ks}], %[xa{ks}], %[la{ks}]", f"v_xor_b32 %[lb{ks}], %[xb{ks}], %[lb{ks}]"]
 
 
 def dma(i):
     """piece i of the next-but-one tile: (instruction in front of the MFMA, instruction behind it) - an SALU write of M0 needs
     one instruction before the LDS-DMA that reads it"""
-    if i < 8:
-        return (f"s_add_u32 m0, %[ma], {A_BUF + i * 4096}", f"buffer_load_dwordx4 %[va{i}], %[sa], 0 offen lds")
-    j = i - 8
-    return (f"s_add_u32 m0, %[ma], {B_BUF + j * 4096}", f"buffer_load_dwordx4 %[vb{j}], %[sb], 0 offen lds")
+    if i < 2 * MI:
+        return (f"s_add_u32 m0, %[ma], {i * 4096}", f"buffer_load_dwordx4 %[va{i}], %[sa], 0 offen lds")
+    j = i - 2 * MI
+    return (f"s_add_u32 m0, %[mb], {j * 4096}", f"buffer_load_dwordx4 %[vb{j}], %[sb], 0 offen lds")
 
 
 def block(mode, p):
     """mode: 'full' (tiles t+1 and t+2 exist), 'nodma' (t+1 exists), 'last'"""
-    pre = {g: [] for g in range(65)}     # instructions in front of MFMA g (g = 64: behind the last)
-    post = {g: [] for g in range(64)}    # instructions right behind MFMA g
-    pre[0].append("s_waitcnt lgkmcnt(8)")
+    NM, nF, ND = 4 * GS(), MI + NI, 2 * (MI + NI)
+    pre = {g: [] for g in range(NM + 1)}     # instructions in front of MFMA g (g = NM: behind the last)
+    post = {g: [] for g in range(NM)}        # instructions right behind MFMA g
+    pre[0].append(f"s_waitcnt lgkmcnt({nF})")
     # --- F[2], F[3] of this tile
     cur = reads(2) + reads(3)
     g = 0
@@ -67,33 +76,35 @@ def block(mode, p):
     last_read_gap = g - 1
     post[last_read_gap + 1] += toggles(2)
     post[last_read_gap + 2] += toggles(3)
+    r2 = p["r2"] if NM == 64 else NM - 2 * nF - 2
+    n0 = p["n0"] if NM == 64 else NM - 2 * nF - 1
     if mode == "last":
         pre[p["r1"]].append("s_waitcnt lgkmcnt(0)")
     else:
         pre[p["r1"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
         issued = 0
         if mode == "full":
-            for i in range(16):
+            for i in range(ND):
                 gg = p["d0"] + i * p["dstep"]
                 a, b = dma(i)
                 pre[gg].append(a)
                 post[gg].append(b)
-                if gg < p["r2"]:
+                if gg < r2:
                     issued += 1
-        pre[p["r2"]] += [f"s_waitcnt vmcnt({issued})", "s_barrier"]
+        pre[r2] += [f"s_waitcnt vmcnt({issued})", "s_barrier"]
         nxt = reads(0) + reads(1)
-        g = p["n0"]
+        g = n0
         while nxt:
             post[g].append(nxt.pop(0))
             g += 1
-        assert g <= 64, g
-        pre[64] += toggles(0) + toggles(1)
+        assert g <= NM, g
+        pre[NM] += toggles(0) + toggles(1)
     lines = []
-    for g in range(64):
+    for g in range(NM):
         lines += pre[g]
         lines.append(mfma(g))
         lines += post[g]
-    lines += pre[64]
+    lines += pre[NM]
     if mode == "last":
         # the epilogue's v_accvgpr_read follow in compiler code, whose hazard recogniser does not see the MFMAs in here: an
         # 8-pass MFMA's result may be read 11 wait states after its issue at the earliest (round 4, first run: the LAST
@@ -123,9 +134,12 @@ def main():
         k, v = a.split("=")
         p[k] = int(v)
     assert p["d0"] > p["r1"] and p["n0"] >= p["r2"] and p["n0"] + 16 <= 64 + 0
-    txt = ["// GENERATED by gen_k4w.py " + " ".join(f"{k}={v}" for k, v in p.items()) + " - do not edit; see the generator for the schedule.",
-           emit("K4W_ASM_FULL", block("full", p)), "", emit("K4W_ASM_NODMA", block("nodma", p)), "",
-           emit("K4W_ASM_LAST", block("last", p)), "", emit("K4W_ASM_PROLOGUE", prologue()), ""]
+    global MI, NI
+    txt = ["// GENERATED by gen_k4w.py " + " ".join(f"{k}={v}" for k, v in p.items()) + " - do not edit; see the generator for the schedule."]
+    for prefix, mi, ni in (("K4W", 4, 4), ("K4WB", 3, 5)):
+        MI, NI = mi, ni
+        txt += [emit(f"{prefix}_ASM_FULL", block("full", p)), "", emit(f"{prefix}_ASM_NODMA", block("nodma", p)), "",
+                emit(f"{prefix}_ASM_LAST", block("last", p)), "", emit(f"{prefix}_ASM_PROLOGUE", prologue()), ""]
     print("\n".join(txt))
 
 

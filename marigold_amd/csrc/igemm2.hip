@@ -111,7 +111,7 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   if (!TRANS && a.splits == 0 && batch_z == 1 && a.epi == MG_EPI_BF16 && a.n_begin == 0 && a.n_end == a.N &&
       tiles < 160 && b.KT >= 32 && g_splitk_ws) {   // (a wider window, < 256 tiles, measured no gain)
     int sp = (int)min((long long)8, (320 + tiles - 1) / tiles);
-    if constexpr (BIG == 2) sp = (int)min((long long)8, max(1ll, 256 / tiles));   // one workgroup per CU: a single round of <= 256
+    if constexpr (BIG == 2 || BIG == 3) sp = (int)min((long long)8, max(1ll, 256 / tiles));   // one workgroup per CU: a single round of <= 256
     sp = min(sp, b.KT / 12);
     while (sp > 1 && (long long)sp * a.M * a.N * 4 > MG_SPLITK_WS_BYTES) --sp;
     if (sp > 1) {
@@ -181,6 +181,13 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
                    "igemm: tile variant 72 addresses its operands with 31-bit byte offsets");
         return launch2<256, 256, 2, 2, 2, false, false, false, 0, 64, -1, 2>(a, batch_z, s);
       } else MG_REQUIRE(false, "igemm: tile variant 72 has no transposed section");
+      return 0;
+    case 73:   // the hand-placed K loop on a 192 x 320 tile (wave tile 96 x 160): full width for the N = 320 k layers
+      if constexpr (!TRANS) {
+        MG_REQUIRE((long long)(a.M / a.rows_per_img) * a.H * a.W * max(a.lda, a.lda1) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30),
+                   "igemm: tile variant 73 addresses its operands with 31-bit byte offsets");
+        return launch2<192, 320, 2, 2, 2, false, false, false, 0, 64, -1, 3>(a, batch_z, s);
+      } else MG_REQUIRE(false, "igemm: tile variant 73 has no transposed section");
       return 0;
     case 46: return launch2<128, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);   // full-width tiles for N = 320
     case 47:   // (no transposed instantiation: 160 accumulators + the token-major epilogue do not fit 256 VGPRs)
@@ -338,8 +345,8 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
     m.n_begin = 0;
     m.n_end = nmain;
     int v = variant ? variant : mg_igemm_auto_variant(m.M, m.n_end, K, batch_z, geglu);
-    if (!variant && v == 72 && !((long long)(a.M / a.rows_per_img) * a.H * a.W * max(a.lda, a.lda1) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30)))
-      v = 62;   // operands beyond the hand-placed loop's 31-bit byte offsets
+    if (!variant && (v == 72 || v == 73) && !((long long)(a.M / a.rows_per_img) * a.H * a.W * max(a.lda, a.lda1) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30)))
+      v = v == 72 ? 62 : 46;   // operands beyond the hand-placed loops' 31-bit byte offsets
     rc = dispatch_tile<false>(m, batch_z, v, s);
     if (rc) return rc;
   }
@@ -362,7 +369,7 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
     tns.res = nullptr;
     tns.epi = MG_EPI_BF16;
     int v = variant ? variant : mg_igemm_auto_variant(tns.M, tns.N, K, batch_z, 0);
-    if (!variant && v == 72) v = 62;   // (the hand-placed loop has no transposed instantiation)
+    if (!variant && (v == 72 || v == 73)) v = 62;   // (the hand-placed loops have no transposed instantiation)
     rc = dispatch_tile<true>(tns, batch_z, v, s);
   }
   return rc;
@@ -396,6 +403,12 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
     static const int k4w = [] { const char* e = getenv("MARIGOLD_K4W"); return e ? atoi(e) : 1; }();
     const long long t = ((M + 255) / 256) * (N / 256) * batch_z;
     if (k4w && !geglu && N % 256 == 0 && K >= 4608 && ((batch_z == 1 && t >= 64 && t <= 128) || (t >= 400 && t <= 512) || t >= 720)) return 72;
+    // ... and its 192 x 320 sibling (variant 73) for the N = 320 k Linear layers and 1x1 convolutions with at least ten K tiles
+    // and a chip's worth of tiles: ff.out of the 96 x 96 level 1280 -> 320: 661 vs 584 TFLOP/s, of the 48 x 48 level
+    // 2560 -> 640: 997 vs 841, conv_shortcut 960 -> 320: 608 vs 550, 640 -> 640: 537 vs 506.  MARIGOLD_K4WB=0: off.
+    static const int k4wb = [] { const char* e = getenv("MARIGOLD_K4WB"); return e ? atoi(e) : 1; }();
+    const long long tb = ((M + 191) / 192) * (N / 320) * batch_z;
+    if (k4w && k4wb && !geglu && N % 320 == 0 && N % 256 != 0 && K >= 640 && tb >= 200) return 73;
   }
   const long long tm256 = (M + 255) / 256;
   // short K (GEGLU projections, K = C linears): 256x128 with 32-deep K tiles - half the LDS per stage,

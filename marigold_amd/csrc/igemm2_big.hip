@@ -19,11 +19,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   igemm2_body<256, 256, 2, 2, 2, false, false, 3, 0, 64>(a);
 }
 
+// ... and its full-width sibling for the N = 320 k layers: 192 x 320 (wave tile 96 x 160)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void igemm2_k4wb_kernel(const Igemm2Args a) {
+  igemm2_body<192, 320, 2, 2, 2, false, false, 3, 0, 64>(a);
+}
+
 }  // namespace
 
 // which: 0 = 32-deep K tiles, 4 stages (128 KB of LDS); 1 = 64-deep K tiles, 2 stages; 2 = the hand-placed K loop.  The argument struct has the same
 // layout in every translation unit (igemm2_body.h); the pointer is launched by igemm2.hip::launch2.
 void* mg_igemm2_big_kernel(int which) {
   if (which == 2) return (void*)igemm2_k4w_kernel;
+  if (which == 3) return (void*)igemm2_k4wb_kernel;
   return which == 0 ? (void*)igemm2_big_kernel<4, 32> : (void*)igemm2_big_kernel<2, 64>;
 }

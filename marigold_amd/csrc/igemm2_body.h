@@ -91,8 +91,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, int LOOP, int ABL, int BK, int PPOPT = 0>
 __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   constexpr bool PF = LOOP == 1, PP = LOOP == 2, K4 = LOOP == 3;
-  static_assert(!K4 || (BM == 256 && BN == 256 && WGM == 2 && WGN == 2 && NSTAGE == 2 && BK == 64 && ABL == 0 && !TRANS),
-                "the hand-placed one-wave-per-SIMD schedule is written for the 256x256 / 4-wave / 2-buffer tile");
+  static_assert(!K4 || (((BM == 256 && BN == 256) || (BM == 192 && BN == 320)) && WGM == 2 && WGN == 2 && NSTAGE == 2 && BK == 64 &&
+                        ABL == 0 && !TRANS),
+                "the hand-placed one-wave-per-SIMD schedule is written for the 256x256 and 192x320 / 4-wave / 2-buffer tiles");
   static_assert(!PP || (BM == 256 && BN == 256 && WGM == 2 && WGN == 4 && NSTAGE == 2 && BK == 64 && ABL == 0),
                 "the ping-pong schedule is written for the 256x256 / 8-wave / 2-stage tile");
   constexpr int NT = WGM * WGN * 64;
@@ -340,8 +341,9 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     // as in the other loops (the DMA source address carries the swizzle).
     typedef __attribute__((ext_vector_type(4))) int i32x4;
     constexpr unsigned OOB = 0x80000000u;
-    static_assert(A_IT == 8 && B_IT == 8 && MI == 4 && NI == 4 && KS == 4, "k4w geometry");
-    unsigned va[8], vb[8];
+    static_assert(((A_IT == 8 && B_IT == 8 && MI == 4 && NI == 4) || (A_IT == 6 && B_IT == 10 && MI == 3 && NI == 5)) && KS == 4, "k4w geometry");
+    constexpr int ABUF = BM * ROWB, BBUF = BN * ROWB;   // LDS: [pixel rows 0 | pixel rows 1 | weight rows 0 | weight rows 1]
+    unsigned va[A_IT], vb[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int ci = it * NT + tid;
@@ -412,28 +414,36 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
       return r;
     };
     const int sw = (l31 >> 1) & 7;
-    int la[KS], lb[KS];
+    int la[KS], lb[KS], xa[KS], xb[KS];   // fragment read addresses and their buffer toggles (XOR)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int q = (((2 * ks + half) ^ sw) << 4) + l31 * ROWB;
       la[ks] = wm * (TM * ROWB) + q;
-      lb[ks] = NSTAGE * BM * ROWB + wn * (TN * ROWB) + q;
+      lb[ks] = 2 * ABUF + wn * (TN * ROWB) + q;
+      xa[ks] = la[ks] ^ (la[ks] + ABUF);
+      xb[ks] = lb[ks] ^ (lb[ks] + BBUF);
     }
-    int ma = wave * 1024;   // LDS address of this wave's first pixel-side piece in the buffer being filled
+    int fill = 0;           // buffer being filled
+    int ma = wave * 1024, mb = 2 * ABUF + wave * 1024;   // LDS addresses of this wave's first pixel / weight piece in it
+    auto flip = [&]() {
+      fill ^= 1;
+      ma = __builtin_amdgcn_readfirstlane(wave * 1024 + fill * ABUF);
+      mb = __builtin_amdgcn_readfirstlane(2 * ABUF + wave * 1024 + fill * BBUF);
+    };
     int staged = 0;         // tiles staged so far
     auto stage_tile = [&]() {   // prologue only: the steady state stages from inside the hand-placed stream
       const i32x4 sa = srd_of(loA, hiA), sb = srd_of(loB, hiB);
 #pragma unroll
-      for (int it = 0; it < 8; ++it)
+      for (int it = 0; it < A_IT; ++it)
         asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                      :: "v"(va[it]), "s"(sa), "s"(ma), "n"(it * 4096) : "memory", "scc");
 #pragma unroll
-      for (int it = 0; it < 8; ++it)
+      for (int it = 0; it < B_IT; ++it)
         asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
-                     :: "v"(vb[it]), "s"(sb), "s"(ma), "n"(NSTAGE * BM * ROWB + it * 4096) : "memory", "scc");
+                     :: "v"(vb[it]), "s"(sb), "s"(mb), "n"(it * 4096) : "memory", "scc");
       add_base(loA, hiA, ROWB);
       add_base(loB, hiB, ROWB);
-      ma ^= BM * ROWB;
+      flip();
       ++staged;
       ++j_c;
       if (--seg_left == 0 && staged < KT) next_segment();
@@ -442,37 +452,59 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa4[ks][i] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
-        fb4[ks][i] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
-      }
+      for (int i = 0; i < MI; ++i) fa4[ks][i] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+#pragma unroll
+      for (int i = 0; i < NI; ++i) fb4[ks][i] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
     }
     stage_tile();                 // tile 0 -> buffer 0
     if (KT > 1) stage_tile();     // tile 1 -> buffer 1
     ln_publish();
     zero_acc();
-    if (KT > 1) wait_vmcnt<16>();
+    if (KT > 1) wait_vmcnt<A_IT + B_IT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 #define K4W_C(ni, mi) [c##ni##mi] "+a"(acc[ni][mi])
 #define K4W_A(ks, i) [a##ks##i] "+v"(fa4[ks][i])
 #define K4W_B(ks, i) [b##ks##i] "+v"(fb4[ks][i])
-#define K4W_OUT                                                                                                             \
+#define K4W_ADDR                                                                                                            \
+  [la0] "+v"(la[0]), [la1] "+v"(la[1]), [la2] "+v"(la[2]), [la3] "+v"(la[3]),                                              \
+  [lb0] "+v"(lb[0]), [lb1] "+v"(lb[1]), [lb2] "+v"(lb[2]), [lb3] "+v"(lb[3])
+#define K4W_TOGGLES                                                                                                         \
+  [xa0] "v"(xa[0]), [xa1] "v"(xa[1]), [xa2] "v"(xa[2]), [xa3] "v"(xa[3]), [xb0] "v"(xb[0]), [xb1] "v"(xb[1]),              \
+  [xb2] "v"(xb[2]), [xb3] "v"(xb[3]), [sa] "s"(sa), [sb] "s"(sb), [ma] "s"(ma), [mb] "s"(mb)
+    // 256 x 256: 4 x 4 fragments per wave, 8 + 8 DMA pieces
+#define K4W_OUT_A                                                                                                           \
   K4W_C(0, 0), K4W_C(0, 1), K4W_C(0, 2), K4W_C(0, 3), K4W_C(1, 0), K4W_C(1, 1), K4W_C(1, 2), K4W_C(1, 3), K4W_C(2, 0),      \
   K4W_C(2, 1), K4W_C(2, 2), K4W_C(2, 3), K4W_C(3, 0), K4W_C(3, 1), K4W_C(3, 2), K4W_C(3, 3),                                \
   K4W_A(0, 0), K4W_A(0, 1), K4W_A(0, 2), K4W_A(0, 3), K4W_A(1, 0), K4W_A(1, 1), K4W_A(1, 2), K4W_A(1, 3), K4W_A(2, 0),      \
   K4W_A(2, 1), K4W_A(2, 2), K4W_A(2, 3), K4W_A(3, 0), K4W_A(3, 1), K4W_A(3, 2), K4W_A(3, 3),                                \
   K4W_B(0, 0), K4W_B(0, 1), K4W_B(0, 2), K4W_B(0, 3), K4W_B(1, 0), K4W_B(1, 1), K4W_B(1, 2), K4W_B(1, 3), K4W_B(2, 0),      \
-  K4W_B(2, 1), K4W_B(2, 2), K4W_B(2, 3), K4W_B(3, 0), K4W_B(3, 1), K4W_B(3, 2), K4W_B(3, 3),                                \
-  [la0] "+v"(la[0]), [la1] "+v"(la[1]), [la2] "+v"(la[2]), [la3] "+v"(la[3]),                                              \
-  [lb0] "+v"(lb[0]), [lb1] "+v"(lb[1]), [lb2] "+v"(lb[2]), [lb3] "+v"(lb[3])
-#define K4W_IN                                                                                                              \
+  K4W_B(2, 1), K4W_B(2, 2), K4W_B(2, 3), K4W_B(3, 0), K4W_B(3, 1), K4W_B(3, 2), K4W_B(3, 3), K4W_ADDR
+#define K4W_IN_A                                                                                                            \
   [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [va3] "v"(va[3]), [va4] "v"(va[4]), [va5] "v"(va[5]),              \
-  [va6] "v"(va[6]), [va7] "v"(va[7]), [vb0] "v"(vb[0]), [vb1] "v"(vb[1]), [vb2] "v"(vb[2]), [vb3] "v"(vb[3]),              \
-  [vb4] "v"(vb[4]), [vb5] "v"(vb[5]), [vb6] "v"(vb[6]), [vb7] "v"(vb[7]), [sa] "s"(sa), [sb] "s"(sb), [ma] "s"(ma)
+  [va6] "v"(va[6]), [va7] "v"(va[7]), [vb0] "v"(vb[0]), [vb1] "v"(vb[1]), [vb2] "v"(vb[2]), [vb3] "v"(vb[3]),  \
+  [vb4] "v"(vb[4]), [vb5] "v"(vb[5]), [vb6] "v"(vb[6]), [vb7] "v"(vb[7]), K4W_TOGGLES
+    // 192 x 320: 3 x 5 fragments per wave, 6 + 10 DMA pieces
+#define K4W_OUT_B                                                                                                           \
+  K4W_C(0, 0), K4W_C(0, 1), K4W_C(0, 2), K4W_C(1, 0), K4W_C(1, 1), K4W_C(1, 2), K4W_C(2, 0), K4W_C(2, 1), K4W_C(2, 2),      \
+  K4W_C(3, 0), K4W_C(3, 1), K4W_C(3, 2), K4W_C(4, 0), K4W_C(4, 1), K4W_C(4, 2),                              \
+  K4W_A(0, 0), K4W_A(0, 1), K4W_A(0, 2), K4W_A(1, 0), K4W_A(1, 1), K4W_A(1, 2), K4W_A(2, 0), K4W_A(2, 1), K4W_A(2, 2),      \
+  K4W_A(3, 0), K4W_A(3, 1), K4W_A(3, 2),                                                                                    \
+  K4W_B(0, 0), K4W_B(0, 1), K4W_B(0, 2), K4W_B(0, 3), K4W_B(0, 4), K4W_B(1, 0), K4W_B(1, 1), K4W_B(1, 2), K4W_B(1, 3), \
+  K4W_B(1, 4), K4W_B(2, 0), K4W_B(2, 1), K4W_B(2, 2), K4W_B(2, 3), K4W_B(2, 4), K4W_B(3, 0), K4W_B(3, 1),         \
+  K4W_B(3, 2), K4W_B(3, 3), K4W_B(3, 4), K4W_ADDR
+#define K4W_IN_B                                                                                                            \
+  [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [va3] "v"(va[3]), [va4] "v"(va[4]), [va5] "v"(va[5]),              \
+  [vb0] "v"(vb[0]), [vb1] "v"(vb[1]), [vb2] "v"(vb[2]), [vb3] "v"(vb[3]), [vb4] "v"(vb[4]), [vb5] "v"(vb[5]),              \
+  [vb6] "v"(vb[6]), [vb7] "v"(vb[7]), [vb8] "v"(vb[8]), [vb9] "v"(vb[9]), K4W_TOGGLES
+#define K4W_RUN(text_a, text_b)                                                                  \
+  do {                                                                                           \
+    if constexpr (MI == 4) asm volatile(text_a : K4W_OUT_A : K4W_IN_A : "memory", "scc");        \
+    else asm volatile(text_b : K4W_OUT_B : K4W_IN_B : "memory", "scc");                          \
+  } while (0)
     {
       const i32x4 sa = srd_of(loA, hiA), sb = srd_of(loB, hiB);
-      asm volatile(K4W_ASM_PROLOGUE : K4W_OUT : K4W_IN : "memory", "scc");
+      K4W_RUN(K4W_ASM_PROLOGUE, K4WB_ASM_PROLOGUE);
     }
     // steady state: while tile t is computed, tile t + 2 is staged into the buffer it is read from - one stream per tile,
     // grouped by the segment of the STAGED tile (the computed tile needs no addressing state at all)
@@ -480,10 +512,10 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
       const int n = min(seg_left, KT - staged);
       for (int i = 0; i < n; ++i) {
         const i32x4 sa = srd_of(loA, hiA), sb = srd_of(loB, hiB);
-        asm volatile(K4W_ASM_FULL : K4W_OUT : K4W_IN : "memory", "scc");
+        K4W_RUN(K4W_ASM_FULL, K4WB_ASM_FULL);
         add_base(loA, hiA, ROWB);
         add_base(loB, hiB, ROWB);
-        ma ^= BM * ROWB;
+        flip();
       }
       staged += n;
       j_c += n;
@@ -492,14 +524,19 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     }
     {
       const i32x4 sa = srd_of(loA, hiA), sb = srd_of(loB, hiB);
-      if (KT > 1) asm volatile(K4W_ASM_NODMA : K4W_OUT : K4W_IN : "memory", "scc");
-      asm volatile(K4W_ASM_LAST : K4W_OUT : K4W_IN : "memory", "scc");
+      if (KT > 1) K4W_RUN(K4W_ASM_NODMA, K4WB_ASM_NODMA);
+      K4W_RUN(K4W_ASM_LAST, K4WB_ASM_LAST);
     }
+#undef K4W_ADDR
+#undef K4W_TOGGLES
+#undef K4W_OUT_A
+#undef K4W_IN_A
+#undef K4W_OUT_B
+#undef K4W_IN_B
+#undef K4W_RUN
 #undef K4W_C
 #undef K4W_A
 #undef K4W_B
-#undef K4W_OUT
-#undef K4W_IN
   } else if constexpr (PP) {
     // Half tiles of K tile t (each 128 LDS rows = two DMA pieces per wave), in consumption order:
     //   H0 = A rows {mi 0,1}  H1 = B rows {ni 0}  H2 = B rows {ni 1}  H3 = A rows {mi 2,3}

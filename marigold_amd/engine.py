@@ -25,7 +25,8 @@ USE_PATCH = os.environ.get("MARIGOLD_PATCH_CONV", "1") != "0"      # patch-resid
 FUSE_GN = os.environ.get("MARIGOLD_FUSE_GN", "auto")               # auto | all | none: GroupNorm apply inside the conv
 FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"
 XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)
-VAE_ATTN_CHUNK_BYTES = int(os.environ.get("MARIGOLD_VAE_ATTN_CHUNK_MB", "192")) << 20   # fp32 scores per launch group (0: one batched launch)
+VAE_ATTN_CHUNK_BYTES = int(os.environ.get("MARIGOLD_VAE_ATTN_CHUNK_MB", "0")) << 20   # fp32 scores per launch group; 0 = one batched launch per stage
+# (query chunks whose scores fit the 256 MB Infinity Cache measured no gain: vae.decode 62.1 vs 62.9 ms, profiles/r4_vae_attention_chunks.log)
 IGEMM72_VAE = os.environ.get("MARIGOLD_IGEMM72_VAE", "1") != "0"    # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
 GN_SLAB = os.environ.get("MARIGOLD_GN_SLAB", "1") != "0"           # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 FLASH_VT_PERM = os.environ.get("MARIGOLD_FLASH_VT_PERM", "1") != "0"   # permuted V^T + generation-3 attention (0: generation 2)
@@ -702,10 +703,9 @@ class Builder:
                          out2=vt, trans_from=2 * C, ldt=ldp), f"{name}.qkv")
         self.free(g)
         o = self.new(x.B, x.H, x.W, C)
-        # The fp32 score matrix of ONE image is T x T x 4 bytes (340 MB at 96 x 96 latent pixels, 3.4 GB for ten members): as
-        # one batched launch per stage it crosses HBM three times.  Round 4: the stages run per CHUNK of query rows whose
-        # scores (<= 192 MB) stay in the 256 MB Infinity Cache between the GEMM that writes them, the softmax and the P V
-        # GEMM - the same two workspace buffers are reused by every chunk, so the lines are overwritten in cache.
+        # The fp32 score matrix of ONE image is T x T x 4 bytes (340 MB at 96 x 96 latent pixels, 3.4 GB for ten members).
+        # Optional (MARIGOLD_VAE_ATTN_CHUNK_MB, off): run the three stages per chunk of query rows whose scores fit the
+        # Infinity Cache - tried in round 4, no gain on MI355X.
         rows = T
         while VAE_ATTN_CHUNK_BYTES and rows * ldp * 4 > VAE_ATTN_CHUNK_BYTES and rows % 2 == 0 and (rows // 2) % 256 == 0:
             rows //= 2

@@ -102,6 +102,10 @@ CONV_CASES = [
     ("g2_k4w_big_k_medge", 1, 13, 12, 1280, 256, 1, 1, None, 72),        # 180 K tiles, M = 156 (one partial tile)
     ("g2_k4w_up_to_size", 1, 4, 6, 64, 64, 1, 1, (7, 11), 72),
     ("g2_k4w_stride2_pad0", 1, 16, 24, 128, 128, 2, 0, None, 72),
+    ("g2_k4wb_up_nedge", 2, 16, 24, 192, 640, 1, 1, (32, 48), 73),       # 192 x 320 tile: 27 K tiles over 9 taps, 16 M tiles
+    ("g2_k4wb_kt9_stride2", 2, 16, 16, 64, 320, 2, 1, None, 73),
+    ("g2_k4wb_big_k_medge", 1, 13, 12, 1280, 320, 1, 1, None, 73),       # 180 K tiles, M = 156 (one partial tile)
+    ("g2_k4wb_nedge", 1, 14, 14, 128, 256, 1, 1, None, 73),              # N = 256 < 320: out-of-range weight rows
     ("g2_128x320", 2, 12, 20, 128, 320, 1, 1, None, 46),
     ("g2_256x320", 2, 12, 20, 64, 640, 1, 1, None, 47),
     ("g2_128x320_burst", 1, 12, 12, 320, 320, 1, 1, None, 48),
@@ -330,7 +334,7 @@ def test_igemm_two_sources_and_gn_channel_windows(dev):
     xh = _nhwc(x)
     a0 = xh[..., :C0].contiguous().to(dev, torch.bfloat16)
     a1 = xh[..., C0:].contiguous().to(dev, torch.bfloat16)
-    for taps, variant in ((1, 0), (9, 0), (9, 62), (1, 53), (9, 33), (9, 72), (1, 72)):
+    for taps, variant in ((1, 0), (9, 0), (9, 62), (1, 53), (9, 33), (9, 72), (1, 72), (9, 73), (1, 73)):
         w = _bf(torch.randn(N, Cin, 3, 3, generator=g) / math.sqrt(taps * Cin)) if taps == 9 else _bf(torch.randn(N, Cin, 1, 1, generator=g) / math.sqrt(Cin))
         ref = F.conv2d(x, w, None, padding=1 if taps == 9 else 0)
         wd = (Wm.pack_conv3x3(w) if taps == 9 else w.reshape(N, Cin)).to(dev, torch.bfloat16)
@@ -394,7 +398,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = torch.randn(N, generator=g) * 0.1
     ref = x @ w.t() + b
-    for variant in (0, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 46, 50, 51, 52, 53, 60, 61, 62, 63, 70, 71, 72):
+    for variant in (0, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 46, 50, 51, 52, 53, 60, 61, 62, 63, 70, 71, 72, 73):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N,
                         bias=b.to(dev), variant=variant))
@@ -406,7 +410,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     xg = _bf(torch.randn(200, C, generator=g))
     u, gt = (xg @ wg.t() + bg).chunk(2, dim=-1)
     ref = u * F.gelu(gt)
-    for group, variants in ((32, (20, 23, 24, 27, 34, 53, 60, 62, 70, 71, 72, 0)),):
+    for group, variants in ((32, (20, 23, 24, 27, 34, 53, 60, 62, 70, 71, 72, 73, 0)),):
         wp, bp = Wm.pack_geglu(wg, bg, group)
         for variant in variants:
             out = torch.full((200, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
@@ -478,7 +482,7 @@ def test_igemm_layernorm_fold(dev):
     b0 = torch.randn(C, generator=g) * 0.1
     res = _bf(torch.randn(M, C, generator=g))
     ref0 = a @ w0.t() + b0 + res
-    for variant in (0, 46, 53, 35, 62, 70, 71, 72):
+    for variant in (0, 46, 53, 35, 62, 70, 71, 72, 73):
         out = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
         st = torch.full((M * (C // 32 + 1), 2), float("nan"), device=dev)
         for rep_ in range(3):   # the tickets reset themselves: every launch finalizes again
@@ -501,7 +505,7 @@ def test_igemm_layernorm_fold(dev):
     b = torch.randn(N, generator=g) * 0.1
     wp, gv, cv = Wm.fold_layernorm(w, b, gamma, beta)
     ref = y @ w.t() + b
-    for variant in (0, 20, 46, 53, 62, 70, 71, 72):
+    for variant in (0, 20, 46, 53, 62, 70, 71, 72, 73):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(xd, wp.to(dev), out, M=M, K=C, N=N, ln_in=stx, ln_g=gv.to(dev), ln_c=cv.to(dev), variant=variant))
         _close(f"ln_fold/bf16/v{variant}", out, ref, tol=2e-2)
@@ -515,7 +519,7 @@ def test_igemm_layernorm_fold(dev):
     refg = u * F.gelu(gt)
     wpk, bpk = Wm.pack_geglu(wg, bg)
     wpg, gg, cg = Wm.fold_layernorm(wpk, bpk, gamma, beta)
-    for variant in (0, 53, 62, 70, 71, 72):
+    for variant in (0, 53, 62, 70, 71, 72, 73):
         og = torch.full((M, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(xd, wpg.to(dev), og, M=M, K=C, N=8 * C, epi=L.EPI_GEGLU, ln_in=stx, ln_g=gg.to(dev), ln_c=cg.to(dev),
                         variant=variant))
@@ -997,7 +1001,7 @@ def test_igemm_pingpong_short_k_and_repeatability(dev):
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N, bias=b.to(dev),
                         variant=60))
         _close(f"pingpong/linear K={K}", out, x @ w.t() + b)
-        for v in (62, 63, 72):
+        for v in (62, 63, 72, 73):
             out.fill_(float("nan"))
             _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N, bias=b.to(dev),
                             variant=v))

@@ -123,6 +123,8 @@ def main():
         ("unet.linear 320->960 @96 (qkv)", E, 96, 320, 960, 1),
         ("unet.linear 640->1920 @48 (qkv)", E, 48, 640, 1920, 1),
         ("unet.linear 1280->320 @96", E, 96, 1280, 320, 1),
+        ("unet.linear 960->320 @96", E, 96, 960, 320, 1),
+        ("unet.linear 5120->1280 @24", E, 24, 5120, 1280, 1),
         ("unet.linear 640->640 @48", E, 48, 640, 640, 1),
         ("unet.linear 2560->640 @48", E, 48, 2560, 640, 1),
         ("unet.linear 1280->1280 @24", E, 24, 1280, 1280, 1),
