@@ -402,7 +402,7 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
     // three splits (profiles/r4_k4w_sweep.log).  MARIGOLD_K4W=0 switches it off (A/B).
     static const int k4w = [] { const char* e = getenv("MARIGOLD_K4W"); return e ? atoi(e) : 1; }();
     const long long t = ((M + 255) / 256) * (N / 256) * batch_z;
-    if (k4w && !geglu && N % 256 == 0 && K >= 4608 && ((batch_z == 1 && t >= 64 && t <= 128) || (t >= 400 && t <= 512) || t >= 720)) return 72;
+    if (k4w && !geglu && N % 256 == 0 && K >= 4096 && ((batch_z == 1 && t >= 64 && t <= 128) || (t >= 200 && t <= 256) || (t >= 400 && t <= 512) || t >= 720)) return 72;
     // ... and its 192 x 320 sibling (variant 73) for the N = 320 k Linear layers and 1x1 convolutions with at least ten K tiles
     // and a chip's worth of tiles: ff.out of the 96 x 96 level 1280 -> 320: 661 vs 584 TFLOP/s, of the 48 x 48 level
     // 2560 -> 640: 997 vs 841, conv_shortcut 960 -> 320: 608 vs 550, 640 -> 640: 537 vs 506.  MARIGOLD_K4WB=0: off.

@@ -27,6 +27,7 @@ FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"
 XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)
 VAE_ATTN_CHUNK_BYTES = int(os.environ.get("MARIGOLD_VAE_ATTN_CHUNK_MB", "0")) << 20   # fp32 scores per launch group; 0 = one batched launch per stage
 # (query chunks whose scores fit the 256 MB Infinity Cache measured no gain: vae.decode 62.1 vs 62.9 ms, profiles/r4_vae_attention_chunks.log)
+IGEMM73_CONV = os.environ.get("MARIGOLD_IGEMM73_CONV", "1") != "0"   # plain N = 320 k convolutions on the hand-placed 192 x 320 GEMM tile
 IGEMM72_VAE = os.environ.get("MARIGOLD_IGEMM72_VAE", "1") != "0"    # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
 GN_SLAB = os.environ.get("MARIGOLD_GN_SLAB", "1") != "0"           # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 FLASH_VT_PERM = os.environ.get("MARIGOLD_FLASH_VT_PERM", "1") != "0"   # permuted V^T + generation-3 attention (0: generation 2)
@@ -441,6 +442,10 @@ class Builder:
         # (variant 72, picked by the library) runs them at 1 284 TFLOP/s against 1 202 / 1 050 for the patch kernels
         big_gemm = (IGEMM72_VAE and up is None and stride == 1 and pad == 1 and cout % 256 == 0 and x.C >= 512 and
                     -(-x.M // 256) * (cout // 256) >= 720)
+        # ... and the plain N = 320 k convolutions with a chip's worth of 192 x 320 tiles (the 640-channel level at 48 x 48) on
+        # variant 73: 640 -> 640 1 193 vs 1 147-1 182 for the four-wave patch kernel, 1280 -> 640 1 303 vs 1 267-1 277
+        big_gemm = big_gemm or (IGEMM73_CONV and up is None and stride == 1 and pad == 1 and cout % 320 == 0 and cout % 256 != 0 and
+                                x.C >= 320 and -(-x.M // 192) * (cout // 320) >= 200)
         if USE_PATCH and not big_gemm and stride == 1 and pad == 1 and self.patch_eligible(x.H, x.W, x.B, cout, up is not None):
             if up is None:
                 return self.conv3x3p([x], name, cout, rowvec=rowvec, residual=residual, out=out)

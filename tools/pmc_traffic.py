@@ -31,7 +31,7 @@ def main():
     base = os.path.join(ROOT, "gpurun_out")
     f = load(os.path.join(base, "pmc_fetch", "r2_counter_collection.csv"), "FETCH_SIZE")
     w = load(os.path.join(base, "pmc_write", "r2_counter_collection.csv"), "WRITE_SIZE")
-    classes = {"igemm_mfma": "igemm2_", "rowgemm_mfma": "rowgemm_", "conv3x3_patch": "conv_patch_", "flash_attn64": "flash_attn64",
+    classes = {"igemm_mfma": "igemm2_", "rowgemm_mfma": "rowgemm_", "conv3x3_patch": "conv_patch", "flash_attn64": "flash_attn64",
                "groupnorm": "gn_", "layernorm": "layernorm"}
     out = {}
     with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.csv"), "w") as c:
