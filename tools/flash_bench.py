@@ -48,8 +48,8 @@ def case(B, heads, T, qscale=1.0):
     outs, ops, times = {}, {}, {v: [] for v in VARIANTS}
     for v in VARIANTS:
         outs[v] = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
-        ops[v] = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
-                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(13 <= v <= 20 or v in (22, 23)))
+        ops[v] = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
+                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(13 <= v <= 20 or v in (22, 23, 25)))
     for rnd in range(ROUNDS):
         for v in VARIANTS:
             times[v].append(timeit(lambda: O.launch(ops[v])))
@@ -63,8 +63,8 @@ def case(B, heads, T, qscale=1.0):
             nw = 8 if v in (9, 11, 13, 15) else 4
             nwg = -(-T // (nw * 32)) * heads * B
             dbg = torch.zeros(nwg * nw * 8, dtype=torch.int64, device=dev)
-            op = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
-                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(13 <= v <= 20 or v in (22, 23)), dbg=dbg)
+            op = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
+                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(13 <= v <= 20 or v in (22, 23, 25)), dbg=dbg)
             O.launch(op)
             O.launch(op)
             torch.cuda.synchronize()
