@@ -115,6 +115,12 @@ enum mg_op_kind {
    *  l[0] q batch stride l[1] k batch stride l[2] vt batch stride l[3] o batch stride;
    *  f[0] softmax scale */
   MG_OP_FLASH_ATTN64 = 6,
+  /* Self-attention core of ONE head of width 512 (the mid-block attention of AutoencoderKL: diffusers Attention in
+   * UNetMidBlock2D, marigold_depth_pipeline.py:491-492, 512-513), flash form: the scores stay in registers.
+   *  p[0] Q bf16 (row stride ldq)  p[1] K (row stride ldq)  p[2] Vt bf16 [B][512][ldvt] (natural key order, ldvt >= Ntok rounded
+   *  up to 32, pad columns zero)  p[3] O bf16 (row stride ldo); i: B, Ntok, ldq, ldo, ldvt ;
+   *  l[0] q batch stride l[1] k batch stride l[2] vt batch stride l[3] o batch stride ; f[0] softmax scale */
+  MG_OP_FLASH_ATTN512 = 11,
   /* Row softmax fp32 -> bf16 (VAE single-head d=512 attention, materialised scores).
    *  p[0] S f32 [R][lds] p[1] P bf16 [R][ldp] ; i: R, ncols, lds, ldp (pad cols zeroed) */
   MG_OP_SOFTMAX_ROWS = 7,

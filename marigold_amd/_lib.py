@@ -16,6 +16,7 @@ OP_IGEMM, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_LAYERNORM = 1, 2, 3, 4, 5
 OP_FLASH_ATTN64, OP_SOFTMAX_ROWS, OP_SOFTMAX_PAIRS = 6, 7, 8
 OP_GN_SLAB = 9
 OP_ROWGEMM = 10
+OP_FLASH_ATTN512 = 11
 RG_BF16, RG_GEGLU, RG_QKV, RG_XATTN = 0, 1, 2, 3
 OP_SCHED_STEP = 12
 OP_LINEAR_SMALL_M, OP_LATENT_1X1, OP_POST_NCHW, OP_IM2COL_SMALL = 13, 14, 15, 16

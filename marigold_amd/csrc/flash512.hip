@@ -1,0 +1,255 @@
+// Flash attention for ONE head of width 512 (MG_OP_FLASH_ATTN512): the mid-block attention of the SD-v2 AutoencoderKL
+// (diffusers `Attention` inside `UNetMidBlock2D`, reached from marigold/marigold_depth_pipeline.py:491-492 (encoder) and
+// :512-513 (decoder): 9 216 tokens per image at 768 x 768).  Rounds 1-3 ran it as scores GEMM -> softmax_rows -> P V GEMM with
+// the fp32 score matrix (T x T x 4 bytes = 340 MB per image, 3.4 GB for ten members) written and re-read through HBM; here the
+// scores never leave the registers.
+//
+//   workgroup = 4 waves (one per SIMD, 512 registers: the 32 x 512 fp32 output tile of a wave is 256 AGPRs) x 32 queries
+//   Q   the wave's 32 rows x 512 channels stay in 128 VGPRs for the whole kernel (pre-scaled by scale * log2 e)
+//   K / V^T tiles of 32 keys stream through a two-stage LDS ring (64 KB per stage) by global_load_lds_dwordx4; a K row is
+//       1 KB (one DMA piece), its 16-byte chunks XOR-swizzled with the key index (conflict-free ds_read_b128 across 32 rows
+//       1 KB apart); V^T rows are 64 bytes, chunk ^ ((row >> 2) & 3)
+//   S = K Q^T swapped (lane = query, registers = keys) on two accumulator chains (32 k-steps of 16 channels); softmax against
+//       a fixed per-query reference (the first tile's maximum, subtracted by the MFMA's C operand; a retry of the row block
+//       if a later score tops it by 2^FA5_THR - see below), bare v_exp_f32, plain v_add_f32 row sums, P regrouped by
+//       v_permlane32_swap, O += V^T P on 16 accumulator tiles
+// Arithmetic per tile and wave: 64 MFMAs against ~70 VALU - matrix-bound, unlike the 64-wide heads.
+// Built without -amdgpu-mfma-vgpr-form (Makefile): the output tile lives in AGPRs.
+#include "common.h"
+
+namespace {
+
+struct Fa5Args {
+  const bf16_t* Q;
+  const bf16_t* K;
+  const bf16_t* Vt;
+  bf16_t* O;
+  const void* zero;
+  int B, Ntok, ldq, ldo, ldvt;
+  long long sQ, sK, sVt, sO;
+  float scale_log2;
+};
+
+constexpr int FA5_D = 512, FA5_KB = 32, FA5_QB = 128;
+constexpr int FA5_KTILE = FA5_KB * FA5_D * 2, FA5_STAGE = 2 * FA5_KTILE;   // K tile + V^T tile: 64 KB
+constexpr float FA5_THR = 60.0f;
+
+__device__ __forceinline__ uint32_t fa5_cvt_pk(float lo, float hi) { return cvt_pk_bf16_f32(lo, hi); }
+
+// The MFMAs are written as asm so that the register CLASS of every accumulator is explicit: the 16 output tiles (256 registers)
+// in AGPRs, the score accumulators in VGPRs beside the 128 registers of Q.  Left to hipcc (this file is built with AGPR
+// accumulators), o + s + s1 + negm = 304 "accumulator" registers did not fit the 256 AGPRs and it spilled Q: one scratch
+// reload per MFMA.  hipcc does not see an asm MFMA's latency: the consumers below are fenced with s_nop by hand.
+__device__ __forceinline__ void fa5_mfma_v(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void fa5_mfma_a(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void fa5_mfma_drain() {   // an 8-pass MFMA's result: 11 wait states before a VALU may read it
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flash_attn512_kernel(const Fa5Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int nqb = (a.Ntok + FA5_QB - 1) / FA5_QB;
+  const int qb = bid % nqb, b = bid / nqb;
+  const bf16_t* Qb = a.Q + (long long)b * a.sQ;
+  const bf16_t* Kb = a.K + (long long)b * a.sK;
+  const bf16_t* Vb = a.Vt + (long long)b * a.sVt;
+  const char* zero = (const char*)a.zero;
+
+  const int q_row = qb * FA5_QB + wave * 32 + l31;
+  const int q_ld = q_row < a.Ntok ? q_row : a.Ntok - 1;
+  bf16x8 qf[32];
+  {
+    const float c = a.scale_log2;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      const uint4 u = *(const uint4*)(Qb + (long long)q_ld * a.ldq + ks * 16 + half * 8);
+      uint4 w;
+      w.x = fa5_cvt_pk(bflo(u.x) * c, bfhi(u.x) * c); w.y = fa5_cvt_pk(bflo(u.y) * c, bfhi(u.y) * c);
+      w.z = fa5_cvt_pk(bflo(u.z) * c, bfhi(u.z) * c); w.w = fa5_cvt_pk(bflo(u.w) * c, bfhi(u.w) * c);
+      qf[ks] = __builtin_bit_cast(bf16x8, w);
+    }
+  }
+  const int nkt = (a.Ntok + FA5_KB - 1) / FA5_KB;
+  // one tile = 16 DMA pieces per wave: K rows 4 i + wave (a 1 KB row per piece), V^T row groups 4 i + wave (16 rows of 64 B)
+  auto issue = [&](int kt, int stage) {
+    char* sb = smem + stage * FA5_STAGE;
+    const int key0 = kt * FA5_KB;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = i * 4 + wave;
+      const char* src = key0 + r < a.Ntok ? (const char*)(Kb + (long long)(key0 + r) * a.ldq + ((lane ^ r) & 63) * 8) : zero;
+      glds16(src, sb + r * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int g = i * 4 + wave;
+      const int d = g * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((d >> 2) & 3);
+      glds16((const char*)(Vb + (long long)d * a.ldvt + key0 + c * 8), sb + FA5_KTILE + g * 1024);
+    }
+  };
+
+  // The softmax runs against a FIXED per-query reference (the first key tile's maximum): p = exp2(s - ref) with no running
+  // maximum and therefore no rescaling of the 256 output accumulators inside the loop (they are only ever touched by MFMAs:
+  // any VALU pass over them makes hipcc shuttle the AGPR file through the VGPRs and spill Q).  fp32 / bf16 carry exponents to
+  // 2^127: as long as no score exceeds its reference by more than 2^FA5_THR nothing overflows and the result is the exact
+  // softmax; if one does (never seen; e^41 above the first tile's maximum), the whole row block is redone with the maxima it
+  // found - a workgroup-uniform retry, so barriers and the DMA ring stay in step.
+  f32x16 o[16], negm;
+  float l0, l1, relmax;
+  float ref = 0.f;
+  auto scores = [&](const char* sK, f32x16& s) {   // s = scale log2e (q . k) - ref for the stage's 32 keys
+    f32x16 s1;
+    s = negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+    const char* krow = sK + l31 * 1024;
+#pragma unroll
+    for (int ks = 0; ks < 32; ks += 2) {
+      const bf16x8 k0 = __builtin_bit_cast(bf16x8, *(const uint4*)(krow + ((((2 * ks + half) ^ l31) & 63) << 4)));
+      const bf16x8 k1 = __builtin_bit_cast(bf16x8, *(const uint4*)(krow + ((((2 * ks + 2 + half) ^ l31) & 63) << 4)));
+      fa5_mfma_v(s, k0, qf[ks]);
+      fa5_mfma_v(s1, k1, qf[ks + 1]);
+    }
+    fa5_mfma_drain();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] += s1[r];
+  };
+  auto tile_max = [&](const f32x16& s) {
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+    float x0, x1;
+    half_swap(mx, mx, x0, x1);
+    return fmaxf(x0, x1);
+  };
+  auto mask_tail = [&](int kt, f32x16& s) {
+    const int kbase = kt * FA5_KB;
+    if (kbase + FA5_KB > a.Ntok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (key >= a.Ntok) s[r] = -1e30f;
+      }
+    }
+  };
+  for (int attempt = 0;; ++attempt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = -ref;
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    l0 = 0.f;
+    l1 = 0.f;
+    relmax = -1e30f;
+    issue(0, 0);
+    if (nkt > 1) issue(1, 1);
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int st = kt & 1;
+      if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const char* sK = smem + st * FA5_STAGE;
+      const char* sV = sK + FA5_KTILE;
+      f32x16 s;
+      scores(sK, s);
+      mask_tail(kt, s);
+      if (attempt == 0 && kt == 0) {   // the reference of the first attempt: this tile's maximum (wave-uniform branch)
+        ref = tile_max(s);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { negm[r] = -ref; s[r] -= ref; }
+      }
+      relmax = fmaxf(relmax, tile_max(s));
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        s[r] = __builtin_amdgcn_exp2f(s[r]);
+        s[r + 1] = __builtin_amdgcn_exp2f(s[r + 1]);
+        l0 += s[r];
+        l1 += s[r + 1];
+      }
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) {
+        const uint32_t a0 = fa5_cvt_pk(s[8 * sh + 0], s[8 * sh + 1]);
+        const uint32_t a1 = fa5_cvt_pk(s[8 * sh + 2], s[8 * sh + 3]);
+        const uint32_t b0 = fa5_cvt_pk(s[8 * sh + 4], s[8 * sh + 5]);
+        const uint32_t b1 = fa5_cvt_pk(s[8 * sh + 6], s[8 * sh + 7]);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(r0[0], r1[0], r0[1], r1[1]));
+        const int c0 = 2 * sh + half;
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) {
+          const int row = dt * 32 + l31;
+          const uint4 vw = *(const uint4*)(sV + row * 64 + ((c0 ^ ((row >> 2) & 3)) << 4));
+          fa5_mfma_a(o[dt], __builtin_bit_cast(bf16x8, vw), pf);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // every wave has read stage st: tile kt + 2 may land in it
+      if (kt + 2 < nkt) issue(kt + 2, st);
+    }
+    fa5_mfma_drain();   // the last P V MFMAs against the VALU that reads (or, on a retry, clears) the output tile
+    if (!__syncthreads_or(relmax > FA5_THR)) break;
+    ref += fmaxf(relmax, 0.f);   // redo the row block against the maxima found (now no score exceeds its reference)
+  }
+  float la, lb;
+  const float l_lane = l0 + l1;
+  half_swap(l_lane, l_lane, la, lb);
+  const float inv = 1.0f / (la + lb);
+  bf16_t* orow = a.O + (long long)b * a.sO + (long long)q_row * a.ldo;
+#pragma unroll
+  for (int dt = 0; dt < 16; ++dt)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) half_swap(o[dt][8 * gp + j] * inv, o[dt][8 * gp + 4 + j] * inv, v[j], v[4 + j]);
+      if (q_row < a.Ntok) {
+        uint4 pk;
+        pk.x = fa5_cvt_pk(v[0], v[1]); pk.y = fa5_cvt_pk(v[2], v[3]);
+        pk.z = fa5_cvt_pk(v[4], v[5]); pk.w = fa5_cvt_pk(v[6], v[7]);
+        *(uint4*)(orow + dt * 32 + 16 * gp + 8 * half) = pk;
+      }
+    }
+}
+
+}  // namespace
+
+int mg_launch_flash512(const mg_op* op, hipStream_t s) {
+  Fa5Args a;
+  a.Q = (const bf16_t*)op->p[0];
+  a.K = (const bf16_t*)op->p[1];
+  a.Vt = (const bf16_t*)op->p[2];
+  a.O = (bf16_t*)op->p[3];
+  a.zero = g_zero_page;
+  a.B = op->i[0]; a.Ntok = op->i[1]; a.ldq = op->i[2]; a.ldo = op->i[3]; a.ldvt = op->i[4];
+  a.sQ = op->l[0]; a.sK = op->l[1]; a.sVt = op->l[2]; a.sO = op->l[3];
+  a.scale_log2 = op->f[0] * 1.4426950408889634f;
+  MG_REQUIRE(g_zero_page || g_dry_run, "flash_attn512: mg_init() not called");
+  MG_REQUIRE(a.Q && a.K && a.Vt && a.O && a.B > 0 && a.Ntok > 0, "flash_attn512: null pointer / empty problem");
+  MG_REQUIRE(a.ldq % 8 == 0 && a.ldo % 8 == 0 && a.ldvt % 8 == 0 && a.ldq >= FA5_D && a.ldo >= FA5_D &&
+             a.ldvt >= (a.Ntok + FA5_KB - 1) / FA5_KB * FA5_KB,
+             "flash_attn512: leading dimensions (V^T rows must hold whole 32-key tiles)");
+  MG_REQUIRE((uintptr_t)a.Q % 16 == 0 && (uintptr_t)a.K % 16 == 0 && (uintptr_t)a.Vt % 16 == 0 && (uintptr_t)a.O % 16 == 0,
+             "flash_attn512: 16-byte alignment");
+  MG_REQUIRE(FA5_D * 2 <= MG_ZERO_BYTES, "flash_attn512: zero page too small");
+  const int LDS = 2 * FA5_STAGE;
+  static bool attr_set = false;
+  if (!attr_set && !g_dry_run) {
+    MG_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const long long grid = (long long)((a.Ntok + FA5_QB - 1) / FA5_QB) * a.B;
+  MG_LAUNCH(flash_attn512_kernel, dim3((unsigned)grid), dim3(256), LDS, s, a);
+  if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
+  return 0;
+}

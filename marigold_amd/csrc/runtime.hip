@@ -43,6 +43,7 @@ static int dispatch(const mg_op* op, hipStream_t s) {
     case MG_OP_GN_APPLY:
     case MG_OP_GN_SLAB:
     case MG_OP_LAYERNORM: return mg_launch_norm(op, s);
+    case MG_OP_FLASH_ATTN512: return mg_launch_flash512(op, s);
     case MG_OP_FLASH_ATTN64:
     case MG_OP_SOFTMAX_ROWS:
     case MG_OP_SOFTMAX_PAIRS: return mg_launch_attention(op, s);

@@ -27,6 +27,7 @@ FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"
 XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)
 VAE_ATTN_CHUNK_BYTES = int(os.environ.get("MARIGOLD_VAE_ATTN_CHUNK_MB", "0")) << 20   # fp32 scores per launch group; 0 = one batched launch per stage
 # (query chunks whose scores fit the 256 MB Infinity Cache measured no gain: vae.decode 62.1 vs 62.9 ms, profiles/r4_vae_attention_chunks.log)
+VAE_FLASH = os.environ.get("MARIGOLD_VAE_FLASH", "1") != "0"          # VAE mid-block attention as a flash kernel (off: materialised scores)
 IGEMM73_CONV = os.environ.get("MARIGOLD_IGEMM73_CONV", "1") != "0"   # plain N = 320 k convolutions on the hand-placed 192 x 320 GEMM tile
 IGEMM72_VAE = os.environ.get("MARIGOLD_IGEMM72_VAE", "1") != "0"    # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
 GN_SLAB = os.environ.get("MARIGOLD_GN_SLAB", "1") != "0"           # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
@@ -696,7 +697,7 @@ class Builder:
         return out
 
     def vae_attention(self, x, name):
-        """Single-head d=C attention of the VAE mid block with materialised fp32 scores."""
+        """Single-head d=C attention of the VAE mid block: flash form for chip-filling batches, else materialised fp32 scores."""
         C, B, T, M = x.C, x.B, x.HW, x.M
         g = self.group_norm(x, f"{name}.group_norm", 1e-6, False)
         wqkv, bqkv = self.ws.qkv(name, True)
@@ -708,6 +709,18 @@ class Builder:
                          out2=vt, trans_from=2 * C, ldt=ldp), f"{name}.qkv")
         self.free(g)
         o = self.new(x.B, x.H, x.W, C)
+        if VAE_FLASH and C == 512 and B * ((T + 127) // 128) >= 200:
+            # round 4: flash form (MG_OP_FLASH_ATTN512) - the T x T scores (340 MB of fp32 per image at 96 x 96 latent pixels)
+            # never leave the registers.  One workgroup per 128 queries and CU: launches that do not fill the chip (the
+            # encoder's single image: 72 workgroups, 0.93 vs 0.50 ms) stay on the three-stage form below
+            # (profiles/r4_flash512.log).
+            self.add(O.flash_attn512(qk, qk.data_ptr() + C * 2, vt, o.t, B=B, Ntok=T, ldq=2 * C, ldo=C, ldvt=ldp,
+                                     sq=T * 2 * C, sk=T * 2 * C, svt=C * ldp, so=T * C, scale=1.0 / math.sqrt(C)), f"{name}.flash")
+            self.free(qk)
+            out = self.dense(o, self.ws.mat(f"{name}.to_out.0"), self.ws.bias(f"{name}.to_out.0"), C,
+                             residual=x, label=f"{name}.to_out")
+            self.free(o)
+            return out
         # The fp32 score matrix of ONE image is T x T x 4 bytes (340 MB at 96 x 96 latent pixels, 3.4 GB for ten members).
         # Optional (MARIGOLD_VAE_ATTN_CHUNK_MB, off): run the three stages per chunk of query rows whose scores fit the
         # Infinity Cache - tried in round 4, no gain on MI355X.

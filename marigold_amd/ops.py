@@ -111,6 +111,11 @@ def flash_attn64(q, k, vt, o, *, B, heads, Ntok, ldq, ldo, ldvt, sq, sk, svt, so
                    p=[q, k, vt, o, dbg], l=[sq, sk, svt, so])
 
 
+def flash_attn512(q, k, vt, o, *, B, Ntok, ldq, ldo, ldvt, sq, sk, svt, so, scale):
+    """One head of width 512 (the VAE mid-block attention), flash form: no score matrix in memory (MG_OP_FLASH_ATTN512)."""
+    return make_op(L.OP_FLASH_ATTN512, i=[B, Ntok, ldq, ldo, ldvt], f=[scale], p=[q, k, vt, o], l=[sq, sk, svt, so])
+
+
 VT_PERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
 
 

@@ -9,14 +9,14 @@ MFMA_PEAK_TFLOPS = 2500.0   # bf16 dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0       # HBM3E spec (6.29 TB/s measured streaming)
 
 CLASS = {
-    L.OP_IGEMM: "igemm_mfma", L.OP_ROWGEMM: "rowgemm_mfma", L.OP_CONV3X3: "conv3x3_patch", L.OP_FLASH_ATTN64: "flash_attn64", L.OP_GN_STATS: "groupnorm",
+    L.OP_IGEMM: "igemm_mfma", L.OP_ROWGEMM: "rowgemm_mfma", L.OP_CONV3X3: "conv3x3_patch", L.OP_FLASH_ATTN64: "flash_attn64", L.OP_FLASH_ATTN512: "flash_attn512", L.OP_GN_STATS: "groupnorm",
     L.OP_GN_FINALIZE: "groupnorm", L.OP_GN_APPLY: "groupnorm", L.OP_GN_SLAB: "groupnorm", L.OP_LAYERNORM: "layernorm",
     L.OP_SOFTMAX_ROWS: "softmax", L.OP_SOFTMAX_PAIRS: "softmax",
     L.OP_SCHED_STEP: "scheduler_step", L.OP_LINEAR_SMALL_M: "time_embedding",
     L.OP_LATENT_1X1: "boundary_conv", L.OP_POST_NCHW: "boundary_conv", L.OP_IM2COL_SMALL: "boundary_conv", L.OP_ENS_DEPTH_STATS: "ensemble", L.OP_ENS_DEPTH_MEDIAN: "ensemble",
     L.OP_ENS_DEPTH_NORM: "ensemble", L.OP_ENS_NORMALS: "ensemble", L.OP_RESIZE: "resize", L.OP_COLORIZE: "resize", L.OP_MEMSET: "memops", L.OP_COPY: "memops",
 }
-BOUND = {"igemm_mfma": "mfma", "rowgemm_mfma": "mfma", "conv3x3_patch": "mfma", "flash_attn64": "mfma"}   # everything else is HBM-bound streaming
+BOUND = {"igemm_mfma": "mfma", "rowgemm_mfma": "mfma", "conv3x3_patch": "mfma", "flash_attn64": "mfma", "flash_attn512": "mfma"}   # everything else is HBM-bound streaming
 
 
 def op_cost(op):
@@ -59,6 +59,10 @@ def op_cost(op):
         B, heads, T = i[0], i[1], i[2]
         flops = 4 * B * heads * T * T * 64
         byts = 4 * B * heads * T * 64 * 2
+    elif k == L.OP_FLASH_ATTN512:
+        B, T = i[0], i[1]
+        flops = 4 * B * T * T * 512
+        byts = 4 * B * T * 512 * 2
     elif k == L.OP_GN_STATS:
         byts = i[0] * i[1] * i[2] * 2
     elif k == L.OP_GN_APPLY:

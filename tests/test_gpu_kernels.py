@@ -1206,6 +1206,75 @@ def test_flash_attn64_running_max_paths(dev, case):
         _close(f"flash_attn64/{case}/v{variant}{'p' if perm else ''}", out, ref)
 
 
+def _flash512_run(dev, q, k, v, B, T):
+    from marigold_amd import ops
+    C = 512
+    ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+    assert torch.isfinite(ref).all()
+    ldvt = ((T + 63) // 64) * 64
+    qk = torch.zeros(B * T + 8, 2 * C, device=dev, dtype=torch.bfloat16)   # the engine's layout: [Q | K] rows, slack rows
+    qk[:B * T] = torch.cat([q, k], dim=-1).reshape(B * T, 2 * C).to(dev, torch.bfloat16)
+    vt = torch.zeros(B, C, ldvt, device=dev, dtype=torch.bfloat16)
+    vt[:, :, :T] = v.permute(0, 2, 1).to(dev, torch.bfloat16)
+    out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.flash_attn512(qk, qk.data_ptr() + C * 2, vt, out, B=B, Ntok=T, ldq=2 * C, ldo=C, ldvt=ldvt,
+                           sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C, scale=1.0 / math.sqrt(C)))
+    return out, ref
+
+
+@pytest.mark.parametrize("B,T", [(1, 32), (1, 31), (2, 130), (3, 576), (1, 1000), (2, 2304)])
+def test_flash_attn512(dev, B, T):
+    """MG_OP_FLASH_ATTN512 (the VAE mid-block attention, one head of width 512) against fp32 SDPA on the host: whole and
+    ragged key tiles, ragged query blocks, several images per launch."""
+    g = torch.Generator().manual_seed(T)
+    q = _bf(torch.randn(B, T, 512, generator=g) * 1.5)
+    k = _bf(torch.randn(B, T, 512, generator=g) * 1.5)
+    v = _bf(torch.randn(B, T, 512, generator=g))
+    out, ref = _flash512_run(dev, q, k, v, B, T)
+    _close(f"flash_attn512/B{B}T{T}", out, ref)
+
+
+@pytest.mark.parametrize("case", ["all_negative", "late_spike", "growing_below_retry", "retry_some_rows", "retry_all_rows"])
+def test_flash_attn512_reference_paths(dev, case):
+    """The kernel's softmax runs against a fixed per-query reference (the first key tile's maximum) and redoes a block of
+    128 queries with the true maxima when a later score tops its reference by more than 2^60:
+      all_negative        - every logit around -60 (log2 units: -87): the reference must be the first tile's maximum whatever
+                            its sign;
+      late_spike          - the largest logit of some rows sits in the last (ragged) tile, ~2^30 above the first tile's;
+      growing_below_retry - the row maximum grows by ~3 log2 units per tile up to ~2^55 times the reference: probabilities
+                            up to 2^55 in the bf16 P operand and the fp32 sums, no retry;
+      retry_some_rows     - a few rows exceed the reference by ~2^80 (their block is redone; its other rows must come out
+                            the same);
+      retry_all_rows      - every row does."""
+    T, C = 1000, 512   # 32 tiles, the last one ragged (8 keys); 8 query blocks, the last one ragged
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(1, T, C, generator=g)
+    k = torch.randn(1, T, C, generator=g)
+    v = _bf(torch.randn(1, T, C, generator=g))
+    u = torch.nn.functional.normalize(torch.randn(C, generator=g), dim=0)
+    sc = math.sqrt(C)   # logit = q.k / sqrt(C)
+    tile = (torch.arange(T) // 32).float()
+    if case == "all_negative":
+        q = q * 0.2 + u * 37.0
+        k = k * 0.2 - u * 37.0                     # q.k ~ -1369, logit ~ -60
+    elif case == "late_spike":
+        k[0, 999] = q[0, 500] * (21.0 * sc / q[0, 500].pow(2).sum())     # logit 21 (2^30) for query 500 at the last key
+        k[0, 996] = q[0, 3] * (25.0 * sc / q[0, 3].pow(2).sum())
+        k[0, 2] = q[0, 900] * (25.0 * sc / q[0, 900].pow(2).sum())       # and one inside tile 0
+    elif case == "growing_below_retry":
+        q = q * 0.1 + u * 8.0
+        k = k * 0.3 + u[None, :] * (tile * (1.75 * 0.6931472 * sc / 8.0))[:, None]   # +1.75 log2 units per tile: 2^54 at tile 31
+    elif case == "retry_some_rows":
+        for i, row in enumerate((5, 130, 131, 640, 999)):
+            k[0, 700 + 3 * i] = q[0, row] * (56.0 * sc / q[0, row].pow(2).sum())   # logit 56 = 2^80.8
+    else:
+        q = q * 0.1 + u * 8.0
+        k = k * 0.3 + u[None, :] * (tile * (2.0 * sc / 8.0))[:, None]   # +2.0 (2.9 log2 units) per tile: 2^89 over the sequence
+    q, k = _bf(q), _bf(k)
+    out, ref = _flash512_run(dev, q, k, v, 1, T)
+    _close(f"flash_attn512/{case}", out, ref)
+
+
 def test_softmax_rows_and_pairs(dev):
     from marigold_amd import ops
     g = torch.Generator().manual_seed(1)
