@@ -16,24 +16,11 @@
 #include <type_traits>
 
 #include "common.h"
+#include "flash_args.h"
+#include "flash25_body.h"
 
 namespace {
 
-struct FaArgs {
-  const bf16_t* Q;
-  const bf16_t* K;
-  const bf16_t* Vt;
-  bf16_t* O;
-  const void* zero;
-  int B, heads, Ntok, ldq, ldo, ldvt, nqb;
-  long long sQ, sK, sVt, sO;
-  float scale_log2;
-  unsigned long long* dbg;   // tuning only: per workgroup (shader cycles, 100 MHz ticks) of the whole kernel body
-};
-
-constexpr int FA_QB = 128;   // queries per workgroup (4 waves x 32)
-constexpr int FA_KB = 64;    // keys per tile
-constexpr int FA_STAGE = 2 * FA_KB * 128;  // K tile + V^T tile, bytes
 
 __global__ __launch_bounds__(256) void flash_attn64_kernel(const FaArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE];
@@ -200,14 +187,7 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(const FaArgs a) {
 //   * P -> bf16 with v_cvt_pk_bf16_f32 (16 instructions per tile instead of ~100 of integer rounding);
 //   * the O / l rescale is skipped (wave-uniform branch) on tiles where no lane's max moved;
 //   * 3-deep K / V^T ring with counted vmcnt + raw s_barrier (tile kt+2 in flight while kt computes).
-typedef __attribute__((ext_vector_type(2))) __bf16 fa_bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) float fa_f32x2_t;
-__device__ __forceinline__ uint32_t fa_cvt_pk(float lo, float hi) {
-  fa_f32x2_t v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, fa_bf16x2_t));
-}
 
-constexpr int FA2_NSTAGE = 3;
 
 // SPLIT: the four LDS-DMA pieces of tile kt+2 are issued behind the two QK^T MFMA groups instead
 // of in one burst after the barrier (their issue cost then overlaps the wave's own MFMAs).
@@ -462,7 +442,6 @@ __global__ __launch_bounds__(NW * 64) void flash_attn64_v2_kernel(const FaArgs a
     }
 }
 
-constexpr float FA3_THR = 3.0f;         // log2 units: the running max is raised when a row max exceeds it by > 2^3
 
 // ---- generation 2.5 ----------------------------------------------------------------------------
 // The generation-2 loop (one score tile live, 3-4 waves per SIMD: every wait is hidden by another wave) with the VALU
@@ -474,228 +453,16 @@ constexpr float FA3_THR = 3.0f;         // log2 units: the running max is raised
 //   * V^T in the accumulator key order (PERM): no v_permlane32_swap;
 //   * row sums as 16 v_pk_add_f32 instead of 32 v_add_f32.
 // 134 registers: three 4-wave workgroups per CU.
-typedef __attribute__((ext_vector_type(2))) float fa_f32x2;
 
 // SUMM (round 4): the row sums come off the matrix pipe - a third P V MFMA per 16 keys against a fragment of ones (every
 // element of its accumulator is the lane's query's sum over the wave tile's keys) replaces the 17 v_pk_add_f32 per tile:
 // the kernel is VALU-issue-bound (~750 issue cycles per tile and wave beside 512 MFMA cycles), the pipe has the room.
 template <int NW, bool PERM, int SUMM = 0>   // SUMM: 0 packed adds, 1 matrix pipe, 2 plain v_add_f32 (two chains)
 __global__ __launch_bounds__(NW * 64) void flash_attn64_v25_kernel(const FaArgs a) {
-  constexpr int NT = NW * 64;
-  constexpr int QB = NW * 32;
-  constexpr int ITS = 512 / NT;
   __shared__ __attribute__((aligned(16))) char smem[FA2_NSTAGE * FA_STAGE];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int nqb = (a.Ntok + QB - 1) / QB;
-  const int qb = bid % nqb;
-  const int bh = bid / nqb;
-  const int h = bh % a.heads, b = bh / a.heads;
-
-  const bf16_t* Qb = a.Q + (long long)b * a.sQ + h * 64;
-  const bf16_t* Kb = a.K + (long long)b * a.sK + h * 64;
-  const bf16_t* Vb = a.Vt + (long long)b * a.sVt + (long long)h * 64 * a.ldvt;
-  const char* zero = (const char*)a.zero;
-
-  const int q_row = qb * QB + wave * 32 + l31;
-  const int q_ld = q_row < a.Ntok ? q_row : a.Ntok - 1;
-  bf16x8 qf[4];
-  {
-    const float c = a.scale_log2;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const uint4 u = *(const uint4*)(Qb + (long long)q_ld * a.ldq + ks * 16 + half * 8);
-      uint4 w;
-      w.x = fa_cvt_pk(bflo(u.x) * c, bfhi(u.x) * c); w.y = fa_cvt_pk(bflo(u.y) * c, bfhi(u.y) * c);
-      w.z = fa_cvt_pk(bflo(u.z) * c, bfhi(u.z) * c); w.w = fa_cvt_pk(bflo(u.w) * c, bfhi(u.w) * c);
-      qf[ks] = __builtin_bit_cast(bf16x8, w);
-    }
-  }
-  const char* k_src[ITS];
-  const char* v_src[ITS];
-  int k_row[ITS];
-#pragma unroll
-  for (int it = 0; it < ITS; ++it) {
-    const int ci = it * NT + tid;
-    const int r = ci >> 3;
-    const int q = (ci & 7) ^ ((r >> 1) & 7);
-    k_row[it] = r;
-    k_src[it] = (const char*)(Kb + (long long)r * a.ldq + q * 8);
-    v_src[it] = (const char*)(Vb + (long long)r * a.ldvt + q * 8);
-  }
-  const long long k_step = (long long)FA_KB * a.ldq * 2;
-  int i_k0 = 0;
-  // only the last key tile can be ragged: every other tile takes its source as it is (no per-lane select)
-  auto issue = [&](int stage, bool ragged) {
-    char* sb = smem + stage * FA_STAGE;
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      const char* src = (!ragged || i_k0 + k_row[it] < a.Ntok) ? k_src[it] : zero;
-      glds16(src, sb + (it * NT + wave * 64) * 16);
-      k_src[it] += k_step;
-    }
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      glds16(v_src[it], sb + FA_KB * 128 + (it * NT + wave * 64) * 16);
-      v_src[it] += FA_KB * 2;
-    }
-    i_k0 += FA_KB;
-  };
-
-  f32x16 o[2], negm, osum;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; osum[r] = 0.f; }
-  fa_f32x2 l2 = {0.f, 0.f};
-  const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
-
-  const int nkt = (a.Ntok + FA_KB - 1) / FA_KB;
-  const bool ragged_end = (a.Ntok & (FA_KB - 1)) != 0;
-  issue(0, nkt == 1 && ragged_end);
-  if (nkt > 1) issue(1, nkt == 2 && ragged_end);
-  auto tile = [&](int kt, int st_c, int st_i, auto issue_tag, auto mask_tag, auto first_tag) {
-    constexpr bool do_issue = decltype(issue_tag)::value;
-    constexpr bool MASK = decltype(mask_tag)::value;
-    constexpr bool FIRST = decltype(first_tag)::value;
-    if (do_issue || kt + 1 < nkt) {
-      if constexpr (ITS == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if constexpr (do_issue) issue(st_i, kt + 3 == nkt && ragged_end);
-    const char* sK = smem + st_c * FA_STAGE;
-    const char* sV = sK + FA_KB * 128;
-    f32x16 s[2];
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-      const int row = t2 * 32 + l31;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int q = ks * 2 + half;
-        const bf16x8 kf = __builtin_bit_cast(bf16x8, *(const uint4*)(sK + row * 128 + ((q ^ ((row >> 1) & 7)) << 4)));
-        s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? negm : s[t2], 0, 0, 0);
-      }
-    }
-    const int kbase = kt * FA_KB;
-    if (MASK && kbase + FA_KB > a.Ntok) {
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kbase + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (key >= a.Ntok) s[t2][r] = -1e30f;
-        }
-    }
-    float m0 = -1e30f, m1 = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) { m0 = fmaxf(fmaxf(m0, s[0][r]), s[0][r + 1]); m1 = fmaxf(fmaxf(m1, s[1][r]), s[1][r + 1]); }
-    float mx = fmaxf(m0, m1);
-    {
-      float x0, x1;
-      half_swap(mx, mx, x0, x1);
-      mx = fmaxf(x0, x1);
-    }
-    if (FIRST || __any(mx > FA3_THR)) {   // raise the running max (first tile: set it, whatever its sign)
-      const float d = FIRST ? mx : fmaxf(mx, 0.f);
-      const float alpha = __builtin_amdgcn_exp2f(-d);
-      if constexpr (!FIRST) {
-        if constexpr (SUMM == 1) osum[0] *= alpha;   // (only element 0 is read at the end; the others run on unscaled, unused)
-        else l2 *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { negm[r] -= d; s[0][r] -= d; s[1][r] -= d; }
-    }
-    fa_f32x2 ps = {0.f, 0.f};
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        fa_f32x2 p2;
-        p2.x = __builtin_amdgcn_exp2f(s[t2][r]);
-        p2.y = __builtin_amdgcn_exp2f(s[t2][r + 1]);
-        s[t2][r] = p2.x;
-        s[t2][r + 1] = p2.y;
-        if constexpr (SUMM == 0) ps += p2;   // v_pk_add_f32
-        if constexpr (SUMM == 2) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(ps.x) : "v"(p2.x)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(ps.y) : "v"(p2.y)); }
-      }
-    if constexpr (SUMM != 1) l2 += ps;
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-#pragma unroll
-      for (int sh = 0; sh < 2; ++sh) {
-        const uint32_t a0 = fa_cvt_pk(s[t2][8 * sh + 0], s[t2][8 * sh + 1]);
-        const uint32_t a1 = fa_cvt_pk(s[t2][8 * sh + 2], s[t2][8 * sh + 3]);
-        const uint32_t b0 = fa_cvt_pk(s[t2][8 * sh + 4], s[t2][8 * sh + 5]);
-        const uint32_t b1 = fa_cvt_pk(s[t2][8 * sh + 6], s[t2][8 * sh + 7]);
-        uint4 pw;
-        if constexpr (PERM) {
-          pw = make_uint4(a0, a1, b0, b1);
-        } else {
-          const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-          const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-          pw = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-        }
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const int row = dt * 32 + l31;
-          const int c0 = 4 * t2 + 2 * sh + half;
-          const uint4 vw = *(const uint4*)(sV + row * 128 + ((c0 ^ ((row >> 1) & 7)) << 4));
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
-        }
-        if constexpr (SUMM == 1) osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, osum, 0, 0, 0);
-      }
-    }
-  };
-  {
-    using T = std::true_type;
-    using F = std::false_type;
-    int kt = 0, st_c = 0, st_i = 2;
-    auto rot = [&]() {
-      st_c = (st_c + 1 == FA2_NSTAGE) ? 0 : st_c + 1;
-      st_i = (st_i + 1 == FA2_NSTAGE) ? 0 : st_i + 1;
-    };
-    if (nkt > 2) tile(0, 0, 2, T{}, F{}, T{});
-    else tile(0, 0, 2, F{}, T{}, T{});
-    kt = 1; rot();
-    for (; kt + 5 <= nkt; kt += 3) {   // literal ring stages in the steady state: kt = 1 (mod 3) here
-      tile(kt, 1, 0, T{}, F{}, F{});
-      tile(kt + 1, 2, 1, T{}, F{}, F{});
-      tile(kt + 2, 0, 2, T{}, F{}, F{});
-    }
-    for (; kt + 2 < nkt; ++kt) { tile(kt, st_c, st_i, T{}, F{}, F{}); rot(); }
-    for (; kt < nkt; ++kt) { tile(kt, st_c, st_i, F{}, T{}, F{}); rot(); }
-  }
-  float inv;
-  if constexpr (SUMM == 1) {
-    inv = 1.0f / osum[0];   // the MFMA summed over both key halves already
-  } else {
-    float l0, l1;
-    const float l_lane = l2.x + l2.y;
-    half_swap(l_lane, l_lane, l0, l1);
-    inv = 1.0f / (l0 + l1);
-  }
-  bf16_t* orow = a.O + (long long)b * a.sO + (long long)q_row * a.ldo + h * 64;
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int gp = 0; gp < 2; ++gp) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) half_swap(o[dt][8 * gp + j] * inv, o[dt][8 * gp + 4 + j] * inv, v[j], v[4 + j]);
-      if (q_row < a.Ntok) {
-        uint4 pk;
-        pk.x = fa_cvt_pk(v[0], v[1]); pk.y = fa_cvt_pk(v[2], v[3]);
-        pk.z = fa_cvt_pk(v[4], v[5]); pk.w = fa_cvt_pk(v[6], v[7]);
-        *(uint4*)(orow + dt * 32 + 16 * gp + 8 * half) = pk;
-      }
-    }
+  const int nqb = (a.Ntok + NW * 32 - 1) / (NW * 32);
+  fa25_body<NW, PERM, SUMM>(a, smem, bid % nqb, bid / nqb);
 }
 
 // ---- generation 3 ------------------------------------------------------------------------------
@@ -1125,6 +892,7 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       a.sQ = op->l[0]; a.sK = op->l[1]; a.sVt = op->l[2]; a.sO = op->l[3];
       a.scale_log2 = op->f[0] * 1.4426950408889634f;
       a.dbg = (unsigned long long*)op->p[4];
+      a.redo_thr = op->f[1] > 0.f ? op->f[1] : 1.2676506e30f;   // 2^100 (tests force the fallback with a tiny value)
       a.nqb = (a.Ntok + FA_QB - 1) / FA_QB;
       MG_REQUIRE(g_zero_page || g_dry_run, "flash_attn64: mg_init() not called");
       MG_REQUIRE(a.Q && a.K && a.Vt && a.O, "flash_attn64: null pointer");
@@ -1136,7 +904,7 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       const bool v2ok = (a.ldo % 8 == 0) && ((uintptr_t)a.O % 16 == 0) && (a.sO % 8 == 0);
       const int var = v2ok ? op->i[6] : 1;
       const bool vt_perm = op->i[7] != 0;   // V^T keys permuted inside every group of 16: [0-3, 8-11, 4-7, 12-15]
-      MG_REQUIRE(vt_perm == ((var >= 13 && var <= 20) || var == 22 || var == 23 || var == 25) || var == 0, "flash_attn64: variant %d and the V^T key order (i[7] = %d) do not match", var, op->i[7]);
+      MG_REQUIRE(vt_perm == ((var >= 13 && var <= 20) || var == 22 || var == 23 || var == 25 || var == 26) || var == 0, "flash_attn64: variant %d and the V^T key order (i[7] = %d) do not match", var, op->i[7]);
       MG_REQUIRE(!vt_perm || a.Ntok % 16 == 0, "flash_attn64: the permuted V^T layout needs Ntok %% 16 == 0");
       const long long g4 = (long long)((a.Ntok + 127) / 128) * a.heads * a.B;
       const long long g8 = (long long)((a.Ntok + 255) / 256) * a.heads * a.B;
@@ -1156,6 +924,9 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
         case 23: MG_LAUNCH((flash_attn64_v25_kernel<8, true, 1>), dim3((unsigned)g8), dim3(512), 0, s, a); break;
         case 24: MG_LAUNCH((flash_attn64_v25_kernel<4, false, 1>), dim3((unsigned)g4), dim3(256), 0, s, a); break;
         case 25: MG_LAUNCH((flash_attn64_v25_kernel<4, true, 2>), dim3((unsigned)g4), dim3(256), 0, s, a); break;   // plain v_add_f32 row sums
+        case 26:   // the hand-placed one-wave-per-SIMD stream (flash4w.hip)
+          MG_REQUIRE(mg_flash4w_ok(a, vt_perm), "flash_attn64 variant 26: Ntok %d must be a multiple of 256 (even number of key tiles), V^T permuted", a.Ntok);
+          return mg_launch_flash4w(a, s);
         case 17: MG_LAUNCH((flash_attn64_v2_kernel<true, 4, 3>), dim3((unsigned)g4), dim3(256), 0, s, a); break;   // vt_perm
         case 18: MG_LAUNCH((flash_attn64_v2_kernel<true, 8, 3>), dim3((unsigned)g8), dim3(512), 0, s, a); break;
         // generation 3: 9 / 10 = 8 / 4 waves, natural V^T; 11 / 12 = + row sums on the matrix pipe; 13-16 = the same four with

@@ -104,10 +104,13 @@ def layernorm(x, gamma, beta, out, *, M, C, eps=1e-5):
     return make_op(L.OP_LAYERNORM, i=[M, C], f=[eps], p=[x, gamma, beta, out])
 
 
-def flash_attn64(q, k, vt, o, *, B, heads, Ntok, ldq, ldo, ldvt, sq, sk, svt, so, scale, variant=0, vt_perm=False, dbg=None):
+def flash_attn64(q, k, vt, o, *, B, heads, Ntok, ldq, ldo, ldvt, sq, sk, svt, so, scale, variant=0, vt_perm=False, dbg=None,
+                 redo_thr=0.0):
     """``vt_perm``: V^T holds its keys in the order [0-3, 8-11, 4-7, 12-15] inside every group of 16 (what MG_OP_IGEMM's
-    transposed section writes with ``trans_perm``) - generation 3 consumes that order without a lane exchange."""
-    return make_op(L.OP_FLASH_ATTN64, i=[B, heads, Ntok, ldq, ldo, ldvt, variant, int(vt_perm)], f=[scale],
+    transposed section writes with ``trans_perm``) - generation 3 consumes that order without a lane exchange.
+    ``redo_thr`` (tests only; 0 = 2^100): the row-sum bound above which the hand-placed kernel (variant 26) redoes a block of
+    queries with the running-maximum loop."""
+    return make_op(L.OP_FLASH_ATTN64, i=[B, heads, Ntok, ldq, ldo, ldvt, variant, int(vt_perm)], f=[scale, redo_thr],
                    p=[q, k, vt, o, dbg], l=[sq, sk, svt, so])
 
 

@@ -1206,6 +1206,71 @@ def test_flash_attn64_running_max_paths(dev, case):
         _close(f"flash_attn64/{case}/v{variant}{'p' if perm else ''}", out, ref)
 
 
+@pytest.mark.parametrize("B,heads,T", [(1, 1, 256), (2, 2, 512), (1, 5, 1024), (1, 2, 2304), (2, 1, 768)])
+@pytest.mark.parametrize("redo_thr", [0.0, 1e-30])
+def test_flash_attn64_hand_placed(dev, B, heads, T, redo_thr):
+    """Variant 26 (flash4w.hip: one wave per SIMD, 64 queries per wave, the key loop as one hand-placed instruction stream,
+    softmax against the first tile's row maximum) against fp32 SDPA on the host; ``redo_thr`` = 1e-30 sends every workgroup
+    through its running-maximum fallback as well."""
+    from marigold_amd import ops
+    C = heads * 64
+    g = torch.Generator().manual_seed(T + heads)
+    qkv = _bf(torch.randn(B, T, 3 * C, generator=g) * 1.3)
+    q, k, v = qkv.split(C, dim=-1)
+    qh, kh, vh = (t.reshape(B, T, heads, 64).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, T, C)
+    qkd = qkv.to(dev, torch.bfloat16)
+    vtp = ops.permute_vt_keys(v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16))
+    out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.flash_attn64(qkd, qkd[:, :, C:], vtp, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=T, sq=T * 3 * C,
+                          sk=T * 3 * C, svt=C * T, so=T * C, scale=0.125, variant=26, vt_perm=True, redo_thr=redo_thr))
+    _close(f"flash_attn64/hand-placed/B{B}h{heads}T{T}/thr{redo_thr}", out, ref)
+
+
+@pytest.mark.parametrize("case", ["all_negative", "late_spike_2^40", "growing_2^90", "spike_past_2^100", "first_tile_spike"])
+def test_flash_attn64_hand_placed_reference_paths(dev, case):
+    """Variant 26 keeps ONE reference per query (the first key tile's row maximum):
+      all_negative     - logits around -60: the reference is the first tile's maximum whatever its sign;
+      late_spike_2^40  - some rows' largest logit sits in the last tile, 2^40 above the first tile's: probabilities up to 2^40
+                         in the bf16 P operand and the fp32 sums, no fallback;
+      growing_2^90     - the row maximum grows by ~6 log2 units per tile over 16 tiles (still below the 2^100 bound);
+      spike_past_2^100 - a few rows exceed their reference by ~2^115: their row sums pass 2^100 and the workgroup redoes its
+                         256 queries with the running-maximum loop (the other workgroups do not);
+      first_tile_spike - the maximum is in tile 0: everything else underflows towards 0 relative to it."""
+    from marigold_amd import ops
+    T, C = 1024, 64
+    g = torch.Generator().manual_seed(9)
+    q = torch.randn(1, T, C, generator=g)
+    k = torch.randn(1, T, C, generator=g)
+    v = _bf(torch.randn(1, T, C, generator=g))
+    u = torch.nn.functional.normalize(torch.randn(C, generator=g), dim=0)
+    tile = (torch.arange(T) // 64).float()
+    if case == "all_negative":
+        q = q * 0.2 + u * 22.0
+        k = k * 0.2 - u * 22.0
+    elif case == "late_spike_2^40":
+        for i, row in enumerate((3, 300, 301, 777, 1023)):
+            k[0, 1000 + 4 * i] = q[0, row] * (28.0 * 8.0 / q[0, row].pow(2).sum())     # logit 28 = 2^40.4
+    elif case == "growing_2^90":
+        q = q * 0.1 + u * 8.0
+        k = k * 0.3 + u[None, :] * (tile * 4.1)[:, None]     # logit +4.1 (5.9 log2 units) per tile: 2^89 at tile 15
+    elif case == "spike_past_2^100":
+        for i, row in enumerate((5, 6, 400)):
+            k[0, 900 + 8 * i] = q[0, row] * (80.0 * 8.0 / q[0, row].pow(2).sum())      # logit 80 = 2^115
+    else:
+        for i, row in enumerate((10, 500, 900)):
+            k[0, 7 + 9 * i] = q[0, row] * (60.0 * 8.0 / q[0, row].pow(2).sum())
+    q, k = _bf(q), _bf(k)
+    ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+    assert torch.isfinite(ref).all()
+    qkv = torch.cat([q, k], dim=-1).to(dev, torch.bfloat16)
+    vtp = ops.permute_vt_keys(v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16))
+    out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.flash_attn64(qkv, qkv[:, :, C:], vtp, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T, sq=0, sk=0, svt=0, so=0,
+                          scale=0.125, variant=26, vt_perm=True))
+    _close(f"flash_attn64/hand-placed/{case}", out, ref)
+
+
 def _flash512_run(dev, q, k, v, B, T):
     from marigold_amd import ops
     C = 512

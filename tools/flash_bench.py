@@ -31,6 +31,16 @@ def timeit(fn, warm=1, iters=4):
 
 
 def case(B, heads, T, qscale=1.0):
+    global VARIANTS
+    all_variants = VARIANTS
+    VARIANTS = tuple(v for v in VARIANTS if v != 26 or (T % 256 == 0 and T >= 256))   # the hand-placed form's shapes
+    try:
+        _case(B, heads, T, qscale)
+    finally:
+        VARIANTS = all_variants
+
+
+def _case(B, heads, T, qscale=1.0):
     C = heads * 64
     g = torch.Generator(device="cpu").manual_seed(2)
     qkv = (torch.randn(B, T, 3 * C, generator=g)).to(torch.bfloat16)
@@ -48,8 +58,8 @@ def case(B, heads, T, qscale=1.0):
     outs, ops, times = {}, {}, {v: [] for v in VARIANTS}
     for v in VARIANTS:
         outs[v] = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
-        ops[v] = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
-                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(13 <= v <= 20 or v in (22, 23, 25)))
+        ops[v] = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25, 26)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
+                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(13 <= v <= 20 or v in (22, 23, 25, 26)))
     for rnd in range(ROUNDS):
         for v in VARIANTS:
             times[v].append(timeit(lambda: O.launch(ops[v])))
@@ -63,8 +73,8 @@ def case(B, heads, T, qscale=1.0):
             nw = 8 if v in (9, 11, 13, 15) else 4
             nwg = -(-T // (nw * 32)) * heads * B
             dbg = torch.zeros(nwg * nw * 8, dtype=torch.int64, device=dev)
-            op = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
-                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(13 <= v <= 20 or v in (22, 23, 25)), dbg=dbg)
+            op = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25, 26)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
+                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(13 <= v <= 20 or v in (22, 23, 25, 26)), dbg=dbg)
             O.launch(op)
             O.launch(op)
             torch.cuda.synchronize()
@@ -88,6 +98,10 @@ def case(B, heads, T, qscale=1.0):
 
 
 if __name__ == "__main__":
+    if os.environ.get("FLASH_OCC"):   # occupancy steps: B x heads x 72 workgroups of 4 waves at 9 216 tokens
+        for bh in [int(x) for x in os.environ.get('FLASH_OCC_BH', '1,2,3,5,7,8,10,11,14,15,21,22').split(',')]:
+            case(1, bh, 9216)
+        sys.exit(0)
     E = int(os.environ.get("FLASH_E", "10"))
     case(E, 5, 9216)
     case(E, 10, 2304)
