@@ -946,6 +946,11 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
           // round 4: the row sums as plain v_add_f32 on two chains instead of v_pk_add_f32 (a packed fp32 add beside MFMAs costs
           // more than the two adds it replaces, MI355X_MICROARCH.md): 9216 tokens 975 vs 947 TFLOP/s, 2304: 795 vs 743
           // (the sums on the matrix pipe, SUMM = 1: 945 / 828) - profiles/r4_flash_rowsum_mfma.log
+          // round 4: the hand-placed one-wave-per-SIMD stream (variant 26, flash4w.hip) where its shape constraints hold
+          // (the 96 x 96 and 48 x 48 levels: 9 216 / 2 304 tokens): 1 022-1 067 vs 907-928 TFLOP/s at 9 216 tokens, 893 vs 782
+          // at 2 304 (profiles/r4_flash4w.log).  MARIGOLD_FLASH4W=0 switches it off (A/B).
+          static const int f4w = [] { const char* e = getenv("MARIGOLD_FLASH4W"); return e ? atoi(e) : 1; }();
+          if (f4w && vt_perm && mg_flash4w_ok(a, true)) return mg_launch_flash4w(a, s);
           if (vt_perm) MG_LAUNCH((flash_attn64_v25_kernel<4, true, 2>), dim3((unsigned)g4), dim3(256), 0, s, a);
           else MG_LAUNCH((flash_attn64_v25_kernel<4, false>), dim3((unsigned)g4), dim3(256), 0, s, a);
           break;

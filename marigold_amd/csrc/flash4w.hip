@@ -8,8 +8,9 @@
 //   * one wave per SIMD (4-wave workgroup, 512 registers per lane), 64 queries per wave = two 32-query blocks that share every
 //     K / V^T fragment read from LDS (half the LDS traffic per MFMA: at 32 queries per wave the fragment reads alone need the
 //     CU's whole 128 B / cycle);
-//   * the key loop is ONE asm statement written by gen_fa4w.py (flash4w.inc): per 64-key tile 32 MFMAs with five VALU
-//     instructions of the softmax behind each, the QK^T MFMAs of tile t + 1 and the P V MFMAs of tile t in the same stream,
+//   * the key loop is ONE asm statement written by gen_fa4w.py (flash4w.inc): per 64-key tile 40 MFMAs (32 + 8 for the row
+//     sums: ones x P) with two or three VALU instructions of the softmax (v_exp_f32, v_cvt_pk_bf16_f32) behind each, the
+//     QK^T MFMAs of tile t + 1 and the P V MFMAs of tile t in the same stream,
 //     fragment reads 3-7 MFMAs ahead with counted waits, the LDS-DMA pieces of ring slot t + 3 among them, one barrier per tile;
 //   * softmax against a FIXED per-query reference (the first tile's row maximum, subtracted by the first QK^T MFMA's C operand):
 //     no running maximum, no rescaling - 16 v_max3 and the branch per tile are gone and the output accumulators (AGPRs) are
@@ -133,31 +134,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int d = 0; d < 2; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[q][d][r] = 0.f;
-  float l00 = 0.f, l01 = 0.f, l10 = 0.f, l11 = 0.f;
+  f32x16 rs[2];   // row sums off the matrix pipe: ones x P (every element = the lane's query's sum over the keys so far)
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rs[q][r] = 0.f;
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
   const int nkt = a.Ntok >> 6;
   unsigned sok = f4_sgpr(3u * kst), sov = f4_sgpr(2u * 128u), mb = f4_sgpr(mw + 3 * F4_SLOT), cnt = f4_sgpr((unsigned)((nkt - 4) >> 1));
   uint4 ka, kb_, va0, va1, vb0, vb1;
+  unsigned long long t0 = 0, r0 = 0;
+  if (a.dbg) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   asm volatile(FA4W_ASM
                : "+{v[128:143]}"(s[0][0]), "+{v[144:159]}"(s[0][1]), "+{v[160:175]}"(s[1][0]), "+{v[176:191]}"(s[1][1]),
                  [o00] "+a"(o[0][0]), [o01] "+a"(o[0][1]), [o10] "+a"(o[1][0]), [o11] "+a"(o[1][1]),
-                 [l00] "+v"(l00), [l01] "+v"(l01), [l10] "+v"(l10), [l11] "+v"(l11),
+                 [rs0] "+a"(rs[0]), [rs1] "+a"(rs[1]),
                  [ad0] "+v"(ad[0]), [ad1] "+v"(ad[1]), [ad2] "+v"(ad[2]), [ad3] "+v"(ad[3]),
                  [ka] "=&v"(ka), [kb] "=&v"(kb_), [va0] "=&v"(va0), [va1] "=&v"(va1), [vb0] "=&v"(vb0), [vb1] "=&v"(vb1),
                  [sok] "+s"(sok), [sov] "+s"(sov), [mb] "+s"(mb), [cnt] "+s"(cnt)
                : [q00] "v"(qf[0][0]), [q01] "v"(qf[0][1]), [q02] "v"(qf[0][2]), [q03] "v"(qf[0][3]),
                  [q10] "v"(qf[1][0]), [q11] "v"(qf[1][1]), [q12] "v"(qf[1][2]), [q13] "v"(qf[1][3]),
-                 [ng0] "v"(negm[0]), [ng1] "v"(negm[1]),
+                 [ng0] "v"(negm[0]), [ng1] "v"(negm[1]), [one] "v"(ones),
                  [vk0] "v"(vk[0]), [vk1] "v"(vk[1]), [vv0] "v"(vv[0]), [vv1] "v"(vv[1]),
                  [srk] "s"(srk), [srv] "s"(srv), [kst] "s"(kst)
                : "memory", "scc", FA4W_CLOBBERS);
+  if (a.dbg) {   // tuning only: shader cycles / 100 MHz ticks of the key loop, per wave
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) { a.dbg[(bid * 4 + wave) * 2] = t1 - t0; a.dbg[(bid * 4 + wave) * 2 + 1] = r1 - r0; }
+  }
   // ---- finalize: O[q][d] = o^T / l; lane^32 exchange -> 8 consecutive d per lane, 16-byte stores ----
   bool bad = false;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    float la, lb;
-    const float l_lane = q == 0 ? l00 + l01 : l10 + l11;
-    half_swap(l_lane, l_lane, la, lb);
-    const float l_tot = la + lb;
+    const float l_tot = rs[q][0];
     bad = bad || !(l_tot < a.redo_thr);   // 2^100 (or not finite): a score topped the first tile's maximum by about that much
     const float inv = 1.0f / l_tot;
     const int q_row = qb * 256 + wave * 64 + q * 32 + l31;

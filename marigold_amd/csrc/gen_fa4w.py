@@ -7,15 +7,16 @@ gfx950 the softmax's VALU work and the MFMAs only overlap when they are interlea
 SIMD that alternate whole phases (what hipcc emits for flash_attn64_v25) reach 75 % of the interleaved stream's rate, and the
 compiled kernel, with its `s_waitcnt lgkmcnt(0)` in front of every MFMA and `s_nop 10` behind every score tile, about half.
 
-One iteration t of the stream (one 64-key tile; the wave's 64 queries are two blocks q of 32) is 32 MFMAs in eight groups
-SG0..SG7 of four:
+One iteration t of the stream (one 64-key tile; the wave's 64 queries are two blocks q of 32) is 40 MFMAs in eight groups
+SG0..SG7:
     SG i:  QK(kb, ks, q0)  QK(kb, ks, q1)  PV(g, d0, q)  PV(g, d1, q)       g = i >> 1, q = i & 1, kb = i >> 2, ks = i & 3
   * QK(kb, ks, q) accumulates the scores of tile t + 1 (key block kb, 16 channels ks) into the NEXT score registers; its first
     k-step takes -reference as its C operand, so that p = exp2(s) needs no subtraction;
   * PV(g, d, q) multiplies V^T (16 keys g, 32 channels d) of tile t by P(q, g), eight probabilities per lane packed IN PLACE
     into the first four registers of their own eight scores;
-  * behind each MFMA come five of the twenty VALU instructions (8 v_exp_f32, 8 v_add_f32 for the row sums, 4
-    v_cvt_pk_bf16_f32) that turn the eight scores of group i + 1 into P(i + 1); SG7 does group 0 of tile t + 1.
+  * a fifth MFMA per group, ones x P(q, g), accumulates the row sums (every element of its accumulator = the query's sum);
+  * behind each MFMA come two or three of the twelve VALU instructions (8 v_exp_f32, 4 v_cvt_pk_bf16_f32) that turn the
+    eight scores of group i + 1 into P(i + 1); SG7 does group 0 of tile t + 1.
   * K / V^T fragments are read (ds_read_b128) three to seven MFMAs ahead into two K and four V buffers, every wait is a counted
     lgkmcnt; the LDS-DMA pieces of ring slot t + 3 (K tile t + 3, V^T tile t + 2) go out behind MFMAs 8 / 12 / 16 / 20;
   * one barrier per tile, behind MFMA 27: slot t + 2 has landed for every wave and nobody reads slot t - 1 any more; the
@@ -36,30 +37,24 @@ def vt(b, n):
     return f"v[{b}:{b + n - 1}]"
 
 
-def vgroup(R, la, lb):
-    """exp2, row sums and packing of the eight scores in v[R : R + 7]; P ends up in v[R : R + 3].  A transcendental's result is
-    never read by the next instruction (gfx940-family TRANS -> VALU hazard: one wait state, nothing inserts it here)."""
+def vgroup(R):
+    """exp2 and packing of the eight scores in v[R : R + 7]; P ends up in v[R : R + 3] (the row sums come off the matrix pipe:
+    a P x ones MFMA per group - in one wave a v_add_f32 costs 5 issue cycles, 64 of them a fifth of the iteration).  A
+    transcendental's result is never read by the next instruction (gfx940-family TRANS -> VALU hazard: one wait state,
+    nothing inserts it here)."""
     r = [f"v{R + j}" for j in range(8)]
     return [
         f"v_exp_f32 {r[0]}, {r[0]}",
         f"v_exp_f32 {r[1]}, {r[1]}",
-        f"v_add_f32 {la}, {la}, {r[0]}",
         f"v_exp_f32 {r[2]}, {r[2]}",
-        f"v_add_f32 {lb}, {lb}, {r[1]}",
         f"v_exp_f32 {r[3]}, {r[3]}",
-        f"v_add_f32 {la}, {la}, {r[2]}",
         f"v_cvt_pk_bf16_f32 {r[0]}, {r[0]}, {r[1]}",
         f"v_exp_f32 {r[4]}, {r[4]}",
-        f"v_add_f32 {lb}, {lb}, {r[3]}",
         f"v_cvt_pk_bf16_f32 {r[1]}, {r[2]}, {r[3]}",
         f"v_exp_f32 {r[5]}, {r[5]}",
-        f"v_add_f32 {la}, {la}, {r[4]}",
         f"v_exp_f32 {r[6]}, {r[6]}",
-        f"v_add_f32 {lb}, {lb}, {r[5]}",
         f"v_exp_f32 {r[7]}, {r[7]}",
         f"v_cvt_pk_bf16_f32 {r[2]}, {r[4]}, {r[5]}",
-        f"v_add_f32 {la}, {la}, {r[6]}",
-        f"v_add_f32 {lb}, {lb}, {r[7]}",
         f"v_cvt_pk_bf16_f32 {r[3]}, {r[6]}, {r[7]}",
     ]
 
@@ -144,16 +139,17 @@ def block(par, kind, queue):
         for d in (0, 1):     # behind the QK^T pair: the P of this group was packed by the last VALU instructions of the
             mf.append((f"{MFMA} %[o{q}{d}], %[{vbuf}{d}], {P}, %[o{q}{d}]", f"{vbuf}{d}"))   # previous group (VALU write ->
             #                                                      MFMA operand read needs wait states nothing inserts here)
+        mf.append((f"{MFMA} %[rs{q}], %[one], {P}, %[rs{q}]", None))      # row sums: every element = the query's sum over the group
         # VALU of this group of MFMAs: scores of group i + 1 (SG7: group 0 of the next tile)
         if i < 7:
             gi = i + 1
             gq, gg = gi & 1, gi >> 1
-            va = vgroup(cur[(gq, gg >> 1)] + 8 * (gg & 1), f"%[l{gq}0]", f"%[l{gq}1]")
+            va = vgroup(cur[(gq, gg >> 1)] + 8 * (gg & 1))
         elif not last:
-            va = vgroup(nxt[(0, 0)], "%[l00]", "%[l01]")
+            va = vgroup(nxt[(0, 0)])
         else:
             va = []
-        per = -(-len(va) // len(mf)) if va else 0
+        split = ([3, 3, 2, 2, 2] if not last else [5, 5, 2]) if va else [0] * len(mf)
         for k, (text, buf) in enumerate(mf):
             kk = k if not last else 2 * k + 1      # (the last tile's two PV MFMAs stand for positions 1 and 3 of the full group)
             if last and k == 0:                    # (... whose P was packed just before: the wait states a QK^T pair gives elsewhere)
@@ -161,7 +157,8 @@ def block(par, kind, queue):
             d_ = dma.get((i, k))
             if d_:
                 st.op(f"s_add_u32 m0, %[mb], {d_[3]}")
-            st.need(buf)
+            if buf:
+                st.need(buf)
             st.op(text)
             if d_:
                 vo, srd, so, _ = d_
@@ -172,7 +169,7 @@ def block(par, kind, queue):
                     st.op("s_add_u32 %[sov], %[sov], 128")
                     st.op("s_add_u32 %[mb], %[mb], 0x4000")
                     st.op("s_and_b32 %[mb], %[mb], 0xffff")
-            for text2 in va[k * per:(k + 1) * per]:
+            for text2 in va[sum(split[:k]):sum(split[:k + 1])]:
                 st.op(text2)
             for (b, ad, off) in rd.get((i, kk), []):
                 st.read(b, ad, off)
@@ -188,7 +185,7 @@ def block(par, kind, queue):
 
 def main():
     lines = ["s_waitcnt lgkmcnt(0)"]
-    lines += vgroup(SA[(0, 0)], "%[l00]", "%[l01]")
+    lines += vgroup(SA[(0, 0)])
     st = Stream([])
     st.op("s_waitcnt vmcnt(4)")
     st.op("s_barrier")

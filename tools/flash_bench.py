@@ -66,6 +66,19 @@ def _case(B, heads, T, qscale=1.0):
     line = f"flash B={B} heads={heads} T={T} qscale={qscale}:"
     if os.environ.get("FLASH_DBG"):   # generation 3 only: shader cycles / wall ticks per workgroup
         for v in VARIANTS:
+            if v == 26:   # the hand-placed form: cycles of the key loop per wave
+                nwg = (T // 256) * heads * B
+                dbg = torch.zeros(nwg * 4 * 2, dtype=torch.int64, device=dev)
+                op = O.flash_attn64(qkd, qkd[:, :, C:], vtp, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt, sq=T * 3 * C,
+                                    sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=26, vt_perm=True, dbg=dbg)
+                O.launch(op)
+                O.launch(op)
+                torch.cuda.synchronize()
+                d = dbg.view(nwg, 4, 2).double().cpu()
+                cyc, tick = d[:, :, 0].flatten(), d[:, :, 1].flatten()
+                print(f"   v26: {nwg} workgroups; key loop {cyc.median():.0f} cycles per wave = {cyc.median() / (T // 64):.0f} per 64-key iteration "
+                      f"(32 MFMAs = 1024); min {cyc.min() / (T // 64):.0f} max {cyc.max() / (T // 64):.0f}; clock {float((cyc / tick).median()) * 100:.0f} MHz", flush=True)
+                continue
             if v < 9:
                 continue
             if v > 16:
