@@ -1,35 +1,38 @@
 #!/usr/bin/env python3
 """Generator of flash4w.inc: the whole key loop of flash attention at head width 64 as ONE hand-placed instruction stream
-(flash4w.hip: one wave per SIMD, 64 queries per wave, 64-key tiles).
+(flash4w.hip: 64 queries per wave, 64-key tiles, two waves per SIMD).
 
 Why a generator: round 4's micro-benchmark (tools/ubench/coissue2.hip, profiles/r4_ubench_flash_like_waves.log) shows that on
 gfx950 the softmax's VALU work and the MFMAs only overlap when they are interleaved instruction by instruction - three waves per
 SIMD that alternate whole phases (what hipcc emits for flash_attn64_v25) reach 75 % of the interleaved stream's rate, and the
 compiled kernel, with its `s_waitcnt lgkmcnt(0)` in front of every MFMA and `s_nop 10` behind every score tile, about half.
+A single wave, though, is bound by its own issue (one instruction at a time: ~9 cycles per v_exp_f32 / v_cvt_pk_bf16_f32, ~5 per
+v_add_f32, ~8 per MFMA: 1 600-1 680 cycles per tile against 1 024 of MFMA time, the first form of this file), so the stream is
+kept to 192 VGPRs + 64 AGPRs and two workgroups share a CU.
 
-One iteration t of the stream (one 64-key tile; the wave's 64 queries are two blocks q of 32) is 40 MFMAs in eight groups
-SG0..SG7:
-    SG i:  QK(kb, ks, q0)  QK(kb, ks, q1)  PV(g, d0, q)  PV(g, d1, q)       g = i >> 1, q = i & 1, kb = i >> 2, ks = i & 3
-  * QK(kb, ks, q) accumulates the scores of tile t + 1 (key block kb, 16 channels ks) into the NEXT score registers; its first
-    k-step takes -reference as its C operand, so that p = exp2(s) needs no subtraction;
-  * PV(g, d, q) multiplies V^T (16 keys g, 32 channels d) of tile t by P(q, g), eight probabilities per lane packed IN PLACE
-    into the first four registers of their own eight scores;
-  * a fifth MFMA per group, ones x P(q, g), accumulates the row sums (every element of its accumulator = the query's sum);
-  * behind each MFMA come two or three of the twelve VALU instructions (8 v_exp_f32, 4 v_cvt_pk_bf16_f32) that turn the
-    eight scores of group i + 1 into P(i + 1); SG7 does group 0 of tile t + 1.
-  * K / V^T fragments are read (ds_read_b128) three to seven MFMAs ahead into two K and four V buffers, every wait is a counted
-    lgkmcnt; the LDS-DMA pieces of ring slot t + 3 (K tile t + 3, V^T tile t + 2) go out behind MFMAs 8 / 12 / 16 / 20;
-  * one barrier per tile, behind MFMA 27: slot t + 2 has landed for every wave and nobody reads slot t - 1 any more; the
-    fragments of the next iteration's first MFMAs are requested right behind it, under MFMAs 28-31.
-The score registers ping-pong between v[128:191] and v[192:255] (physical: single registers of the score tuples are VALU
-operands), so the stream is emitted for both parities; the loop body is two iterations.
+The wave's 64 queries are two blocks q of 32; a key tile is two halves of 32 keys = four groups g of 16.  The scores live in
+two register sets of 2 x 16: X = v[128:159] (half 0 of a tile), Y = v[160:191] (half 1) - physical registers, single ones are
+VALU operands.  One iteration t = one tile = 32 MFMAs in eight groups SG0..SG7 of four:
+    SG0-3 (half 0):  two QK^T MFMAs of tile t's half 1 into Y (q0: SG0 / SG1, q1: SG2 / SG3), two P V MFMAs of X's groups
+    SG4-7 (half 1):  two QK^T MFMAs of tile t + 1's half 0 into X,                              two P V MFMAs of Y's groups
+  * a QK^T chain's first k-step takes -reference as its C operand: p = exp2(s) needs no subtraction;
+  * P(q, g) - eight probabilities per lane - is packed IN PLACE into the first four registers of its own eight scores, by the
+    twenty VALU instructions (8 v_exp_f32, 8 v_add_f32 for the row sums, 4 v_cvt_pk_bf16_f32) placed five behind each MFMA of
+    the group BEFORE the one whose P V MFMAs read it (a VALU result needs wait states before an MFMA may read it as an operand:
+    nothing inserts them in an asm stream; the QK^T pair in front of every P V pair provides them);
+  * the four K fragments of a half and the four V^T fragments of two groups stay in registers for both query blocks (half the
+    LDS traffic per MFMA of a 32-query wave), reloaded by ds_read_b128 as soon as their last MFMA has issued, every wait a
+    counted lgkmcnt;
+  * ring slot t of four 16 KB slots holds what iteration t reads: K rows 64 t + 32 ... 64 t + 95 (tile t's half 1, tile t + 1's
+    half 0) and V^T tile t; the LDS-DMA pieces of slot t + 3 go out behind the first MFMAs of SG1-SG4; one barrier per tile,
+    behind SG6: slot t + 1 has landed for every wave and nobody reads slot t - 1 any more.
 
-Stream = ENTRY, LOOP x cnt {FULL_A, FULL_B}, FULL_A, VONLY_B, NODMA_A, LAST_B   (nkt even, >= 4; cnt = (nkt - 4) / 2)
+Stream = ENTRY, LOOP x cnt {FULL}, NODMA(vmcnt 4), NODMA(vmcnt 0), LAST        (cnt = nkt - 3 >= 1)
 """
 import sys
 
-SA = {(0, 0): 128, (0, 1): 144, (1, 0): 160, (1, 1): 176}
-SB = {(0, 0): 192, (0, 1): 208, (1, 0): 224, (1, 1): 240}
+X = {0: 128, 1: 144}      # score set of a tile's half 0: query block -> first register
+Y = {0: 160, 1: 176}
 MFMA = "v_mfma_f32_32x32x16_bf16"
 
 
@@ -37,24 +40,30 @@ def vt(b, n):
     return f"v[{b}:{b + n - 1}]"
 
 
-def vgroup(R):
-    """exp2 and packing of the eight scores in v[R : R + 7]; P ends up in v[R : R + 3] (the row sums come off the matrix pipe:
-    a P x ones MFMA per group - in one wave a v_add_f32 costs 5 issue cycles, 64 of them a fifth of the iteration).  A
-    transcendental's result is never read by the next instruction (gfx940-family TRANS -> VALU hazard: one wait state,
-    nothing inserts it here)."""
+def vgroup(R, la, lb):
+    """exp2, row sums and packing of the eight scores in v[R : R + 7]; P ends up in v[R : R + 3].  A transcendental's result is
+    never read by the next instruction (gfx940-family TRANS -> VALU hazard: one wait state, nothing inserts it here)."""
     r = [f"v{R + j}" for j in range(8)]
     return [
         f"v_exp_f32 {r[0]}, {r[0]}",
         f"v_exp_f32 {r[1]}, {r[1]}",
+        f"v_add_f32 {la}, {la}, {r[0]}",
         f"v_exp_f32 {r[2]}, {r[2]}",
+        f"v_add_f32 {lb}, {lb}, {r[1]}",
         f"v_exp_f32 {r[3]}, {r[3]}",
+        f"v_add_f32 {la}, {la}, {r[2]}",
         f"v_cvt_pk_bf16_f32 {r[0]}, {r[0]}, {r[1]}",
         f"v_exp_f32 {r[4]}, {r[4]}",
+        f"v_add_f32 {lb}, {lb}, {r[3]}",
         f"v_cvt_pk_bf16_f32 {r[1]}, {r[2]}, {r[3]}",
         f"v_exp_f32 {r[5]}, {r[5]}",
+        f"v_add_f32 {la}, {la}, {r[4]}",
         f"v_exp_f32 {r[6]}, {r[6]}",
+        f"v_add_f32 {lb}, {lb}, {r[5]}",
         f"v_exp_f32 {r[7]}, {r[7]}",
         f"v_cvt_pk_bf16_f32 {r[2]}, {r[4]}, {r[5]}",
+        f"v_add_f32 {la}, {la}, {r[6]}",
+        f"v_add_f32 {lb}, {lb}, {r[7]}",
         f"v_cvt_pk_bf16_f32 {r[3]}, {r[6]}, {r[7]}",
     ]
 
@@ -85,96 +94,106 @@ class Stream:
             self.queue = []
 
 
-def rotate(st, j):
-    st.op(f"v_add_u32 %[ad{j}], 0x4000, %[ad{j}]")
-    st.op(f"v_and_b32 %[ad{j}], 0xffff, %[ad{j}]")
+KOFF0, KOFF1, VOFF = 0, 4096, 8192     # inside a slot: K of this tile's half 1, K of the next tile's half 0, V^T
 
 
-def tail(st, vmcnt, kreads):
-    """Slot t + 2 has landed for everybody, slot t - 1 is free; the first fragments of the next iteration."""
-    st.drain()
-    st.op(f"s_waitcnt vmcnt({vmcnt})")
-    st.op("s_barrier")
-    rotate(st, 0)
-    if kreads:
-        st.read("ka", 0, 0)
-    st.read("va0", 0, 8192)
-    st.read("va1", 0, 8192 + 4096)
-    for j in (1, 2, 3):
-        rotate(st, j)
+def entry_reads(st):
+    """The fragments SG0 of an iteration starts from, out of the slot the address registers point at."""
+    st.read("kf0", 0, KOFF0)
+    st.read("kf1", 1, KOFF0)
+    st.read("vf0", 0, VOFF)
+    st.read("vf1", 0, VOFF + 4096)
 
 
-def block(par, kind, queue):
-    """kind: 'full' (K + V^T pieces of slot t + 3) | 'vonly' (V^T of the last tile only) | 'nodma' | 'last' (no next tile)."""
-    cur, nxt = (SA, SB) if par == 0 else (SB, SA)
+def entry_reads2(st):
+    st.read("kf2", 2, KOFF0)
+    st.read("kf3", 3, KOFF0)
+    st.read("vf2", 1, VOFF)
+    st.read("vf3", 1, VOFF + 4096)
+
+
+def block(kind, queue):
+    """kind: 'full' (LDS-DMA of slot t + 3) | 'nodma4' | 'nodma0' (no DMA; tail waits vmcnt(4) / vmcnt(0)) | 'last'."""
     st = Stream(queue)
     last = kind == "last"
-    if not last:
-        st.read("kb", 1, 0)                       # K(j = 1): kb = 0, ks = 1
-    # fragment reads issued behind MFMA k of group i: (buffer, address register, offset)
-    rd = {(0, 1): [("vb0", 1, 8192), ("vb1", 1, 12288)],
-          (1, 3): [("va0", 2, 8192), ("va1", 2, 12288)],
-          (3, 3): [("vb0", 3, 8192), ("vb1", 3, 12288)]}
-    if not last:
-        for i, j in ((0, 2), (1, 3), (2, 4), (3, 5), (4, 6), (5, 7)):   # K(j) into the buffer group i has just released
-            rd.setdefault((i, 1), []).insert(0, ("ka" if j % 2 == 0 else "kb", j & 3, (j >> 2) * 4096))
     dma = {}
     if kind == "full":
-        dma = {(2, 0): ("vk0", "srk", "sok", 0), (3, 0): ("vk1", "srk", "sok", 4096),
-               (4, 0): ("vv0", "srv", "sov", 8192), (5, 0): ("vv1", "srv", "sov", 12288)}
-    elif kind == "vonly":
-        dma = {(4, 0): ("vv0", "srv", "sov", 8192), (5, 0): ("vv1", "srv", "sov", 12288)}
+        dma = {1: ("vk0", "srk", "sok", 0), 2: ("vk1", "srk", "sok", 4096), 3: ("vv0", "srv", "sov", 8192), 4: ("vv1", "srv", "sov", 12288)}
     for i in range(8):
-        g, q = i >> 1, i & 1
-        kbj, ksj = i >> 2, i & 3
-        vbuf = "va" if g % 2 == 0 else "vb"
-        P = vt(cur[(q, g >> 1)] + 8 * (g & 1), 4)
-        mf = []
-        if not last:
-            kbuf = "ka" if i % 2 == 0 else "kb"
-            for qq in (0, 1):
-                D = vt(nxt[(qq, kbj)], 16)
-                C = f"%[ng{qq}]" if ksj == 0 else D
-                mf.append((f"{MFMA} {D}, %[{kbuf}], %[q{qq}{ksj}], {C}", kbuf))
-        for d in (0, 1):     # behind the QK^T pair: the P of this group was packed by the last VALU instructions of the
-            mf.append((f"{MFMA} %[o{q}{d}], %[{vbuf}{d}], {P}, %[o{q}{d}]", f"{vbuf}{d}"))   # previous group (VALU write ->
-            #                                                      MFMA operand read needs wait states nothing inserts here)
-        mf.append((f"{MFMA} %[rs{q}], %[one], {P}, %[rs{q}]", None))      # row sums: every element = the query's sum over the group
-        # VALU of this group of MFMAs: scores of group i + 1 (SG7: group 0 of the next tile)
-        if i < 7:
-            gi = i + 1
-            gq, gg = gi & 1, gi >> 1
-            va = vgroup(cur[(gq, gg >> 1)] + 8 * (gg & 1))
+        half = i >> 2
+        cur = X if half == 0 else Y          # scores being consumed
+        nxt = Y if half == 0 else X          # scores being produced (this tile's half 1 / the next tile's half 0)
+        q = (i >> 1) & 1                     # SG0,1 / SG4,5: query block 0;  SG2,3 / SG6,7: query block 1
+        pair = i & 1                         # k-steps (2 pair, 2 pair + 1) of the QK^T chain; group 2 half + pair of P V
+        qk, pv = [], []
+        if not (last and half == 1):
+            for ks in (2 * pair, 2 * pair + 1):
+                D = vt(nxt[q], 16)
+                C = f"%[ng{q}]" if ks == 0 else D
+                qk.append((f"{MFMA} {D}, %[kf{ks}], %[q{q}{ks}], {C}", f"kf{ks}"))
+        P = vt(cur[q] + 8 * pair, 4)
+        vb = 2 * pair                        # V^T buffers: vf0, vf1 for a half's first group, vf2, vf3 for its second
+        for d in (0, 1):
+            pv.append((f"{MFMA} %[o{q}{d}], %[vf{vb + d}], {P}, %[o{q}{d}]", f"vf{vb + d}"))
+        # QK, PV, QK, PV: the two k-steps of one score accumulator are not back to back, every P V MFMA has an MFMA and five
+        # VALU instructions between the packing of its P and itself
+        mf = [qk[0], pv[0], qk[1], pv[1]] if qk else pv
+        # the VALU stream: P of the group whose P V MFMAs come in the NEXT group of MFMAs
+        j = i + 1
+        if j < 8:
+            jh, jq, jp = j >> 2, (j >> 1) & 1, j & 1
+            va = vgroup((X if jh == 0 else Y)[jq] + 8 * jp, f"%[l{jq}0]", f"%[l{jq}1]")
         elif not last:
-            va = vgroup(nxt[(0, 0)])
+            va = vgroup(X[0], "%[l00]", "%[l01]")       # (q0, first group) of the next tile
         else:
             va = []
-        split = ([3, 3, 2, 2, 2] if not last else [5, 5, 2]) if va else [0] * len(mf)
+        n = len(mf)
+        per = -(-len(va) // n) if va else 0
         for k, (text, buf) in enumerate(mf):
-            kk = k if not last else 2 * k + 1      # (the last tile's two PV MFMAs stand for positions 1 and 3 of the full group)
-            if last and k == 0:                    # (... whose P was packed just before: the wait states a QK^T pair gives elsewhere)
-                st.op("s_nop 4")
-            d_ = dma.get((i, k))
-            if d_:
-                st.op(f"s_add_u32 m0, %[mb], {d_[3]}")
-            if buf:
-                st.need(buf)
+            first = k == 0
+            if first and i in dma:
+                st.op(f"s_add_u32 m0, %[mb], {dma[i][3]}")
+            if last and half == 1 and first:
+                st.op("s_nop 4")      # (no QK^T pair in front of this P V pair: the wait states behind the VALU that packed its P)
+            st.need(buf)
             st.op(text)
-            if d_:
-                vo, srd, so, _ = d_
+            if first and i in dma:
+                vo, srd, so, _ = dma[i]
                 st.op(f"buffer_load_dwordx4 %[{vo}], %[{srd}], %[{so}] offen lds")
-                if (i, k) == (3, 0):
+                if i == 2:
                     st.op("s_add_u32 %[sok], %[sok], %[kst]")
-                if (i, k) == (5, 0):
+                if i == 4:
                     st.op("s_add_u32 %[sov], %[sov], 128")
                     st.op("s_add_u32 %[mb], %[mb], 0x4000")
                     st.op("s_and_b32 %[mb], %[mb], 0xffff")
-            for text2 in va[sum(split[:k]):sum(split[:k + 1])]:
+            for text2 in va[k * per:(k + 1) * per]:
                 st.op(text2)
-            for (b, ad, off) in rd.get((i, kk), []):
-                st.read(b, ad, off)
+            qk_done = (not (last and half == 1)) and k == 2       # behind the group's second QK^T MFMA
+            pv_done = k == n - 1
+            # fragment reloads, as soon as the buffer's last MFMA has issued (q1's groups: SG2, SG3 / SG6, SG7)
+            if i == 2 and qk_done and not last:
+                st.read("kf0", 0, KOFF1)
+                st.read("kf1", 1, KOFF1)
+            if i == 3 and qk_done and not last:
+                st.read("kf2", 2, KOFF1)
+                st.read("kf3", 3, KOFF1)
+            if i == 2 and pv_done:
+                st.read("vf0", 2, VOFF)
+                st.read("vf1", 2, VOFF + 4096)
+            if i == 3 and pv_done:
+                st.read("vf2", 3, VOFF)
+                st.read("vf3", 3, VOFF + 4096)
         if i == 6 and not last:
-            tail(st, {"full": 4, "vonly": 2, "nodma": 0}[kind], kind != "nodma")
+            # slot t + 1 has landed for everybody, slot t - 1 is free; the address registers move on
+            st.drain()
+            st.op("s_waitcnt vmcnt(%d)" % {"full": 8, "nodma4": 4, "nodma0": 0}[kind])
+            st.op("s_barrier")
+            for jj in range(4):
+                st.op(f"v_add_u32 %[ad{jj}], 0x4000, %[ad{jj}]")
+                st.op(f"v_and_b32 %[ad{jj}], 0xffff, %[ad{jj}]")
+            entry_reads(st)
+        if i == 7 and not last:
+            entry_reads2(st)
     if last:
         st.drain()
         st.op("s_nop 7")
@@ -185,40 +204,34 @@ def block(par, kind, queue):
 
 def main():
     lines = ["s_waitcnt lgkmcnt(0)"]
-    lines += vgroup(SA[(0, 0)])
+    lines += vgroup(X[0], "%[l00]", "%[l01]")
     st = Stream([])
-    st.op("s_waitcnt vmcnt(4)")
+    st.op("s_waitcnt vmcnt(8)")
     st.op("s_barrier")
-    st.read("ka", 0, 0)
-    st.read("va0", 0, 8192)
-    st.read("va1", 0, 8192 + 4096)
+    entry_reads(st)
+    entry_reads2(st)
     lines += st.out
     q0 = st.queue
-    fa, qa = block(0, "full", q0)
-    fb, qb = block(1, "full", qa)
-    assert qa == q0 and qb == q0, (q0, qa, qb)
-    lines += ["s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 .Lfa4w_after%=", ".Lfa4w_loop%=:"]
-    lines += fa + fb
-    lines += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 .Lfa4w_loop%=", ".Lfa4w_after%=:"]
-    lines += fa
-    vb, q1 = block(1, "vonly", qa)
-    lines += vb
-    na, q2 = block(0, "nodma", q1)
-    lines += na
-    lb, q3 = block(1, "last", q2)
+    full, qa = block("full", q0)
+    assert qa == q0, (q0, qa)
+    lines += [".Lfa4w_loop%=:"]
+    lines += full
+    lines += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 .Lfa4w_loop%="]
+    n4, q1 = block("nodma4", q0)
+    n0, q2 = block("nodma0", q1)
+    lb, q3 = block("last", q2)
     assert q3 == []
-    lines += lb
-    n_mfma = sum(1 for x in fa if x.startswith(MFMA))
-    n_valu = sum(1 for x in fa if x.startswith("v_") and not x.startswith(MFMA))
-    n_lds = sum(1 for x in fa if x.startswith("ds_"))
+    lines += n4 + n0 + lb
+    n_mfma = sum(1 for x in full if x.startswith(MFMA))
+    n_valu = sum(1 for x in full if x.startswith("v_") and not x.startswith(MFMA))
+    n_lds = sum(1 for x in full if x.startswith("ds_"))
     with open(sys.argv[1] if len(sys.argv) > 1 else "flash4w.inc", "w") as f:
         f.write("// Generated by gen_fa4w.py - do not edit.  One FULL iteration: %d MFMA, %d VALU, %d ds_read_b128, %d lines.\n"
-                % (n_mfma, n_valu, n_lds, len(fa)))
+                % (n_mfma, n_valu, n_lds, len(full)))
         f.write("#define FA4W_ASM \\\n")
         for x in lines:
             f.write('  "%s\\n\\t" \\\n' % x)
         f.write('  ""\n')
-        f.write("#define FA4W_CLOBBERS " + ", ".join('"v%d"' % r for r in range(192, 256)) + "\n")
 
 
 if __name__ == "__main__":
