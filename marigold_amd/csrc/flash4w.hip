@@ -19,9 +19,18 @@
 //     are only ever touched by MFMAs.  Exact as long as no later score tops its reference by more than ~2^100; the row sums
 //     tell (>= 2^100 or not finite) and such a workgroup redoes its queries with the running-maximum loop of flash_attn64_v25
 //     (flash25_body.h; FaArgs::redo_thr lets the tests force that path).
-// Ring slot t of the four 16 KB slots holds what iteration t reads: K rows 64 t + 32 ... 64 t + 95 and V^T tile t; K rows
-// 0 ... 31 go to a 4 KB region of their own for the prologue.  Needs Ntok % 256 == 0, at least four key tiles and V^T in the
-// accumulator's key order (vt_perm).
+// Ring slot t of the four 16 KB slots holds what iteration t reads: K rows 64 t + 32 ... 64 t + 95 and V^T tile t; the K rows
+// of the prologue (the first 32 keys of the sequence: the reference; the first 32 keys of the segment: the stream's first
+// scores) go to two 4 KB regions of their own.  Needs Ntok % 256 == 0, at least four key tiles and V^T in the accumulator's
+// key order (vt_perm).
+//
+// Workgroups: a block of 256 queries keeps a workgroup busy for ~200 us, so a launch whose number of blocks is not a multiple of
+// the chip's slots ends in a round that a few CUs run alone (E = 10 at 9 216 tokens: 1 800 blocks on 512 slots = 3.52 rounds,
+// paid as 4).  With a workspace from the caller (FaArgs::ws) the blocks beyond the last multiple of the CU count are therefore
+// split along the KEYS over the slots: the fixed reference depends on the sequence's first 32 keys only - every piece of a block
+// computes the same one - so the pieces' unnormalised outputs and row sums simply ADD.  Each piece leaves its partial result
+// in the workspace and draws a ticket; the block's last piece adds the others to its registers, normalises and stores (no
+// spinning: nothing waits for a workgroup that may not be resident).
 #include "flash_args.h"
 #include "flash25_body.h"
 #include "flash4w.inc"
@@ -33,7 +42,10 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
-constexpr int F4_SLOT = 16384, F4_PRE = 4 * F4_SLOT, F4_LDS = F4_PRE + 4096;
+constexpr int F4_SLOT = 16384, F4_PRE = 4 * F4_SLOT, F4_LDS = F4_PRE + 2 * 4096;
+constexpr int F4_PIECES = 4;                                   // at most four key pieces per block of queries
+constexpr int F4_PART_BYTES = 4 * (16384 + 1024);               // one piece's partial result: per wave 64 x 64 fp32 + 16 bytes of row sums per lane
+constexpr int F4_CTR_BYTES = 4096;                             // tickets (zero between launches) in front of the partial results
 
 __device__ __forceinline__ void f4_mfma(f32x16& acc, const bf16x8& a, const bf16x8& b) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
@@ -43,35 +55,31 @@ __device__ __forceinline__ void f4_dma(unsigned voff, i32x4 srd, unsigned soff, 
 }
 __device__ __forceinline__ unsigned f4_sgpr(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn64_4w_kernel(const FaArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // the ring: LDS address 0 (the stream wraps addresses at 64 KB)
+// Piece boundaries of the split blocks, in key tiles over the concatenated blocks: workgroup r of `nwg` takes [f4_bound(r),
+// f4_bound(r + 1)).  A boundary closer than four tiles to a block's edge moves onto it (the stream needs four tiles).
+// (32-bit: the launcher keeps r total below 2^31)
+__device__ __host__ __forceinline__ unsigned f4_bound(unsigned r, unsigned nwg, unsigned total, unsigned nkt) {
+  unsigned s = (r * total + nwg / 2) / nwg;
+  const unsigned m = s % nkt;
+  if (m > 0 && m < 4) s -= m;
+  else if (m + 4 > nkt) s += nkt - m;
+  return s;
+}
+
+// One segment: key tiles [t0, t1) of the 256 queries of block `blk`.  `part` < 0: the whole block (normalise and store);
+// else: piece `part` of `npieces` of split block `rem` (partial result + ticket, the last piece finishes).
+__device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const int blk, const int t0, const int t1, const int part,
+                                           const int npieces, const int rem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int nqb = a.Ntok >> 8;
-  const int qb = bid % nqb, bh = bid / nqb;
+  const int qb = blk % nqb, bh = blk / nqb;
   const int h = bh % a.heads, b = bh / a.heads;
   const bf16_t* Qb = a.Q + (long long)b * a.sQ + h * 64;
   const bf16_t* Kb = a.K + (long long)b * a.sK + h * 64;
   const bf16_t* Vb = a.Vt + (long long)b * a.sVt + (long long)h * 64 * a.ldvt;
 
-  bf16x8 qf[2][4];
-  {
-    const float c = a.scale_log2;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int q_row = qb * 256 + wave * 64 + q * 32 + l31;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const uint4 u = *(const uint4*)(Qb + (long long)q_row * a.ldq + ks * 16 + half * 8);
-        uint4 w;
-        w.x = cvt_pk_bf16_f32(bflo(u.x) * c, bfhi(u.x) * c); w.y = cvt_pk_bf16_f32(bflo(u.y) * c, bfhi(u.y) * c);
-        w.z = cvt_pk_bf16_f32(bflo(u.z) * c, bfhi(u.z) * c); w.w = cvt_pk_bf16_f32(bflo(u.w) * c, bfhi(u.w) * c);
-        qf[q][ks] = __builtin_bit_cast(bf16x8, w);
-      }
-    }
-  }
   // LDS-DMA: 16-byte element ci = it * 256 + tid of a tile = row ci >> 3, chunk position ci & 7 (source chunk XOR-swizzled)
   unsigned vk[2], vv[2];
 #pragma unroll
@@ -89,34 +97,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const i32x4 srk = srd_of(Kb, (unsigned)((a.Ntok - 1) * a.ldq * 2 + 128)), srv = srd_of(Vb, 0x80000000u);
   const unsigned kst = f4_sgpr((unsigned)(64 * a.ldq * 2));   // one key tile of K rows, bytes
   const unsigned mw = f4_sgpr((unsigned)(wave * 1024));
-  // K rows 0 ... 31 into the prologue's region, then slots 0, 1, 2 (K rows 64 s + 32 ..., V^T tile s)
+  const unsigned k0 = f4_sgpr((unsigned)t0 * kst), v0 = f4_sgpr((unsigned)t0 * 128u);
+  __builtin_amdgcn_s_barrier();   // (a previous segment's / the fallback's readers are done with the ring)
+  // K rows 0 ... 31 (the reference) and 64 t0 ... + 31 (the stream's first scores), then slots 0, 1, 2
   f4_dma(vk[0], srk, 0u, f4_sgpr(mw + F4_PRE));
+  f4_dma(vk[0], srk, k0, f4_sgpr(mw + F4_PRE + 4096));
 #pragma unroll
   for (int sl = 0; sl < 3; ++sl) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) f4_dma(vk[it], srk, f4_sgpr((unsigned)sl * kst + (kst >> 1)), f4_sgpr(mw + sl * F4_SLOT + it * 4096));
+    for (int it = 0; it < 2; ++it) f4_dma(vk[it], srk, f4_sgpr(k0 + (unsigned)sl * kst + (kst >> 1)), f4_sgpr(mw + sl * F4_SLOT + it * 4096));
 #pragma unroll
-    for (int it = 0; it < 2; ++it) f4_dma(vv[it], srv, (unsigned)(sl * 128), f4_sgpr(mw + sl * F4_SLOT + 8192 + it * 4096));
+    for (int it = 0; it < 2; ++it) f4_dma(vv[it], srv, f4_sgpr(v0 + (unsigned)(sl * 128)), f4_sgpr(mw + sl * F4_SLOT + 8192 + it * 4096));
+  }
+  // (the queries after the LDS-DMA pieces: their latency runs beside the DMA's; the counted waits below and in the stream only
+  // ever see fewer loads in flight than they allow)
+  bf16x8 qf[2][4];
+  {
+    const float c = a.scale_log2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int q_row = qb * 256 + wave * 64 + q * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 u = *(const uint4*)(Qb + (long long)q_row * a.ldq + ks * 16 + half * 8);
+        uint4 w;
+        w.x = cvt_pk_bf16_f32(bflo(u.x) * c, bfhi(u.x) * c); w.y = cvt_pk_bf16_f32(bflo(u.y) * c, bfhi(u.y) * c);
+        w.z = cvt_pk_bf16_f32(bflo(u.z) * c, bfhi(u.z) * c); w.w = cvt_pk_bf16_f32(bflo(u.w) * c, bfhi(u.w) * c);
+        qf[q][ks] = __builtin_bit_cast(bf16x8, w);
+      }
+    }
   }
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  // scores of the first 32 keys (S^T = K Q^T: lane = query, registers = keys) and the queries' reference = their row maximum
+  // S^T = K Q^T (lane = query, registers = keys): the reference = the row maximum over the sequence's first 32 keys
   const int sw = (l31 >> 1) & 7;
   unsigned ad[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) ad[ks] = (unsigned)(l31 * 128 + (((2 * ks + half) ^ sw) << 4));
   f32x16 s[2], negm[2];
+  auto first_scores = [&](int region) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[q][r] = 0.f;
+      for (int r = 0; r < 16; ++r) s[q][r] = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const bf16x8 kf = __builtin_bit_cast(bf16x8, *(const uint4*)(smem + F4_PRE + ad[ks]));
-    f4_mfma(s[0], kf, qf[0][ks]);
-    f4_mfma(s[1], kf, qf[1][ks]);
-  }
-  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 kf = __builtin_bit_cast(bf16x8, *(const uint4*)(smem + region + ad[ks]));
+      f4_mfma(s[0], kf, qf[0][ks]);
+      f4_mfma(s[1], kf, qf[1][ks]);
+    }
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+  };
+  first_scores(F4_PRE);
+  float ref[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     float mx = -1e30f;
@@ -124,10 +157,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[q][r], s[q][r + 1]));
     float x0, x1;
     half_swap(mx, mx, x0, x1);
-    const float ref = fmaxf(x0, x1);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { negm[q][r] = -ref; s[q][r] -= ref; }
+    ref[q] = fmaxf(x0, x1);
   }
+  if (t0 != 0) first_scores(F4_PRE + 4096);   // (wave-uniform)
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { negm[q][r] = -ref[q]; s[q][r] -= ref[q]; }
   f32x16 o[2][2];
 #pragma unroll
   for (int q = 0; q < 2; ++q)
@@ -136,11 +172,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[q][d][r] = 0.f;
   float l00 = 0.f, l01 = 0.f, l10 = 0.f, l11 = 0.f;
-  const int nkt = a.Ntok >> 6;
-  unsigned sok = f4_sgpr(3u * kst + (kst >> 1)), sov = f4_sgpr(3u * 128u), mb = f4_sgpr(mw + 3 * F4_SLOT), cnt = f4_sgpr((unsigned)(nkt - 3));
+  unsigned sok = f4_sgpr(k0 + 3u * kst + (kst >> 1)), sov = f4_sgpr(v0 + 3u * 128u), mb = f4_sgpr(mw + 3 * F4_SLOT),
+           cnt = f4_sgpr((unsigned)(t1 - t0 - 3));
   uint4 kf0, kf1, kf2, kf3, vf0, vf1, vf2, vf3;
-  unsigned long long t0 = 0, r0 = 0;
-  if (a.dbg) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  unsigned long long tm0 = 0, rm0 = 0;
+  if (a.dbg) { tm0 = __builtin_amdgcn_s_memtime(); rm0 = __builtin_amdgcn_s_memrealtime(); }
   asm volatile(FA4W_ASM
                : "+{v[128:143]}"(s[0]), "+{v[144:159]}"(s[1]),
                  [o00] "+v"(o[0][0]), [o01] "+v"(o[0][1]), [o10] "+v"(o[1][0]), [o11] "+v"(o[1][1]),
@@ -155,19 +191,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                  [vk0] "v"(vk[0]), [vk1] "v"(vk[1]), [vv0] "v"(vv[0]), [vv1] "v"(vv[1]),
                  [srk] "s"(srk), [srv] "s"(srv), [kst] "s"(kst)
                : "memory", "scc", F4_CLOBBER_Y);
-  if (a.dbg) {   // tuning only: shader cycles / 100 MHz ticks of the key loop, per wave
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (lane == 0) { a.dbg[(bid * 4 + wave) * 2] = t1 - t0; a.dbg[(bid * 4 + wave) * 2 + 1] = r1 - r0; }
+  if (a.dbg) {   // tuning only: shader cycles / 100 MHz ticks (+ tiles << 40) of the key loop, per wave of the workgroup's last segment
+    const unsigned long long tm1 = __builtin_amdgcn_s_memtime(), rm1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      a.dbg[((long long)blockIdx.x * 4 + wave) * 2] = tm1 - tm0;
+      a.dbg[((long long)blockIdx.x * 4 + wave) * 2 + 1] = (rm1 - rm0) | ((unsigned long long)(t1 - t0) << 40);
+    }
   }
+  float ll[2] = {l00 + l01, l10 + l11};   // the lane's share of its queries' row sums (the other half-wave holds the rest)
+  bool finish = true;
+  if (part >= 0) {
+    // ---- a piece: leave the partial result, draw a ticket; the block's last piece adds the others to its registers ----
+    // Hand-off (cdna_hip_programming.md, the split-K slab recipe in its write-through form): 16-byte sc1 stores -> every wave
+    // drains vmcnt -> __syncthreads -> ONE relaxed agent-scope ticket; the last piece reads the slabs with sc1 loads (they
+    // bypass its L1; the stores went through L2).  No release / acquire fence: an agent-scope release writes back the XCD's
+    // whole L2 - with __threadfence() here the split launch ran 1.7 x SLOWER than the unsplit one.
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc((char*)a.ws + F4_CTR_BYTES, 0, 0x7fffffff, 0x00020000);
+    const unsigned mine = (unsigned)(((long long)rem * F4_PIECES + part) * F4_PART_BYTES + wave * (16384 + 1024));
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32x4 v = {__float_as_uint(o[q][d][4 * j]), __float_as_uint(o[q][d][4 * j + 1]), __float_as_uint(o[q][d][4 * j + 2]),
+                           __float_as_uint(o[q][d][4 * j + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, wsr, mine + ((q * 2 + d) * 4 + j) * 1024 + lane * 16, 0, 16);
+        }
+    {
+      const u32x4 v = {__float_as_uint(ll[0]), __float_as_uint(ll[1]), 0u, 0u};
+      __builtin_amdgcn_raw_buffer_store_b128(v, wsr, mine + 16384 + lane * 16, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = (int*)(smem + F4_PRE);
+    if (tid == 0) {
+      unsigned* ctr = (unsigned*)a.ws + rem;
+      const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool lastp = ticket == (unsigned)(npieces - 1);
+      if (lastp) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream-ordered)
+      *flag = lastp ? 1 : 0;
+    }
+    __syncthreads();
+    finish = *flag != 0;
+    __syncthreads();
+    if (finish) {
+      for (int pp = 0; pp < npieces; ++pp) {
+        if (pp == part) continue;
+        const unsigned other = (unsigned)(((long long)rem * F4_PIECES + pp) * F4_PART_BYTES + wave * (16384 + 1024));
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wsr, other + ((q * 2 + d) * 4 + j) * 1024 + lane * 16, 0, 16);
+              o[q][d][4 * j] += __uint_as_float(v.x); o[q][d][4 * j + 1] += __uint_as_float(v.y);
+              o[q][d][4 * j + 2] += __uint_as_float(v.z); o[q][d][4 * j + 3] += __uint_as_float(v.w);
+            }
+        const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(wsr, other + 16384 + lane * 16, 0, 16);
+        ll[0] += __uint_as_float(lv.x); ll[1] += __uint_as_float(lv.y);
+      }
+    }
+  }
+  if (!finish) return;   // (workgroup-uniform)
   // ---- finalize: O[q][d] = o^T / l; lane^32 exchange -> 8 consecutive d per lane, 16-byte stores ----
   bool bad = false;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     float la, lb;
-    const float l_lane = q == 0 ? l00 + l01 : l10 + l11;
-    half_swap(l_lane, l_lane, la, lb);
+    half_swap(ll[q], ll[q], la, lb);
     const float l_tot = la + lb;
-    bad = bad || !(l_tot < a.redo_thr);   // 2^100 (or not finite): a score topped the first tile's maximum by about that much
+    bad = bad || !(l_tot < a.redo_thr);   // 2^100 (or not finite): a score topped the reference by about that much
     const float inv = 1.0f / l_tot;
     const int q_row = qb * 256 + wave * 64 + q * 32 + l31;
     bf16_t* orow = a.O + (long long)b * a.sO + (long long)q_row * a.ldo + h * 64;
@@ -184,7 +280,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *(uint4*)(orow + dt * 32 + 16 * gp + 8 * half) = pk;
       }
   }
-  // a workgroup whose reference was too low redoes its 256 queries with the running-maximum form (two blocks of 128)
+  // a block whose reference was too low redoes its 256 queries with the running-maximum form (two blocks of 128)
   __syncthreads();   // (no __syncthreads_or: its static LDS word would move the ring off LDS address 0)
   if (lane == 0) ((int*)smem)[wave] = __any(bad) ? 1 : 0;
   __syncthreads();
@@ -194,6 +290,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     fa25_body<4, true, 2>(a, smem, 2 * qb, bh);
     __syncthreads();
     fa25_body<4, true, 2>(a, smem, 2 * qb + 1, bh);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn64_4w_kernel(const FaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // the ring: LDS address 0 (the stream wraps addresses at 64 KB)
+  const int nkt = a.Ntok >> 6;
+  const int bid = (int)blockIdx.x;
+  // a whole block of 256 queries (bid < n_full), or a range of key tiles over the concatenated split blocks beyond them
+  const bool whole = bid < a.n_full;
+  const unsigned r = (unsigned)(bid - a.n_full), nwg = (unsigned)a.n_rem_wg, unkt = (unsigned)nkt;
+  const unsigned total = (unsigned)a.n_rem * unkt;
+  unsigned s0 = whole ? 0u : f4_bound(r, nwg, total, unkt);
+  const unsigned s1 = whole ? unkt : f4_bound(r + 1, nwg, total, unkt);
+  while (s0 < s1) {   // (one call site: the stream is ~1 300 instructions)
+    const unsigned rem = s0 / unkt, t0 = s0 - rem * unkt;
+    const unsigned t1 = (s1 - s0) < (unkt - t0) ? t0 + (s1 - s0) : unkt;
+    int part = -1, npieces = 1;
+    if (!(t0 == 0 && t1 == unkt)) {   // this block's pieces: the workgroups whose ranges meet [rem nkt, (rem + 1) nkt)
+      const unsigned b0 = rem * unkt, b1 = b0 + unkt;
+      unsigned rf = r, rl = r;
+      while (rf > 0 && f4_bound(rf, nwg, total, unkt) > b0) --rf;
+      while (rl + 1 < nwg && f4_bound(rl + 1, nwg, total, unkt) < b1) ++rl;
+      part = (int)(r - rf);
+      npieces = (int)(rl - rf + 1);
+    }
+    f4_segment(a, smem, whole ? xcd_remap(bid, a.n_full) : a.n_full + (int)rem, (int)t0, (int)t1, part, npieces, (int)rem);
+    s0 += t1 - t0;
   }
 }
 
@@ -207,19 +331,48 @@ bool mg_flash4w_ok(const FaArgs& a, bool vt_perm) {
          (long long)a.Ntok * a.ldq * 2 < (1ll << 31) && 64ll * a.ldvt * 2 < (1ll << 31);
 }
 
-int mg_launch_flash4w(const FaArgs& a, hipStream_t s) {
+int mg_launch_flash4w(const FaArgs& a_in, hipStream_t s) {
+  FaArgs a = a_in;
   MG_REQUIRE(mg_flash4w_ok(a, true), "flash_attn64 (hand-placed form): Ntok %d must be a multiple of 256, "
              "16-byte aligned operands", a.Ntok);
   const int LDS = F4_LDS;
   static bool attr_set = false;
+  static int n_cu = 256;
   if (!attr_set && !g_dry_run) {
     hipFuncAttributes fa;
     MG_CHECK_HIP(hipFuncGetAttributes(&fa, (const void*)flash_attn64_4w_kernel));
     MG_REQUIRE(fa.sharedSizeBytes == 0, "flash_attn64 (hand-placed form): the ring must start at LDS address 0 (static LDS %d bytes)", (int)fa.sharedSizeBytes);
     MG_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn64_4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
     attr_set = true;
   }
-  const long long grid = (long long)(a.Ntok / 256) * a.heads * a.B;
+  const int nkt = a.Ntok / 64;
+  const long long nb = (long long)(a.Ntok / 256) * a.heads * a.B;
+  MG_REQUIRE(nb < (1ll << 30), "flash_attn64: too many query blocks");
+  // whole blocks in multiples of the CU count (two workgroups share a CU: 3 1/2 blocks per slot end in a round that a few CUs
+  // run alone); the rest in key pieces of at least a third of a block over up to two workgroups per CU
+  a.n_full = (int)nb;
+  a.n_rem = 0;
+  a.n_rem_wg = 0;
+  static const int split = [] { const char* e = getenv("MARIGOLD_FLASH4W_SPLIT"); return e ? atoi(e) : 1; }();
+  // (measured, profiles/r4_flash4w.log: a piece costs ~15-20 us of prologue / partial result / combine on top of its key loop -
+  // splitting pays for a FEW left-over blocks behind many whole ones (1 800 = 7 x 256 + 8: 919 -> 863 us), not for a left-over of
+  // half a round (900 blocks at 2 304 tokens: 142 -> 154 us) or for a launch that does not fill the chip anyway)
+  if (split && a.ws && nb > n_cu && nb % n_cu != 0 && (nb % n_cu) * 8 <= n_cu) {
+    const long long rem = nb % n_cu;
+    const long long cap = (a.ws_bytes - F4_CTR_BYTES) / ((long long)F4_PIECES * F4_PART_BYTES);
+    long long wg = 2ll * n_cu;
+    if (wg > 3 * rem) wg = 3 * rem;                               // pieces of >= a third of a block: at most four per block
+    if (wg > (long long)rem * nkt / 4) wg = (long long)rem * nkt / 4;   // ... and of four tiles at least
+    if (rem <= cap && rem * 4 <= F4_CTR_BYTES && wg > rem && (wg + 1) * rem * nkt < (1ll << 31)) {
+      a.n_full = (int)(nb - rem);
+      a.n_rem = (int)rem;
+      a.n_rem_wg = (int)wg;
+    }
+  }
+  const long long grid = (long long)a.n_full + a.n_rem_wg;
   MG_LAUNCH(flash_attn64_4w_kernel, dim3((unsigned)grid), dim3(256), LDS, s, a);
   return 0;
 }

@@ -13,6 +13,9 @@ struct FaArgs {
   float scale_log2;
   unsigned long long* dbg;   // tuning only: per workgroup (shader cycles, 100 MHz ticks) of the whole kernel body
   float redo_thr;            // flash4w.hip: row sums at or above this send the workgroup to the running-maximum loop (2^100)
+  void* ws;                  // flash4w.hip: workspace of the key-split blocks (tickets + partial results), or null: no split
+  long long ws_bytes;
+  int n_full, n_rem, n_rem_wg;   // (set by mg_launch_flash4w) whole blocks, split blocks, workgroups over the split blocks
 };
 
 constexpr int FA_QB = 128;   // queries per workgroup (4 waves x 32)

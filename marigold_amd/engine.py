@@ -580,9 +580,10 @@ class Builder:
                              out2=vt, trans_from=2 * C, ldt=ldvt, trans_perm=perm), f"{prefix}.qkv")
             self.free(y)
         o = self.new(h.B, h.H, h.W, C)
+        ws = self.zeros_persistent(("flash_ws",), O.FLASH_WS_BYTES)   # key-split blocks of the hand-placed kernel (tickets stay 0)
         self.add(O.flash_attn64(qk, qk.data_ptr() + C * 2, vt, o.t, B=B, heads=heads, Ntok=T, ldq=2 * C,
                                 ldo=C, ldvt=ldvt, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C,
-                                scale=1.0 / math.sqrt(C // heads), vt_perm=perm), f"{prefix}.flash")
+                                scale=1.0 / math.sqrt(C // heads), vt_perm=perm, ws=ws, ws_bytes=O.FLASH_WS_BYTES), f"{prefix}.flash")
         self.free(qk)
         if rg and st_out is not None:
             self.add(O.rowgemm(o.t, self.ws.rg_mat(f"{prefix}.to_out.0"), h.t, M=M, K=C, N=C, residual=h.t,

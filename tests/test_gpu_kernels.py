@@ -1206,12 +1206,15 @@ def test_flash_attn64_running_max_paths(dev, case):
         _close(f"flash_attn64/{case}/v{variant}{'p' if perm else ''}", out, ref)
 
 
-@pytest.mark.parametrize("B,heads,T", [(1, 1, 256), (2, 2, 512), (1, 5, 1024), (1, 2, 2304), (2, 1, 768)])
+@pytest.mark.parametrize("B,heads,T", [(1, 1, 256), (2, 2, 512), (1, 5, 1024), (1, 2, 2304), (2, 1, 768), (13, 5, 1024), (3, 23, 1280)])
 @pytest.mark.parametrize("redo_thr", [0.0, 1e-30])
-def test_flash_attn64_hand_placed(dev, B, heads, T, redo_thr):
-    """Variant 26 (flash4w.hip: one wave per SIMD, 64 queries per wave, the key loop as one hand-placed instruction stream,
-    softmax against the first tile's row maximum) against fp32 SDPA on the host; ``redo_thr`` = 1e-30 sends every workgroup
-    through its running-maximum fallback as well."""
+@pytest.mark.parametrize("split", [False, True])
+def test_flash_attn64_hand_placed(dev, B, heads, T, redo_thr, split):
+    """Variant 26 (flash4w.hip: 64 queries per wave, the key loop as one hand-placed instruction stream, softmax against the
+    row maximum over the first 32 keys) against fp32 SDPA on the host; ``redo_thr`` = 1e-30 sends every workgroup through its
+    running-maximum fallback as well; ``split``: with the workspace, i.e. the blocks of queries beyond a multiple of the CU
+    count split along the keys (13 x 5 x 4 = 260 and 3 x 23 x 5 = 345 blocks: whole ones AND pieces in one launch; the small
+    shapes: pieces only) - twice, the tickets must be back at zero."""
     from marigold_amd import ops
     C = heads * 64
     g = torch.Generator().manual_seed(T + heads)
@@ -1221,10 +1224,15 @@ def test_flash_attn64_hand_placed(dev, B, heads, T, redo_thr):
     ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, T, C)
     qkd = qkv.to(dev, torch.bfloat16)
     vtp = ops.permute_vt_keys(v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16))
-    out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
-    _run(ops.flash_attn64(qkd, qkd[:, :, C:], vtp, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=T, sq=T * 3 * C,
-                          sk=T * 3 * C, svt=C * T, so=T * C, scale=0.125, variant=26, vt_perm=True, redo_thr=redo_thr))
-    _close(f"flash_attn64/hand-placed/B{B}h{heads}T{T}/thr{redo_thr}", out, ref)
+    ws = torch.zeros(ops.FLASH_WS_BYTES, dtype=torch.uint8, device=dev) if split else None
+    for rnd in range(2 if split else 1):
+        out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.flash_attn64(qkd, qkd[:, :, C:], vtp, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=T, sq=T * 3 * C,
+                              sk=T * 3 * C, svt=C * T, so=T * C, scale=0.125, variant=26, vt_perm=True, redo_thr=redo_thr,
+                              ws=ws, ws_bytes=ops.FLASH_WS_BYTES if split else 0))
+        _close(f"flash_attn64/hand-placed/B{B}h{heads}T{T}/thr{redo_thr}/split{int(split)}/{rnd}", out, ref)
+        if split:
+            assert int(ws[:4096].view(torch.int32).abs().sum()) == 0, "tickets not back at zero"
 
 
 @pytest.mark.parametrize("case", ["all_negative", "late_spike_2^40", "growing_2^90", "spike_past_2^100", "first_tile_spike"])
@@ -1265,10 +1273,12 @@ def test_flash_attn64_hand_placed_reference_paths(dev, case):
     assert torch.isfinite(ref).all()
     qkv = torch.cat([q, k], dim=-1).to(dev, torch.bfloat16)
     vtp = ops.permute_vt_keys(v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16))
-    out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
-    _run(ops.flash_attn64(qkv, qkv[:, :, C:], vtp, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T, sq=0, sk=0, svt=0, so=0,
-                          scale=0.125, variant=26, vt_perm=True))
-    _close(f"flash_attn64/hand-placed/{case}", out, ref)
+    for split in (False, True):
+        ws = torch.zeros(ops.FLASH_WS_BYTES, dtype=torch.uint8, device=dev) if split else None
+        out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
+        _run(ops.flash_attn64(qkv, qkv[:, :, C:], vtp, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T, sq=0, sk=0, svt=0, so=0,
+                              scale=0.125, variant=26, vt_perm=True, ws=ws, ws_bytes=ops.FLASH_WS_BYTES if split else 0))
+        _close(f"flash_attn64/hand-placed/{case}/split{int(split)}", out, ref)
 
 
 def _flash512_run(dev, q, k, v, B, T):

@@ -15,6 +15,7 @@ VARIANTS = tuple(int(v) for v in os.environ.get("FLASH_VARIANTS", "6,9,10").spli
 ROUNDS = int(os.environ.get("FLASH_ROUNDS", "5"))
 dev = torch.device("cuda:0")
 L.init(0)
+WS = torch.zeros(O.FLASH_WS_BYTES, dtype=torch.uint8, device=dev)
 
 
 def timeit(fn, warm=1, iters=4):
@@ -33,7 +34,7 @@ def timeit(fn, warm=1, iters=4):
 def case(B, heads, T, qscale=1.0):
     global VARIANTS
     all_variants = VARIANTS
-    VARIANTS = tuple(v for v in VARIANTS if v != 26 or (T % 256 == 0 and T >= 256))   # the hand-placed form's shapes
+    VARIANTS = tuple(v for v in VARIANTS if v not in (26, 27) or (T % 256 == 0 and T >= 256))   # the hand-placed form's shapes
     try:
         _case(B, heads, T, qscale)
     finally:
@@ -58,26 +59,34 @@ def _case(B, heads, T, qscale=1.0):
     outs, ops, times = {}, {}, {v: [] for v in VARIANTS}
     for v in VARIANTS:
         outs[v] = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
-        ops[v] = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25, 26)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
-                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(13 <= v <= 20 or v in (22, 23, 25, 26)))
+        vv = 26 if v == 27 else v     # 27 = variant 26 with the key-split workspace
+        ops[v] = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25, 26, 27)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
+                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=vv, vt_perm=(13 <= v <= 20 or v in (22, 23, 25, 26, 27)),
+                                ws=WS if v == 27 else None, ws_bytes=O.FLASH_WS_BYTES if v == 27 else 0)
     for rnd in range(ROUNDS):
         for v in VARIANTS:
             times[v].append(timeit(lambda: O.launch(ops[v])))
     line = f"flash B={B} heads={heads} T={T} qscale={qscale}:"
     if os.environ.get("FLASH_DBG"):   # generation 3 only: shader cycles / wall ticks per workgroup
         for v in VARIANTS:
-            if v == 26:   # the hand-placed form: cycles of the key loop per wave
-                nwg = (T // 256) * heads * B
+            if v in (26, 27):   # the hand-placed form: cycles of the key loop per wave (27: with the key-split workspace)
+                nwg = (T // 256) * heads * B + 1024
                 dbg = torch.zeros(nwg * 4 * 2, dtype=torch.int64, device=dev)
                 op = O.flash_attn64(qkd, qkd[:, :, C:], vtp, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt, sq=T * 3 * C,
-                                    sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=26, vt_perm=True, dbg=dbg)
+                                    sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=26, vt_perm=True, dbg=dbg,
+                                    ws=WS if v == 27 else None, ws_bytes=O.FLASH_WS_BYTES if v == 27 else 0)
                 O.launch(op)
                 O.launch(op)
                 torch.cuda.synchronize()
-                d = dbg.view(nwg, 4, 2).double().cpu()
-                cyc, tick = d[:, :, 0].flatten(), d[:, :, 1].flatten()
-                print(f"   v26: {nwg} workgroups; key loop {cyc.median():.0f} cycles per wave = {cyc.median() / (T // 64):.0f} per 64-key iteration "
-                      f"(32 MFMAs = 1024); min {cyc.min() / (T // 64):.0f} max {cyc.max() / (T // 64):.0f}; clock {float((cyc / tick).median()) * 100:.0f} MHz", flush=True)
+                d = dbg.view(nwg, 4, 2).cpu()
+                used = d[:, 0, 0] > 0
+                cyc = d[used][:, :, 0].double().flatten()
+                tick = (d[used][:, :, 1] & ((1 << 40) - 1)).double().flatten()
+                tiles = (d[used][:, :, 1] >> 40).double().flatten()
+                per = cyc / tiles
+                print(f"   v{v}: {int(used.sum())} workgroups; last segment {tiles.min():.0f}-{tiles.max():.0f} tiles; key loop {per.median():.0f} cycles per 64-key "
+                      f"iteration (32 MFMAs = 1024), min {per.min():.0f} max {per.max():.0f}; clock {float((cyc / tick).median()) * 100:.0f} MHz; "
+                      f"loop time per workgroup median {float((tick / 100).median()):.1f} us max {float((tick / 100).max()):.1f} us", flush=True)
                 continue
             if v < 9:
                 continue
