@@ -895,6 +895,7 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       a.redo_thr = op->f[1] > 0.f ? op->f[1] : 1.2676506e30f;   // 2^100 (tests force the fallback with a tiny value)
       a.ws = op->p[5];                                            // variant 26: workspace of the key-split blocks (i[8] KB)
       a.ws_bytes = (long long)op->i[8] * 1024;
+      a.split = op->i[9];
       a.n_full = a.n_rem = a.n_rem_wg = 0;
       MG_REQUIRE(!a.ws || ((uintptr_t)a.ws % 16 == 0 && a.ws_bytes > 0), "flash_attn64: workspace must be 16-byte aligned, its size (KB) in i[8]");
       a.nqb = (a.Ntok + FA_QB - 1) / FA_QB;

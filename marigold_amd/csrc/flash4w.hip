@@ -237,8 +237,17 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
     finish = *flag != 0;
     __syncthreads();
     if (finish) {
+      // the sum in the order of the pieces whichever arrived last - its own slab is read back like the others - so that the
+      // launch is bit-reproducible (fp32 addition is not associative)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        ll[q] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[q][d][r] = 0.f;
+      }
       for (int pp = 0; pp < npieces; ++pp) {
-        if (pp == part) continue;
         const unsigned other = (unsigned)(((long long)rem * F4_PIECES + pp) * F4_PART_BYTES + wave * (16384 + 1024));
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -360,7 +369,8 @@ int mg_launch_flash4w(const FaArgs& a_in, hipStream_t s) {
   // (measured, profiles/r4_flash4w.log: a piece costs ~15-20 us of prologue / partial result / combine on top of its key loop -
   // splitting pays for a FEW left-over blocks behind many whole ones (1 800 = 7 x 256 + 8: 919 -> 863 us), not for a left-over of
   // half a round (900 blocks at 2 304 tokens: 142 -> 154 us) or for a launch that does not fill the chip anyway)
-  if (split && a.ws && nb > n_cu && nb % n_cu != 0 && (nb % n_cu) * 8 <= n_cu) {
+  // (FaArgs::split: 0 = that rule, 1 = split whatever is left over - the tests, 2 = never)
+  if (split && a.split != 2 && a.ws && nb % n_cu != 0 && (a.split == 1 || (nb > n_cu && (nb % n_cu) * 8 <= n_cu))) {
     const long long rem = nb % n_cu;
     const long long cap = (a.ws_bytes - F4_CTR_BYTES) / ((long long)F4_PIECES * F4_PART_BYTES);
     long long wg = 2ll * n_cu;

@@ -15,6 +15,7 @@ struct FaArgs {
   float redo_thr;            // flash4w.hip: row sums at or above this send the workgroup to the running-maximum loop (2^100)
   void* ws;                  // flash4w.hip: workspace of the key-split blocks (tickets + partial results), or null: no split
   long long ws_bytes;
+  int split;                 // 0: split the left-over blocks when it pays, 1: always (tests), 2: never
   int n_full, n_rem, n_rem_wg;   // (set by mg_launch_flash4w) whole blocks, split blocks, workgroups over the split blocks
 };
 

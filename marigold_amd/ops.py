@@ -108,14 +108,14 @@ FLASH_WS_BYTES = 4096 + 255 * 4 * 4 * (16384 + 1024)   # tickets + four partial 
 
 
 def flash_attn64(q, k, vt, o, *, B, heads, Ntok, ldq, ldo, ldvt, sq, sk, svt, so, scale, variant=0, vt_perm=False, dbg=None,
-                 redo_thr=0.0, ws=None, ws_bytes=0):
+                 redo_thr=0.0, ws=None, ws_bytes=0, split=0):
     """``vt_perm``: V^T holds its keys in the order [0-3, 8-11, 4-7, 12-15] inside every group of 16 (what MG_OP_IGEMM's
     transposed section writes with ``trans_perm``) - generation 3 consumes that order without a lane exchange.
     ``redo_thr`` (tests only; 0 = 2^100): the row-sum bound above which the hand-placed kernel (variant 26) redoes a block of
     queries with the running-maximum loop.  ``ws`` (optional, ZEROED once, then owned by the launches of one stream): workspace of
     the hand-placed kernel's key-split blocks - the blocks of 256 queries beyond the last multiple of the CU count are split
-    along the keys over the chip (``FLASH_WS_BYTES`` covers every case)."""
-    return make_op(L.OP_FLASH_ATTN64, i=[B, heads, Ntok, ldq, ldo, ldvt, variant, int(vt_perm), ws_bytes // 1024], f=[scale, redo_thr],
+    along the keys over the chip (``FLASH_WS_BYTES`` covers every case); ``split``: 0 = when it pays, 1 = always (tests), 2 = never."""
+    return make_op(L.OP_FLASH_ATTN64, i=[B, heads, Ntok, ldq, ldo, ldvt, variant, int(vt_perm), ws_bytes // 1024, split], f=[scale, redo_thr],
                    p=[q, k, vt, o, dbg, ws], l=[sq, sk, svt, so])
 
 

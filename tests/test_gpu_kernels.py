@@ -1225,14 +1225,18 @@ def test_flash_attn64_hand_placed(dev, B, heads, T, redo_thr, split):
     qkd = qkv.to(dev, torch.bfloat16)
     vtp = ops.permute_vt_keys(v.permute(0, 2, 1).contiguous().to(dev, torch.bfloat16))
     ws = torch.zeros(ops.FLASH_WS_BYTES, dtype=torch.uint8, device=dev) if split else None
-    for rnd in range(2 if split else 1):
+    first = None
+    for rnd in range(3 if split else 1):
         out = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.flash_attn64(qkd, qkd[:, :, C:], vtp, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=T, sq=T * 3 * C,
                               sk=T * 3 * C, svt=C * T, so=T * C, scale=0.125, variant=26, vt_perm=True, redo_thr=redo_thr,
-                              ws=ws, ws_bytes=ops.FLASH_WS_BYTES if split else 0))
+                              ws=ws, ws_bytes=ops.FLASH_WS_BYTES if split else 0, split=1 if split else 2))
         _close(f"flash_attn64/hand-placed/B{B}h{heads}T{T}/thr{redo_thr}/split{int(split)}/{rnd}", out, ref)
         if split:
             assert int(ws[:4096].view(torch.int32).abs().sum()) == 0, "tickets not back at zero"
+            if first is None:
+                first = out.clone()
+            assert torch.equal(first, out), "key-split launches must be bit-identical (the pieces are summed in a fixed order)"
 
 
 @pytest.mark.parametrize("case", ["all_negative", "late_spike_2^40", "growing_2^90", "spike_past_2^100", "first_tile_spike"])
@@ -1277,7 +1281,7 @@ def test_flash_attn64_hand_placed_reference_paths(dev, case):
         ws = torch.zeros(ops.FLASH_WS_BYTES, dtype=torch.uint8, device=dev) if split else None
         out = torch.full((1, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.flash_attn64(qkv, qkv[:, :, C:], vtp, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T, sq=0, sk=0, svt=0, so=0,
-                              scale=0.125, variant=26, vt_perm=True, ws=ws, ws_bytes=ops.FLASH_WS_BYTES if split else 0))
+                              scale=0.125, variant=26, vt_perm=True, ws=ws, ws_bytes=ops.FLASH_WS_BYTES if split else 0, split=1 if split else 2))
         _close(f"flash_attn64/hand-placed/{case}/split{int(split)}", out, ref)
 
 
