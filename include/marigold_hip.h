@@ -113,7 +113,13 @@ enum mg_op_kind {
    *  kernel, 1 = generation-1 kernel kept for A/B runs), i[7] 1 = Vt's keys are in the order [0-3, 8-11, 4-7, 12-15]
    *  inside every group of 16 (as written by MG_OP_IGEMM i[26]; Ntok % 16 == 0) ; p[4] tuning only: cycle stamps | NULL ;
    *  l[0] q batch stride l[1] k batch stride l[2] vt batch stride l[3] o batch stride;
-   *  f[0] softmax scale */
+   *  f[0] softmax scale.
+   *  With i[7] = 1 and Ntok % 256 == 0 (>= 256) the current kernel is the hand-placed one (flash4w.hip; variant 26 forces
+   *  it): softmax against a fixed per-query reference, exact, with an in-kernel running-maximum fallback for rows whose sums
+   *  reach f[1] (0 = 2^100; tests force the fallback with a tiny value).  Optional p[5]: workspace (16-byte aligned, i[8] KB,
+   *  ZEROED once by the caller, then owned by this op's launches on ONE stream - tickets return to zero): the blocks of 256
+   *  queries left over beyond a multiple of the CU count are then split along the keys over the chip (bit-reproducible);
+   *  4 KB + 69 632 bytes x 4 x (blocks % CUs) suffice; i[9]: 0 = split when it pays, 1 = always, 2 = never. */
   MG_OP_FLASH_ATTN64 = 6,
   /* Self-attention core of ONE head of width 512 (the mid-block attention of AutoencoderKL: diffusers Attention in
    * UNetMidBlock2D, marigold_depth_pipeline.py:491-492, 512-513), flash form: the scores stay in registers.

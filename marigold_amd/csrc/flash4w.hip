@@ -98,6 +98,8 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
   const unsigned kst = f4_sgpr((unsigned)(64 * a.ldq * 2));   // one key tile of K rows, bytes
   const unsigned mw = f4_sgpr((unsigned)(wave * 1024));
   const unsigned k0 = f4_sgpr((unsigned)t0 * kst), v0 = f4_sgpr((unsigned)t0 * 128u);
+  unsigned long long* dbgw = a.dbg ? a.dbg + ((long long)blockIdx.x * 4 + wave) * 8 : nullptr;   // tuning only: phase time stamps
+  if (dbgw && lane == 0) dbgw[2] = __builtin_amdgcn_s_memrealtime();
   __builtin_amdgcn_s_barrier();   // (a previous segment's / the fallback's readers are done with the ring)
   // K rows 0 ... 31 (the reference) and 64 t0 ... + 31 (the stream's first scores), then slots 0, 1, 2
   f4_dma(vk[0], srk, 0u, f4_sgpr(mw + F4_PRE));
@@ -127,8 +129,10 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
       }
     }
   }
+  if (dbgw && lane == 0) dbgw[3] = __builtin_amdgcn_s_memrealtime();
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (dbgw && lane == 0) dbgw[4] = __builtin_amdgcn_s_memrealtime();
   // S^T = K Q^T (lane = query, registers = keys): the reference = the row maximum over the sequence's first 32 keys
   const int sw = (l31 >> 1) & 7;
   unsigned ad[4];
@@ -194,8 +198,10 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
   if (a.dbg) {   // tuning only: shader cycles / 100 MHz ticks (+ tiles << 40) of the key loop, per wave of the workgroup's last segment
     const unsigned long long tm1 = __builtin_amdgcn_s_memtime(), rm1 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
-      a.dbg[((long long)blockIdx.x * 4 + wave) * 2] = tm1 - tm0;
-      a.dbg[((long long)blockIdx.x * 4 + wave) * 2 + 1] = (rm1 - rm0) | ((unsigned long long)(t1 - t0) << 40);
+      dbgw[0] = tm1 - tm0;
+      dbgw[1] = (rm1 - rm0) | ((unsigned long long)(t1 - t0) << 40);
+      dbgw[5] = rm0;
+      dbgw[6] = rm1;
     }
   }
   float ll[2] = {l00 + l01, l10 + l11};   // the lane's share of its queries' row sums (the other half-wave holds the rest)
@@ -289,6 +295,7 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
         *(uint4*)(orow + dt * 32 + 16 * gp + 8 * half) = pk;
       }
   }
+  if (dbgw && lane == 0) dbgw[7] = __builtin_amdgcn_s_memrealtime();
   // a block whose reference was too low redoes its 256 queries with the running-maximum form (two blocks of 128)
   __syncthreads();   // (no __syncthreads_or: its static LDS word would move the ring off LDS address 0)
   if (lane == 0) ((int*)smem)[wave] = __any(bad) ? 1 : 0;

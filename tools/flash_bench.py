@@ -71,15 +71,20 @@ def _case(B, heads, T, qscale=1.0):
         for v in VARIANTS:
             if v in (26, 27):   # the hand-placed form: cycles of the key loop per wave (27: with the key-split workspace)
                 nwg = (T // 256) * heads * B + 1024
-                dbg = torch.zeros(nwg * 4 * 2, dtype=torch.int64, device=dev)
+                dbg = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device=dev)
                 op = O.flash_attn64(qkd, qkd[:, :, C:], vtp, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt, sq=T * 3 * C,
                                     sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=26, vt_perm=True, dbg=dbg,
                                     ws=WS if v == 27 else None, ws_bytes=O.FLASH_WS_BYTES if v == 27 else 0)
                 O.launch(op)
                 O.launch(op)
                 torch.cuda.synchronize()
-                d = dbg.view(nwg, 4, 2).cpu()
+                d = dbg.view(nwg, 4, 8).cpu()
                 used = d[:, 0, 0] > 0
+                st = d[used][:, 0, 2:8].double() / 100.0      # us: entry, DMA + Q issued, first data landed, stream in, stream out, stored
+                ph = st[:, 1:] - st[:, :-1]
+                print(f"   v{v} phases (us, median over workgroups): issue DMA + queries {ph[:, 0].median():.2f}, wait first data {ph[:, 1].median():.2f}, "
+                      f"first scores / reference {ph[:, 2].median():.2f}, stream {ph[:, 3].median():.2f}, store {ph[:, 4].median():.2f}; "
+                      f"kernel span (first entry -> last store) {float(st[:, 5].max() - st[:, 0].min()):.1f} us", flush=True)
                 cyc = d[used][:, :, 0].double().flatten()
                 tick = (d[used][:, :, 1] & ((1 << 40) - 1)).double().flatten()
                 tiles = (d[used][:, :, 1] >> 40).double().flatten()
