@@ -178,7 +178,10 @@ enum mg_op_kind {
    *       output; zero padding stays zero)
    *  i[0] B  i[1] H  i[2] W  i[3] C0  i[4] C1  i[5] N  i[6] sub-pixel 2x mode  i[7] silu  i[8] lda0  i[9] lda1
    *  i[10] ldo  i[11] ldr  i[12] ldw  i[13] rowvec broadcast  i[14] tile variant (0 = auto)
-   *  l[0] parity stride of Wt in elements (sub-pixel mode) */
+   *  l[0] parity stride of Wt in elements (sub-pixel mode)
+   *  p[8] (optional) f32 [B][i[16]][N / i[15]][2]: (sum, sum of squares) of every group of i[15] (4 | 8 | 16 | 32) output
+   *  channels over each tile's pixels, of the values as stored - the partial table MG_OP_GN_FINALIZE reduces (slots = i[16] =
+   *  mg_conv3x3_gn_slots(op), HW = H W or 4 H W): the next GroupNorm's statistics without a pass over the tensor. */
   MG_OP_CONV3X3 = 17,
   /* Test-time ensembling (marigold/util/ensemble.py).
    * DEPTH_STATS : one pass over [E][HW]: per-member min,max,mean and the centred E x E
@@ -264,6 +267,9 @@ void mg_program_destroy(mg_program* prog);
 /* Named wrappers - what a binding for the reference's seams would call directly. */
 int mg_conv2d_igemm(const mg_op* conv_desc, void* stream);   /* kind must be MG_OP_IGEMM */
 int mg_conv3x3(const mg_op* conv_desc, void* stream);        /* kind must be MG_OP_CONV3X3 (ResnetBlock2D norm+silu+conv) */
+/* Slots per image of the partial table this MG_OP_CONV3X3 can fill with the GroupNorm statistics of its OUTPUT (p[8], see the
+ * op), or 0 when the tile variant it runs on does not produce them (then leave p[8] NULL and use MG_OP_GN_STATS). */
+int mg_conv3x3_gn_slots(const mg_op* conv_desc);
 int mg_sched_step(const float* x, const float* model_out, const float* noise, float* out,
                   int64_t n, float cx, float cm, float cn, void* stream);
 int mg_ensemble_normals(const float* normals, float* out, float* unc, int E, int64_t hw,

@@ -167,6 +167,7 @@ void mg_set_error(const char* fmt, ...);
 int mg_launch_igemm(const mg_op* op, hipStream_t s);
 int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant);  // -1: shape outside the kernel's contract
 int mg_launch_conv_patch(const mg_op* op, hipStream_t s);
+int mg_conv3x3_gn_slots_of(const mg_op* op);
 int mg_launch_rowgemm(const mg_op* op, hipStream_t s);
 int mg_launch_norm(const mg_op* op, hipStream_t s);
 int mg_launch_attention(const mg_op* op, hipStream_t s);

@@ -38,7 +38,11 @@ __device__ __forceinline__ void cp_wait_vmcnt() {
 }
 
 // TH x TW output pixels x BN output channels per workgroup; WGM x WGN waves (wave tile TM x TN); NSTB weight stages.
-template <int TH, int TW, int BN, int WGM, int WGN, int NSTB, bool FIX>
+// GNS: the epilogue also leaves the tile's GroupNorm partial sums of the output (ConvPArgs::gn_part) - what MG_OP_GN_STATS would
+// compute by re-reading the tensor (4.6 ms per VAE decode at E = 10, HBM-bound); on the 12-wave tiles the extra VALU hides
+// under the other waves' MFMAs.  Per wave: sums over its pixels in registers, a 32-lane butterfly, one LDS row per wave; the
+// waves' rows are added in wave order (bit-reproducible) and the tile's groups written as one table slot.
+template <int TH, int TW, int BN, int WGM, int WGN, int NSTB, bool FIX, bool GNS = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void conv_patch_kernel(const ConvPArgs a) {
   constexpr int NW = WGM * WGN, NT = NW * 64;
   constexpr int BM = TH * TW, TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
@@ -311,6 +315,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_patch_kernel(const ConvPAr
   }
 
   // ---------------- epilogue (the non-transposed epilogue of igemm2.hip with the tile's pixel map) ----------------
+  float gsum[GNS ? NI : 1][2][2], gsq[GNS ? NI : 1][2][2];   // [ni][gp][k]: this lane's pixels, channels 4 k ... of its 8-channel vector
+  if constexpr (GNS) {                                        // (k = 1 only with 4-channel groups)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) gsum[ni][gp][0] = gsum[ni][gp][1] = gsq[ni][gp][0] = gsq[ni][gp][1] = 0.f;
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int p = wm * TM + mi * 32 + l31;
@@ -348,8 +359,53 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_patch_kernel(const ConvPAr
           pk.x = cvt_pk_bf16_f32(v[0], v[1]); pk.y = cvt_pk_bf16_f32(v[2], v[3]);
           pk.z = cvt_pk_bf16_f32(v[4], v[5]); pk.w = cvt_pk_bf16_f32(v[6], v[7]);
           *(uint4*)(a.out + orow * a.ldo + n) = pk;
+          if constexpr (GNS) {   // of the values as stored (bf16): what a statistics pass over the tensor would see
+            const float w[8] = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y), bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+            gsum[ni][gp][0] += (w[0] + w[1]) + (w[2] + w[3]);
+            gsq[ni][gp][0] += (w[0] * w[0] + w[1] * w[1]) + (w[2] * w[2] + w[3] * w[3]);
+            gsum[ni][gp][1] += (w[4] + w[5]) + (w[6] + w[7]);
+            gsq[ni][gp][1] += (w[4] * w[4] + w[5] * w[5]) + (w[6] * w[6] + w[7] * w[7]);
+          }
         }
       }
+    }
+  }
+  if constexpr (GNS) {
+    // the wave's rows: [ni][gp][half][k] (sum, sum of squares) - 8-channel vector c8 = wn TN + 32 ni + 16 gp + 8 half of the tile
+    float* const gl = (float*)smem;                       // [NW][TN / 4][2]; the ring is free behind this barrier
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          float s_ = gsum[ni][gp][k], q_ = gsq[ni][gp][k];
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) { s_ += __shfl_xor(s_, o); q_ += __shfl_xor(q_, o); }   // over the 32 pixels of a half-wave
+          if (l31 == 0) {
+            float* d = gl + ((wave * (TN / 4) + (ni * 8 + gp * 4 + half * 2 + k)) << 1);
+            d[0] = s_;
+            d[1] = q_;
+          }
+        }
+    __syncthreads();
+    // group g of the tile's BN / cpg: its 4-channel quarters q4 = g cpg / 4 ... of column wave wn, over the WGM pixel waves
+    const int cpg = a.gn_cpg, ngt = BN / cpg, gtot = a.N / cpg;
+    const int slot = (z * a.tiles_y + ty) * a.tiles_x + tx;
+    for (int g = tid; g < ngt; g += NT) {
+      float s_ = 0.f, q_ = 0.f;
+      for (int q4 = g * cpg / 4; q4 < (g + 1) * cpg / 4; ++q4) {
+        const int wn_ = q4 / (TN / 4), qq = q4 % (TN / 4);
+        for (int wm_ = 0; wm_ < WGM; ++wm_) {
+          const float* d = gl + (((wm_ * WGN + wn_) * (TN / 4) + qq) << 1);
+          s_ += d[0];
+          q_ += d[1];
+        }
+      }
+      float* out = a.gn_part + ((((long long)img * a.gn_slots + slot) * gtot + tile_n * ngt + g) << 1);
+      out[0] = s_;
+      out[1] = q_;
     }
   }
 }
@@ -368,10 +424,23 @@ int launch_patch(const ConvPArgs& a0, hipStream_t s) {
   MG_REQUIRE(grid > 0 && grid < (1ll << 31), "conv3x3: bad grid %lld", grid);
   void (*kern)(const ConvPArgs) = a.ss ? conv_patch_kernel<TH, TW, BN, WGM, WGN, NSTB, true>
                                        : conv_patch_kernel<TH, TW, BN, WGM, WGN, NSTB, false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[a.ss ? 1 : 0] && !g_dry_run) {
+  int ki = a.ss ? 1 : 0;
+  if constexpr (WGM * WGN == 12 && BN != 320) {   // the output's GroupNorm statistics as a by-product: the VAE's 12-wave tiles
+    if (a.gn_part) {
+      kern = a.ss ? conv_patch_kernel<TH, TW, BN, WGM, WGN, NSTB, true, true> : conv_patch_kernel<TH, TW, BN, WGM, WGN, NSTB, false, true>;
+      ki += 2;
+      MG_REQUIRE((a.gn_cpg == 4 || a.gn_cpg == 8 || a.gn_cpg == 16 || a.gn_cpg == 32) && a.N % a.gn_cpg == 0 && a.N % BN == 0 &&
+                 a.gn_slots == a.tiles_x * a.tiles_y * (a.subpix ? 4 : 1),
+                 "conv3x3: output statistics need 4 / 8 / 16 / 32 channels per group, N %% %d == 0 and %d table slots (got %d)", BN,
+                 a.tiles_x * a.tiles_y * (a.subpix ? 4 : 1), a.gn_slots);
+    }
+  } else {
+    MG_REQUIRE(!a.gn_part, "conv3x3: this tile variant does not produce output statistics (mg_conv3x3_gn_slots() tells)");
+  }
+  static bool attr_set[4] = {false, false, false, false};
+  if (!attr_set[ki] && !g_dry_run) {
     MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set[a.ss ? 1 : 0] = true;
+    attr_set[ki] = true;
   }
   MG_LAUNCH(kern, dim3((unsigned)grid), dim3(NT), LDS, s, a);
   if (!g_dry_run) MG_CHECK_HIP(hipGetLastError());
@@ -416,6 +485,28 @@ int mg_conv3x3_auto_variant(int N, int subpix, int B, int H, int W, int has_ss, 
   return 4;
 }
 
+// the tile variant MG_OP_CONV3X3 `op` runs on (i[14], or the automatic choice)
+static int mg_conv3x3_variant_of(const mg_op* op) {
+  const int C0 = op->i[3], C1 = op->i[4], N = op->i[5], subpix = op->i[6], silu = op->i[7];
+  const int lda0 = op->i[8] > 0 ? op->i[8] : C0, lda1 = op->i[9] > 0 ? op->i[9] : C1;
+  const bool ss = op->p[7] != nullptr;
+  // (the four-wave kernels: SiLU with the fused norm, 31-bit byte offsets into the operands)
+  const int allow4w = (!ss || silu) && (long long)op->i[0] * op->i[1] * op->i[2] * (lda0 > lda1 ? lda0 : lda1) < (1ll << 30) &&
+                      (long long)N * (op->i[12] > 0 ? op->i[12] : (subpix ? 4 : 9) * (C0 + C1)) < (1ll << 30);
+  int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(N, subpix, op->i[0], op->i[1], op->i[2], ss, C0 + C1, allow4w);
+  if (!op->i[14] && variant == 6 && ss && C0 + C1 > 1024) variant = 3;   // (variant 6 keeps the fused norm's [2][Cin] vectors in 8 KB of LDS)
+  return variant;
+}
+
+// Table slots per image of the output-statistics by-product (p[8]) for this op - 0: its tile variant does not produce them.
+int mg_conv3x3_gn_slots_of(const mg_op* op) {
+  const int variant = mg_conv3x3_variant_of(op);
+  const int H = op->i[1], W = op->i[2], N = op->i[5], par = op->i[6] ? 4 : 1;
+  if (variant == 8 && N % 128 == 0) return ((H + 23) / 24) * ((W + 15) / 16) * par;
+  if (variant == 9 && N % 256 == 0) return ((H + 11) / 12) * ((W + 15) / 16) * par;
+  return 0;
+}
+
 int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
   ConvPArgs a;
   a.A0 = (const bf16_t*)op->p[0];
@@ -426,6 +517,9 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
   a.res = (const bf16_t*)op->p[5];
   a.A1 = (const bf16_t*)op->p[6];
   a.ss = (const float*)op->p[7];
+  a.gn_part = (float*)op->p[8];
+  a.gn_cpg = op->i[15];
+  a.gn_slots = op->i[16];
   a.zero = g_zero_page;
   a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C0 = op->i[3];
   const int C1 = op->i[4];
@@ -441,11 +535,7 @@ int mg_launch_conv_patch(const mg_op* op, hipStream_t s) {
   a.tw = a.subpix ? 2 : 3;
   a.ldw = op->i[12] > 0 ? op->i[12] : a.T * a.Cin;
   a.rv_stride = op->i[13] ? 0 : a.N;
-  // (the four-wave kernels: SiLU with the fused norm, 31-bit byte offsets into the operands)
-  const int allow4w = (!a.ss || a.silu) && (long long)a.B * a.H * a.W * (a.lda0 > a.lda1 ? a.lda0 : a.lda1) < (1ll << 30) &&
-                      (long long)a.N * (op->i[12] > 0 ? op->i[12] : (a.subpix ? 4 : 9) * (a.C0 + C1)) < (1ll << 30);
-  int variant = op->i[14] ? op->i[14] : mg_conv3x3_auto_variant(a.N, a.subpix, a.B, a.H, a.W, a.ss != nullptr, a.C0 + C1, allow4w);
-  if (!op->i[14] && variant == 6 && a.ss && a.C0 + C1 > 1024) variant = 3;   // (variant 6 keeps the fused norm's [2][Cin] vectors in 8 KB of LDS)
+  const int variant = mg_conv3x3_variant_of(op);
   a.sW = op->l[0];
   a.chunks = a.Cin / 64;
   a.c0t = a.C0 / 64;

@@ -209,6 +209,11 @@ int mg_conv2d_igemm(const mg_op* conv_desc, void* stream) {
   return mg_launch_igemm(conv_desc, (hipStream_t)stream);
 }
 
+int mg_conv3x3_gn_slots(const mg_op* conv_desc) {
+  if (!conv_desc || conv_desc->kind != MG_OP_CONV3X3) return 0;
+  return mg_conv3x3_gn_slots_of(conv_desc);
+}
+
 int mg_conv3x3(const mg_op* conv_desc, void* stream) {
   MG_REQUIRE(conv_desc && conv_desc->kind == MG_OP_CONV3X3, "mg_conv3x3: op kind must be MG_OP_CONV3X3");
   return mg_launch_conv_patch(conv_desc, (hipStream_t)stream);

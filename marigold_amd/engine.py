@@ -27,6 +27,8 @@ FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"
 XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)
 VAE_ATTN_CHUNK_BYTES = int(os.environ.get("MARIGOLD_VAE_ATTN_CHUNK_MB", "0")) << 20   # fp32 scores per launch group; 0 = one batched launch per stage
 # (query chunks whose scores fit the 256 MB Infinity Cache measured no gain: vae.decode 62.1 vs 62.9 ms, profiles/r4_vae_attention_chunks.log)
+GN_BYPRODUCT = os.environ.get("MARIGOLD_GN_BYPRODUCT", "1") != "0"   # GroupNorm partial sums from the producing convolution's epilogue
+UNFUSE_320 = int(os.environ.get("MARIGOLD_UNFUSE_320", "0"))   # > 0: minimum Cin from which the 320-channel level's GroupNorm is NOT fused into its convolution
 VAE_FLASH = os.environ.get("MARIGOLD_VAE_FLASH", "1") != "0"          # VAE mid-block attention as a flash kernel (off: materialised scores)
 IGEMM73_CONV = os.environ.get("MARIGOLD_IGEMM73_CONV", "1") != "0"   # plain N = 320 k convolutions on the hand-placed 192 x 320 GEMM tile
 IGEMM72_VAE = os.environ.get("MARIGOLD_IGEMM72_VAE", "1") != "0"    # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
@@ -40,10 +42,11 @@ ROWGEMM_MIN_M = int(os.environ.get("MARIGOLD_ROWGEMM_MIN_M", "9216"))   # below:
 
 class Act:
     """A bf16 NHWC activation [B][H][W][C] living in a pooled buffer."""
-    __slots__ = ("t", "B", "H", "W", "C")
+    __slots__ = ("t", "B", "H", "W", "C", "gn")
 
     def __init__(self, t, B, H, W, C):
         self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
+        self.gn = None   # (partial table, slots per image): its GroupNorm partial sums, left by the convolution that wrote it
 
     @property
     def M(self):
@@ -253,6 +256,9 @@ class Builder:
         for x in xs:
             if x is None:
                 continue
+            if isinstance(x, Act) and x.gn is not None:
+                self.pool.put(x.gn[0])
+                x.gn = None
             self.pool.put(x.t if isinstance(x, Act) else x)
 
     def zeros_persistent(self, key, nbytes):
@@ -344,6 +350,12 @@ class Builder:
             return self.gn_slab(srcs, name, eps, False, False)[0]
         B, HW = srcs[0].B, srcs[0].HW
         C = sum(x.C for x in srcs)
+        if len(srcs) == 1 and srcs[0].gn is not None:   # the producing convolution left the partial sums: no pass over the tensor
+            part, slots = srcs[0].gn
+            ss = self.raw(B * 2 * C * 4)
+            self.add(O.gn_finalize(part, self.ws.vec(f"{name}.weight"), self.ws.vec(f"{name}.bias"), ss, B=B, C=C,
+                                   groups=self.groups, slots=slots, HW=HW, eps=eps), f"{name}.finalize")
+            return ss
         # ~288 (chunk, image) blocks - about one per CU - of >= 32 rows: with eight row loads in flight per thread and the
         # chunk's tail fetched as one batch (round 3) a block streams its rows in 2-4 round trips, and the cost that is left
         # grows with the NUMBER of blocks (tickets, the last block's table reduction): 59 MB at E = 10 takes 16.3 us with 24-32
@@ -412,6 +424,8 @@ class Builder:
         mode = FUSE_GN
         if mode != "auto":
             return mode == "all"
+        if UNFUSE_320 and N == 320 and Cin >= UNFUSE_320 and IGEMM73_CONV:
+            return False   # (A/B, round 4) the UNet's 320-channel level: one apply pass + the plain convolution on the 192 x 320 GEMM tile
         tiles_n = 1 if N in (128, 256, 320) else -(-N // (256 if N % 256 == 0 else 128))
         return tiles_n == 1 or B * H * W * Cin * 2 >= (192 << 20)
 
@@ -423,10 +437,20 @@ class Builder:
             out = self.new(x.B, H, W, cout)
         Cin = x.C + (skip.C if skip else 0)
         w = self.ws.conv3x3_subpix(name) if subpix else self.ws.conv3x3(name)
-        self.add(O.conv3x3(x.t, w, out.t, B=x.B, H=x.H, W=x.W, C0=x.C, N=cout, a1=skip.t if skip else None,
-                           C1=skip.C if skip else 0, subpix=subpix, ss=ss, silu=silu, bias=self.ws.bias(name),
-                           rowvec=rowvec, rowvec_bcast=rowvec is not None,
-                           residual=None if residual is None else residual.t, wz=cout * 4 * Cin if subpix else 0), name)
+        kw = dict(B=x.B, H=x.H, W=x.W, C0=x.C, N=cout, a1=skip.t if skip else None, C1=skip.C if skip else 0, subpix=subpix, ss=ss,
+                  silu=silu, bias=self.ws.bias(name), rowvec=rowvec, rowvec_bcast=rowvec is not None,
+                  residual=None if residual is None else residual.t, wz=cout * 4 * Cin if subpix else 0)
+        op = O.conv3x3(x.t, w, out.t, **kw)
+        # (round 4) the GroupNorm statistics of the output as a by-product of the 12-wave tiles' epilogue - the tensors of the
+        # VAE's 768^2 / 384^2 levels are re-read at HBM speed otherwise (4.6 ms of statistics passes per decode at E = 10)
+        cpg = cout // self.groups
+        if GN_BYPRODUCT and out.gn is None and cout % self.groups == 0 and cpg in (4, 8, 16, 32) and out.HW * cout * 2 >= (8 << 20):
+            slots = O.conv3x3_gn_slots(op)
+            if slots > 0:
+                part = self.raw(x.B * slots * self.groups * 2 * 4)
+                op = O.conv3x3(x.t, w, out.t, gn_part=part, gn_cpg=cpg, gn_slots=slots, **kw)
+                out.gn = (part, slots)
+        self.add(op, name)
         return out
 
     def conv3x3(self, x, name, cout, *, stride=1, pad=1, up=None, rowvec=None, residual=None, out=None):

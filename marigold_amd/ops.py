@@ -60,12 +60,19 @@ def igemm(a, w, out, *, B, H, W, Cin, Ho, Wo, N, taps=1, stride=1, pad=0, up=Non
 
 
 def conv3x3(a0, w, out, *, B, H, W, C0, N, a1=None, C1=0, subpix=False, ss=None, silu=False, bias=None, rowvec=None,
-            residual=None, lda0=0, lda1=0, ldo=0, ldr=0, ldw=0, rowvec_bcast=False, variant=0, wz=0):
+            residual=None, lda0=0, lda1=0, ldo=0, ldr=0, ldw=0, rowvec_bcast=False, variant=0, wz=0, gn_part=None, gn_cpg=0,
+            gn_slots=0):
     """Patch-resident conv3x3 / pad 1 (MG_OP_CONV3X3): fused GroupNorm scale/shift (+SiLU) on the input, second
-    channel source, sub-pixel 2x up-sampling."""
+    channel source, sub-pixel 2x up-sampling; ``gn_part``: the output's GroupNorm partial sums as a by-product
+    (``conv3x3_gn_slots`` tells whether / how many slots per image)."""
     return make_op(L.OP_CONV3X3,
-                   i=[B, H, W, C0, C1, N, int(subpix), int(silu), lda0, lda1, ldo, ldr, ldw, int(rowvec_bcast), variant],
-                   p=[a0, w, out, bias, rowvec, residual, a1, ss], l=[wz])
+                   i=[B, H, W, C0, C1, N, int(subpix), int(silu), lda0, lda1, ldo, ldr, ldw, int(rowvec_bcast), variant, gn_cpg, gn_slots],
+                   p=[a0, w, out, bias, rowvec, residual, a1, ss, gn_part], l=[wz])
+
+
+def conv3x3_gn_slots(op):
+    """Partial-table slots per image this MG_OP_CONV3X3 fills with its output's GroupNorm statistics (0: its tile does not)."""
+    return int(L.load().mg_conv3x3_gn_slots(ctypes.byref(op)))
 
 
 def rowgemm(x, wp, out, *, M, K, N, form=L.RG_BF16, ldx=0, ldo=0, ldr=0, residual=None, ln_in=None, ln_out=None, vt=None,

@@ -297,6 +297,65 @@ def test_conv3x3_patch_subpixel(dev, B, H, W, Cin, N, variant):
     _close(f"conv3x3p/subpixel B{B} {H}x{W} {Cin}->{N} v{variant}", out.float().permute(0, 3, 1, 2), ref, tol=2e-2)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,N,variant,fused,use_res,subpix", [
+    (2, 48, 32, 128, 128, 8, True, True, False),     # 24 x 16 x 128 tiles: 4-channel groups (two per 8-channel vector)
+    (1, 50, 37, 64, 128, 8, False, False, False),    # ragged tiles: the pixels outside the image stay out of the sums
+    (2, 24, 32, 128, 256, 9, True, True, False),     # 12 x 16 x 256 tiles: 8-channel groups
+    (1, 24, 16, 64, 512, 9, False, False, False),    # two channel tiles, 16-channel groups (both halves of a lane pair)
+    (1, 13, 21, 64, 256, 9, False, False, True),     # the sub-pixel up-sampling: four parities = four slots per tile
+])
+def test_conv3x3_patch_output_groupnorm_statistics(dev, B, H, W, Cin, N, variant, fused, use_res, subpix):
+    """MG_OP_CONV3X3 p[8]: the GroupNorm partial sums of the convolution's OUTPUT as a by-product of the 12-wave tiles'
+    epilogue, reduced by MG_OP_GN_FINALIZE, against (a) MG_OP_GN_STATS + FINALIZE over the stored tensor and (b) torch's
+    statistics of it; the convolution's output itself must be bit-identical with and without the by-product, and the table
+    bit-stable across launches."""
+    from marigold_amd import ops, weights as Wm
+    g = torch.Generator().manual_seed(H * W + N)
+    x = _bf(torch.randn(B, Cin, H, W, generator=g))
+    w = _bf(torch.randn(N, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    bias = (torch.randn(N, generator=g) * 0.5 + 0.3).to(dev)
+    ss_in = (torch.stack([1.0 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], dim=1).to(dev).contiguous()
+             if fused else None)
+    Ho, Wo = (2 * H, 2 * W) if subpix else (H, W)
+    res = torch.randn(B, Ho, Wo, N, generator=g).to(dev, torch.bfloat16) if use_res else None
+    xd = _nhwc(x).to(dev, torch.bfloat16)
+    wd = (Wm.pack_conv3x3_subpix(w) if subpix else Wm.pack_conv3x3(w)).to(dev, torch.bfloat16)
+    kw = dict(B=B, H=H, W=W, C0=Cin, N=N, ss=ss_in, silu=fused, bias=bias, residual=res, subpix=subpix, wz=N * 4 * Cin if subpix else 0,
+              variant=variant)
+    plain = torch.full((B, Ho, Wo, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    _run(ops.conv3x3(xd, wd, plain, **kw))
+    slots = ops.conv3x3_gn_slots(ops.conv3x3(xd, wd, plain, **kw))
+    assert slots > 0
+    cpg = N // 32
+    gamma, beta = (1 + 0.2 * torch.randn(N, generator=g)).to(dev), (0.2 * torch.randn(N, generator=g)).to(dev)
+    HW = Ho * Wo
+    tables = []
+    for rep in range(2):
+        out = torch.full_like(plain, float("nan"))
+        part = torch.full((B, slots, 32, 2), float("nan"), device=dev)
+        _run(ops.conv3x3(xd, wd, out, gn_part=part, gn_cpg=cpg, gn_slots=slots, **kw))
+        assert torch.equal(out, plain), "the by-product must not change the convolution's output"
+        tables.append(part.clone())
+    assert torch.equal(tables[0], tables[1]), "partial table not bit-stable"
+    ss = torch.full((B, 2, N), float("nan"), device=dev)
+    _run(ops.gn_finalize(tables[0], gamma, beta, ss, B=B, C=N, groups=32, slots=slots, HW=HW, eps=1e-6))
+    # (a) the statistics pass over the stored tensor
+    chunks = 8
+    part2 = torch.empty(B, chunks, 32, 2, device=dev)
+    ss2 = torch.full((B, 2, N), float("nan"), device=dev)
+    _run(ops.gn_stats(plain, part2, B=B, HW=HW, C=N, chunks=chunks, groups=32))
+    _run(ops.gn_finalize(part2, gamma, beta, ss2, B=B, C=N, groups=32, slots=chunks, HW=HW, eps=1e-6))
+    _close(f"conv3x3p/gn by-product vs statistics pass/N{N}v{variant}", ss, ss2, tol=1e-5)
+    # (b) torch on the stored values
+    o = plain.float().cpu().reshape(B, HW, 32, cpg)
+    mean, var = o.mean(dim=(1, 3)), o.var(dim=(1, 3), unbiased=False)
+    rstd = (var + 1e-6).rsqrt()
+    sc_ref = rstd.repeat_interleave(cpg, 1) * gamma.cpu()
+    sh_ref = beta.cpu() - mean.repeat_interleave(cpg, 1) * sc_ref
+    _close(f"conv3x3p/gn by-product scale/N{N}v{variant}", ss[:, 0], sc_ref, tol=2e-4)
+    _close(f"conv3x3p/gn by-product shift/N{N}v{variant}", ss[:, 1], sh_ref, tol=2e-4)
+
+
 def test_conv3x3_patch_equals_unfused_chain(dev):
     """The fused kernel feeds the MFMAs the same operands as gn_apply -> concat -> implicit GEMM (same fp32 affine +
     SiLU, same bf16 rounding of the normalised activation); only the fp32 accumulation order differs (channel tile
