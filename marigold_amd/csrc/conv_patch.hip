@@ -380,10 +380,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_patch_kernel(const ConvPAr
       for (int gp = 0; gp < 2; ++gp)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+          // over the 32 pixels of a half-wave: an inclusive scan inside each row of 16 lanes (DPP row_shr 1, 2, 4, 8, zeros
+          // shifted in), then lane 15's total into the odd rows (row_bcast:15) - lanes 31 and 63 hold the half-waves' sums; five
+          // VALU adds per value where the ds_bpermute butterfly took fifteen instructions
           float s_ = gsum[ni][gp][k], q_ = gsq[ni][gp][k];
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) { s_ += __shfl_xor(s_, o); q_ += __shfl_xor(q_, o); }   // over the 32 pixels of a half-wave
-          if (l31 == 0) {
+          auto dpp_sum = [](float v) {
+#define CP_DPP(ctrl, rmask) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), ctrl, rmask, 0xf, true))
+            v += CP_DPP(0x111, 0xf);
+            v += CP_DPP(0x112, 0xf);
+            v += CP_DPP(0x114, 0xf);
+            v += CP_DPP(0x118, 0xf);
+            v += CP_DPP(0x142, 0xa);
+#undef CP_DPP
+            return v;
+          };
+          s_ = dpp_sum(s_);
+          q_ = dpp_sum(q_);
+          if (l31 == 31) {
             float* d = gl + ((wave * (TN / 4) + (ni * 8 + gp * 4 + half * 2 + k)) << 1);
             d[0] = s_;
             d[1] = q_;
