@@ -29,6 +29,7 @@ VAE_ATTN_CHUNK_BYTES = int(os.environ.get("MARIGOLD_VAE_ATTN_CHUNK_MB", "0")) <<
 # (query chunks whose scores fit the 256 MB Infinity Cache measured no gain: vae.decode 62.1 vs 62.9 ms, profiles/r4_vae_attention_chunks.log)
 GN_BYPRODUCT = os.environ.get("MARIGOLD_GN_BYPRODUCT", "1") != "0"   # GroupNorm partial sums from the producing convolution's epilogue
 UNFUSE_320 = int(os.environ.get("MARIGOLD_UNFUSE_320", "0"))   # > 0: minimum Cin from which the 320-channel level's GroupNorm is NOT fused into its convolution
+VAE_FLASH_SMALL = os.environ.get("MARIGOLD_VAE_FLASH_SMALL", "1") != "0"   # ... also for launches of < 200 query blocks (the encoder)
 VAE_FLASH = os.environ.get("MARIGOLD_VAE_FLASH", "1") != "0"          # VAE mid-block attention as a flash kernel (off: materialised scores)
 IGEMM73_CONV = os.environ.get("MARIGOLD_IGEMM73_CONV", "1") != "0"   # plain N = 320 k convolutions on the hand-placed 192 x 320 GEMM tile
 IGEMM72_VAE = os.environ.get("MARIGOLD_IGEMM72_VAE", "1") != "0"    # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
@@ -734,11 +735,13 @@ class Builder:
                          out2=vt, trans_from=2 * C, ldt=ldp), f"{name}.qkv")
         self.free(g)
         o = self.new(x.B, x.H, x.W, C)
-        if VAE_FLASH and C == 512 and B * ((T + 127) // 128) >= 200:
+        if VAE_FLASH and C == 512 and (VAE_FLASH_SMALL or B * ((T + 127) // 128) >= 200):
             # round 4: flash form (MG_OP_FLASH_ATTN512) - the T x T scores (340 MB of fp32 per image at 96 x 96 latent pixels)
-            # never leave the registers.  One workgroup per 128 queries and CU: launches that do not fill the chip (the
-            # encoder's single image: 72 workgroups, 0.93 vs 0.50 ms) stay on the three-stage form below
-            # (profiles/r4_flash512.log).
+            # never leave the registers.  One workgroup per 128 queries and CU: a launch that does not fill the chip (the
+            # encoder's single image: 72 workgroups) takes 0.93 ms against 0.50 ms for the three-stage form below
+            # (profiles/r4_flash512.log; two-wave workgroups of 64 queries were tried for such launches: 1.12 ms, the tile's
+            # LDS-DMA traffic per query doubles) - it runs here all the same, so that no score matrix is materialised anywhere
+            # (MARIGOLD_VAE_FLASH_SMALL=0: the three-stage form for such launches).
             self.add(O.flash_attn512(qk, qk.data_ptr() + C * 2, vt, o.t, B=B, Ntok=T, ldq=2 * C, ldo=C, ldvt=ldp,
                                      sq=T * 2 * C, sk=T * 2 * C, svt=C * ldp, so=T * C, scale=1.0 / math.sqrt(C)), f"{name}.flash")
             self.free(qk)

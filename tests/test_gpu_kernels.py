@@ -1360,7 +1360,7 @@ def _flash512_run(dev, q, k, v, B, T):
     return out, ref
 
 
-@pytest.mark.parametrize("B,T", [(1, 32), (1, 31), (2, 130), (3, 576), (1, 1000), (2, 2304)])
+@pytest.mark.parametrize("B,T", [(1, 32), (1, 31), (2, 130), (3, 576), (1, 1000), (2, 2304), (13, 1984), (7, 3700)])
 def test_flash_attn512(dev, B, T):
     """MG_OP_FLASH_ATTN512 (the VAE mid-block attention, one head of width 512) against fp32 SDPA on the host: whole and
     ragged key tiles, ragged query blocks, several images per launch."""
