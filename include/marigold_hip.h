@@ -266,6 +266,11 @@ void mg_program_destroy(mg_program* prog);
 
 /* Named wrappers - what a binding for the reference's seams would call directly. */
 int mg_conv2d_igemm(const mg_op* conv_desc, void* stream);   /* kind must be MG_OP_IGEMM */
+/* Host-only test hook (no device work): how MG_OP_FLASH_ATTN64's hand-placed kernel would share out B x heads sequences of Ntok
+ * tokens over a chip of n_cu CUs given a workspace of ws_bytes and the split mode (op i[9]): out[0] whole blocks of 256 queries,
+ * out[1] blocks split along the keys, out[2] workgroups over the split blocks; bounds[0 .. out[2]] (or NULL): the workgroups'
+ * piece boundaries in 64-key tiles over the concatenated split blocks. */
+int mg_flash4w_plan_test(int B, int heads, int Ntok, int n_cu, long long ws_bytes, int split, int* out, unsigned* bounds);
 int mg_conv3x3(const mg_op* conv_desc, void* stream);        /* kind must be MG_OP_CONV3X3 (ResnetBlock2D norm+silu+conv) */
 /* Slots per image of the partial table this MG_OP_CONV3X3 can fill with the GroupNorm statistics of its OUTPUT (p[8], see the
  * op), or 0 when the tile variant it runs on does not produce them (then leave p[8] NULL and use MG_OP_GN_STATS). */

@@ -33,7 +33,7 @@ OP_NAMES = {v: k[3:].lower() for k, v in list(globals().items()) if k.startswith
 EXPORTS = [
     "mg_abi_version", "mg_last_error", "mg_init", "mg_geglu_interleave", "mg_device_info", "mg_launch",
     "mg_program_create", "mg_program_num_ops", "mg_program_run", "mg_program_validate", "mg_program_run_range",
-    "mg_program_capture", "mg_program_profile", "mg_program_destroy", "mg_conv2d_igemm", "mg_conv3x3", "mg_conv3x3_gn_slots",
+    "mg_program_capture", "mg_program_profile", "mg_program_destroy", "mg_conv2d_igemm", "mg_conv3x3", "mg_conv3x3_gn_slots", "mg_flash4w_plan_test",
     "mg_sched_step", "mg_ensemble_normals", "mg_ens_align_cost_grad", "mg_bfgs_minimize", "mg_ens_align_minimize", "mg_event_create", "mg_event_record",
     "mg_event_elapsed_ms", "mg_event_destroy", "mg_clock_probe",
 ]
@@ -71,6 +71,7 @@ def load():
     lib.mg_conv3x3.argtypes = [ctypes.POINTER(MgOp), ctypes.c_void_p]
     lib.mg_conv3x3_gn_slots.argtypes = [ctypes.POINTER(MgOp)]
     lib.mg_conv3x3_gn_slots.restype = ctypes.c_int
+    lib.mg_flash4w_plan_test.argtypes = [ctypes.c_int] * 4 + [ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)]
     lib.mg_program_create.restype = ctypes.c_void_p
     lib.mg_program_create.argtypes = [ctypes.POINTER(MgOp), ctypes.c_int]
     lib.mg_program_num_ops.argtypes = [ctypes.c_void_p]

@@ -347,6 +347,48 @@ bool mg_flash4w_ok(const FaArgs& a, bool vt_perm) {
          (long long)a.Ntok * a.ldq * 2 < (1ll << 31) && 64ll * a.ldvt * 2 < (1ll << 31);
 }
 
+// Whole blocks in multiples of the CU count (two workgroups share a CU: 3 1/2 blocks per slot end in a round that a few CUs run
+// alone); the rest in key pieces of at least a third of a block (at most four pieces per block) over up to two workgroups per CU.
+// (measured, profiles/r4_flash4w.log: a piece costs ~15-20 us of prologue / partial result / combine on top of its key loop -
+// splitting pays for a FEW left-over blocks behind many whole ones (1 800 = 7 x 256 + 8: 919 -> 863 us), not for a left-over of
+// half a round (900 blocks at 2 304 tokens: 142 -> 154 us) or for a launch that does not fill the chip anyway)
+// (FaArgs::split: 0 = that rule, 1 = split whatever is left over - the tests, 2 = never)
+void mg_flash4w_plan(FaArgs* a, int n_cu) {
+  const int nkt = a->Ntok / 64;
+  const long long nb = (long long)(a->Ntok / 256) * a->heads * a->B;
+  a->n_full = (int)nb;
+  a->n_rem = 0;
+  a->n_rem_wg = 0;
+  static const int split = [] { const char* e = getenv("MARIGOLD_FLASH4W_SPLIT"); return e ? atoi(e) : 1; }();
+  if (split && a->split != 2 && a->ws && nb % n_cu != 0 && (a->split == 1 || (nb > n_cu && (nb % n_cu) * 8 <= n_cu))) {
+    const long long rem = nb % n_cu;
+    const long long cap = (a->ws_bytes - F4_CTR_BYTES) / ((long long)F4_PIECES * F4_PART_BYTES);
+    long long wg = 2ll * n_cu;
+    if (wg > 3 * rem) wg = 3 * rem;                               // pieces of >= a third of a block: at most four per block
+    if (wg > (long long)rem * nkt / 4) wg = (long long)rem * nkt / 4;   // ... and of four tiles at least
+    if (rem <= cap && rem * 4 <= F4_CTR_BYTES && wg > rem && (wg + 1) * rem * nkt < (1ll << 31)) {
+      a->n_full = (int)(nb - rem);
+      a->n_rem = (int)rem;
+      a->n_rem_wg = (int)wg;
+    }
+  }
+}
+
+// (host tests) the plan for B x heads sequences of Ntok tokens and the piece boundaries of its split blocks:
+// out[0..2] = whole blocks, split blocks, workgroups over them; bounds[0 .. out[2]] (if not null) in key tiles
+extern "C" int mg_flash4w_plan_test(int B, int heads, int Ntok, int n_cu, long long ws_bytes, int split, int* out, unsigned* bounds) {
+  FaArgs a = {};
+  a.B = B; a.heads = heads; a.Ntok = Ntok;
+  a.ws = ws_bytes > 0 ? (void*)(uintptr_t)16 : nullptr;
+  a.ws_bytes = ws_bytes;
+  a.split = split;
+  mg_flash4w_plan(&a, n_cu);
+  out[0] = a.n_full; out[1] = a.n_rem; out[2] = a.n_rem_wg;
+  if (bounds && a.n_rem_wg > 0)
+    for (int r = 0; r <= a.n_rem_wg; ++r) bounds[r] = f4_bound((unsigned)r, (unsigned)a.n_rem_wg, (unsigned)a.n_rem * (unsigned)(Ntok / 64), (unsigned)(Ntok / 64));
+  return 0;
+}
+
 int mg_launch_flash4w(const FaArgs& a_in, hipStream_t s) {
   FaArgs a = a_in;
   MG_REQUIRE(mg_flash4w_ok(a, true), "flash_attn64 (hand-placed form): Ntok %d must be a multiple of 256, "
@@ -364,31 +406,8 @@ int mg_launch_flash4w(const FaArgs& a_in, hipStream_t s) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
     attr_set = true;
   }
-  const int nkt = a.Ntok / 64;
-  const long long nb = (long long)(a.Ntok / 256) * a.heads * a.B;
-  MG_REQUIRE(nb < (1ll << 30), "flash_attn64: too many query blocks");
-  // whole blocks in multiples of the CU count (two workgroups share a CU: 3 1/2 blocks per slot end in a round that a few CUs
-  // run alone); the rest in key pieces of at least a third of a block over up to two workgroups per CU
-  a.n_full = (int)nb;
-  a.n_rem = 0;
-  a.n_rem_wg = 0;
-  static const int split = [] { const char* e = getenv("MARIGOLD_FLASH4W_SPLIT"); return e ? atoi(e) : 1; }();
-  // (measured, profiles/r4_flash4w.log: a piece costs ~15-20 us of prologue / partial result / combine on top of its key loop -
-  // splitting pays for a FEW left-over blocks behind many whole ones (1 800 = 7 x 256 + 8: 919 -> 863 us), not for a left-over of
-  // half a round (900 blocks at 2 304 tokens: 142 -> 154 us) or for a launch that does not fill the chip anyway)
-  // (FaArgs::split: 0 = that rule, 1 = split whatever is left over - the tests, 2 = never)
-  if (split && a.split != 2 && a.ws && nb % n_cu != 0 && (a.split == 1 || (nb > n_cu && (nb % n_cu) * 8 <= n_cu))) {
-    const long long rem = nb % n_cu;
-    const long long cap = (a.ws_bytes - F4_CTR_BYTES) / ((long long)F4_PIECES * F4_PART_BYTES);
-    long long wg = 2ll * n_cu;
-    if (wg > 3 * rem) wg = 3 * rem;                               // pieces of >= a third of a block: at most four per block
-    if (wg > (long long)rem * nkt / 4) wg = (long long)rem * nkt / 4;   // ... and of four tiles at least
-    if (rem <= cap && rem * 4 <= F4_CTR_BYTES && wg > rem && (wg + 1) * rem * nkt < (1ll << 31)) {
-      a.n_full = (int)(nb - rem);
-      a.n_rem = (int)rem;
-      a.n_rem_wg = (int)wg;
-    }
-  }
+  MG_REQUIRE((long long)(a.Ntok / 256) * a.heads * a.B < (1ll << 30), "flash_attn64: too many query blocks");
+  mg_flash4w_plan(&a, n_cu);
   const long long grid = (long long)a.n_full + a.n_rem_wg;
   MG_LAUNCH(flash_attn64_4w_kernel, dim3((unsigned)grid), dim3(256), LDS, s, a);
   return 0;

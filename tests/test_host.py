@@ -920,3 +920,44 @@ def test_native_bfgs_follows_scipy():
             total += 1
             same += a[2:] == b[2:]
     assert same >= total - 2, (same, total)
+
+
+@pytest.mark.parametrize("B,heads,Ntok", [(10, 5, 9216), (10, 10, 2304), (1, 5, 9216), (13, 5, 1024), (3, 23, 1280), (2, 5, 9216), (7, 3, 512),
+                                          (1, 1, 256), (16, 16, 4096)])
+@pytest.mark.parametrize("split", [0, 1, 2])
+def test_flash_attention_key_split_plan(B, heads, Ntok, split):
+    """MG_OP_FLASH_ATTN64's hand-placed kernel splits the blocks of 256 queries left over beyond a multiple of the CU count along
+    the keys (csrc/flash4w.hip).  Host-side properties of that plan (mg_flash4w_plan_test, no device): every block is either whole
+    or split, the workgroups' ranges tile the split blocks' key tiles exactly once, every piece of a block has at least the four
+    tiles the stream needs, a block has at most four pieces (the workspace holds four partial results per block)."""
+    import ctypes
+    from marigold_amd import _lib as L, ops as O
+    lib = L.load()
+    n_cu, nkt = 256, Ntok // 64
+    nb = (Ntok // 256) * heads * B
+    out = (ctypes.c_int * 3)()
+    bounds = (ctypes.c_uint * 1026)()
+    assert lib.mg_flash4w_plan_test(B, heads, Ntok, n_cu, O.FLASH_WS_BYTES, split, out, bounds) == 0
+    n_full, n_rem, nwg = out[0], out[1], out[2]
+    assert n_full + n_rem == nb and n_full % n_cu == 0 or n_rem == 0
+    if split == 2 or nb % n_cu == 0:
+        assert n_rem == 0 and nwg == 0
+    if split == 1 and nb % n_cu != 0 and nkt >= 8:
+        assert n_rem == nb % n_cu and nwg > n_rem
+    if n_rem == 0:
+        return
+    assert nwg <= 2 * n_cu
+    b = [bounds[r] for r in range(nwg + 1)]
+    assert b[0] == 0 and b[-1] == n_rem * nkt and all(x <= y for x, y in zip(b, b[1:]))
+    pieces = [0] * n_rem
+    for lo, hi in zip(b, b[1:]):
+        s = lo
+        while s < hi:                         # the kernel's walk over its range, block by block
+            blk, t0 = divmod(s, nkt)
+            t1 = min(nkt, t0 + hi - s)
+            assert t1 - t0 >= 4, (lo, hi, blk, t0, t1)
+            pieces[blk] += 1
+            s += t1 - t0
+    assert min(pieces) >= 1 and max(pieces) <= 4, (min(pieces), max(pieces))
+    # without a workspace nothing is split
+    assert lib.mg_flash4w_plan_test(B, heads, Ntok, n_cu, 0, split, out, None) == 0 and out[1] == 0 and out[0] == nb
