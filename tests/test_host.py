@@ -961,3 +961,22 @@ def test_flash_attention_key_split_plan(B, heads, Ntok, split):
     assert min(pieces) >= 1 and max(pieces) <= 4, (min(pieces), max(pieces))
     # without a workspace nothing is split
     assert lib.mg_flash4w_plan_test(B, heads, Ntok, n_cu, 0, split, out, None) == 0 and out[1] == 0 and out[0] == nb
+
+
+def test_generated_instruction_streams_are_in_sync(tmp_path):
+    """The hand-placed instruction streams are written by generators (csrc/gen_k4w.py, gen_cp4w.py, gen_fa4w.py) and committed as
+    .inc files (the build regenerates them when a generator is newer): the committed files must be what the generators write."""
+    import subprocess
+    import sys
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "marigold_amd", "csrc")
+    for gen, inc, to_stdout in (("gen_k4w.py", "igemm2_k4w.inc", True), ("gen_cp4w.py", "conv_patch4w.inc", True), ("gen_fa4w.py", "flash4w.inc", False)):
+        out = tmp_path / inc
+        if to_stdout:
+            r = subprocess.run([sys.executable, os.path.join(csrc, gen)], capture_output=True, text=True, cwd=csrc, timeout=300)
+            assert r.returncode == 0, r.stderr[-500:]
+            text = r.stdout
+        else:
+            r = subprocess.run([sys.executable, os.path.join(csrc, gen), str(out)], capture_output=True, text=True, cwd=csrc, timeout=300)
+            assert r.returncode == 0, r.stderr[-500:]
+            text = out.read_text()
+        assert text == open(os.path.join(csrc, inc)).read(), f"{inc} is not what {gen} writes"
