@@ -438,7 +438,8 @@ int launch_patch(const ConvPArgs& a0, hipStream_t s) {
   void (*kern)(const ConvPArgs) = a.ss ? conv_patch_kernel<TH, TW, BN, WGM, WGN, NSTB, true>
                                        : conv_patch_kernel<TH, TW, BN, WGM, WGN, NSTB, false>;
   int ki = a.ss ? 1 : 0;
-  if constexpr (WGM * WGN == 12 && BN != 320) {   // the output's GroupNorm statistics as a by-product: the VAE's 12-wave tiles
+  if constexpr ((WGM * WGN == 12 && BN != 320) || (TH == 16 && BN == 256 && NSTB == 2)) {   // the output's GroupNorm statistics as a
+    // by-product: the VAE's 12-wave tiles and the 16 x 16 x 256 tile its 256-channel sub-pixel up-sampling runs on
     if (a.gn_part) {
       kern = a.ss ? conv_patch_kernel<TH, TW, BN, WGM, WGN, NSTB, true, true> : conv_patch_kernel<TH, TW, BN, WGM, WGN, NSTB, false, true>;
       ki += 2;
@@ -515,6 +516,7 @@ static int mg_conv3x3_variant_of(const mg_op* op) {
 int mg_conv3x3_gn_slots_of(const mg_op* op) {
   const int variant = mg_conv3x3_variant_of(op);
   const int H = op->i[1], W = op->i[2], N = op->i[5], par = op->i[6] ? 4 : 1;
+  if (variant == 1 && N % 256 == 0) return ((H + 15) / 16) * ((W + 15) / 16) * par;
   if (variant == 8 && N % 128 == 0) return ((H + 23) / 24) * ((W + 15) / 16) * par;
   if (variant == 9 && N % 256 == 0) return ((H + 11) / 12) * ((W + 15) / 16) * par;
   return 0;

@@ -303,6 +303,8 @@ def test_conv3x3_patch_subpixel(dev, B, H, W, Cin, N, variant):
     (2, 24, 32, 128, 256, 9, True, True, False),     # 12 x 16 x 256 tiles: 8-channel groups
     (1, 24, 16, 64, 512, 9, False, False, False),    # two channel tiles, 16-channel groups (both halves of a lane pair)
     (1, 13, 21, 64, 256, 9, False, False, True),     # the sub-pixel up-sampling: four parities = four slots per tile
+    (2, 18, 33, 128, 256, 1, False, False, True),    # ... on the 16 x 16 x 256 / 8-wave tile the VAE's up-sampling runs on
+    (1, 32, 16, 64, 256, 1, True, True, False),
 ])
 def test_conv3x3_patch_output_groupnorm_statistics(dev, B, H, W, Cin, N, variant, fused, use_res, subpix):
     """MG_OP_CONV3X3 p[8]: the GroupNorm partial sums of the convolution's OUTPUT as a by-product of the 12-wave tiles'
