@@ -980,3 +980,20 @@ def test_generated_instruction_streams_are_in_sync(tmp_path):
             assert r.returncode == 0, r.stderr[-500:]
             text = out.read_text()
         assert text == open(os.path.join(csrc, inc)).read(), f"{inc} is not what {gen} writes"
+
+
+def test_conv3x3_groupnorm_byproduct_slots():
+    """mg_conv3x3_gn_slots (host-only): which MG_OP_CONV3X3 launches can leave the GroupNorm partial sums of their output, and
+    how many table slots per image they fill (one per tile, four per tile in the sub-pixel form); 0 for the tiles that cannot."""
+    from marigold_amd import ops
+    def slots(**kw):
+        base = dict(B=10, H=384, W=384, C0=256, N=256)
+        base.update(kw)
+        return ops.conv3x3_gn_slots(ops.conv3x3(0, 0, 0, **base))
+    assert slots(variant=9) == 32 * 24                          # 12 x 16 pixel tiles
+    assert slots(variant=9, subpix=True, wz=1) == 4 * 32 * 24
+    assert slots(variant=8, N=128, H=768, W=768) == 32 * 48    # 24 x 16
+    assert slots(variant=1, subpix=True, wz=1) == 4 * 24 * 24  # 16 x 16
+    assert slots(variant=8, N=128, H=50, W=37) == 3 * 3        # ragged
+    assert slots(variant=6, N=320, C0=320) == 0 and slots(variant=10) == 0 and slots(variant=11, N=320, C0=320) == 0
+    assert slots(variant=9, N=128) == 0                         # the 256-channel tile needs N % 256 == 0
