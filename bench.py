@@ -11,6 +11,9 @@ script/depth/infer.py).  The image is already resident in HBM when the timed reg
 
 N > 1: one process per GPU; the E members of every map are sharded over the ranks, collected with
 ONE gather (RCCL over xGMI) and aggregated on rank 0 ("strong" scaling: the work per map is fixed).
+MARIGOLD_BENCH_FORCE_DIST=1 takes the SAME code path with one rank (``init_process_group("nccl", device_id=...)``,
+``enable_member_parallel``, the rooted gather to self, the all-reduce of the timing): the RCCL path executed on one GPU
+(tests/test_gpu_pipeline.py::test_bench_nccl_path_single_rank); the line then carries a ``collective`` object.
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).  Weights are seeded synthetic
 tensors in the real SD-v2 architecture (no checkpoints / network here); arithmetic is bf16 with fp32
 accumulation.
@@ -316,8 +319,16 @@ def main():
     assert shared_gpu or world <= n_dev, f"--gpus {args.gpus} but only {n_dev} GPU(s) visible"
     torch.cuda.set_device(local_rank % n_dev)
     dev = torch.device("cuda", local_rank % n_dev)
-    if world > 1:
+    force_dist = os.environ.get("MARIGOLD_BENCH_FORCE_DIST") == "1"   # one rank through the multi-rank code path (RCCL on one GPU)
+    dist_on = world > 1 or force_dist
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "WORLD_SIZE" not in os.environ:   # forced, without a launcher: rendezvous with ourselves
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         dist.init_process_group("gloo" if shared_gpu else "nccl", **({} if shared_gpu else {"device_id": dev}))
         seen = torch.ones(1, device="cpu" if shared_gpu else dev)
         dist.all_reduce(seen)
@@ -350,8 +361,8 @@ def main():
                scheduler=DDIMScheduler() if args.scheduler == "ddim" else LCMScheduler(), empty_text_embed=ctx,
                default_denoising_steps=args.denoise,
                default_processing_resolution=0, **extra).to(dev)
-    if world > 1:
-        pipe.enable_member_parallel(root=0)
+    if dist_on:
+        pipe.enable_member_parallel(root=0, force_collective=force_dist)
     if rank == 0:
         log(f"[bench] synthetic weights + pipeline ready in {time.perf_counter() - t0:.1f}s "
             f"(host cores {os.cpu_count()})")
@@ -367,7 +378,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -391,8 +402,8 @@ def main():
         out = pipe(img, **kw)
     barrier()
     dt = time.perf_counter() - t1
-    tt = torch.tensor([dt], device="cpu" if (world > 1 and dist.get_backend() == "gloo") else dev, dtype=torch.float64)
-    if world > 1:
+    tt = torch.tensor([dt], device="cpu" if (dist_on and dist.get_backend() == "gloo") else dev, dtype=torch.float64)
+    if dist_on:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     if rank == 0:
@@ -471,13 +482,15 @@ def main():
             from marigold_amd import ensemble as ens
             C = {"depth": 1, "normals": 3, "iid": 6}[args.kind]
             local_n = len(mdist.shard_members(args.ensemble, world, rank)) if world > 1 else args.ensemble
-            if world > 1:
+            if dist_on:
                 buf = torch.rand(local_n, C, args.res, args.res, device=dev)
                 barrier()
                 t1 = time.perf_counter()
                 for _ in range(3):
-                    mdist.gather_members(buf, args.ensemble, (C, args.res, args.res), dev, None, 0)
+                    got = mdist.gather_members(buf, args.ensemble, (C, args.res, args.res), dev, None, 0, force=force_dist)
                 barrier()
+                if rank == 0 and world == 1:   # the forced single-rank gather returns the members it was given
+                    assert got is not buf and torch.equal(got, buf), "forced single-rank gather changed the members"
                 if rank == 0:
                     stages["gather"] = {"ms": round((time.perf_counter() - t1) / 3 * 1e3, 3),
                                         "bytes_to_root": (args.ensemble - local_n) * C * args.res * args.res * 4}
@@ -538,6 +551,8 @@ def main():
                        "members_per_gpu": -(-args.ensemble // world), "parallelism": f"member-parallel x{world}",
                        "hipgraph": bool(args.graph)},
             "roofline": roof,
+            "collective": ({"backend": dist.get_backend(), "world_size": world, "forced_single_rank": bool(force_dist and world == 1),
+                            "gathers_per_map": 1} if dist_on else None),
             "cpu_baseline": cpu,
             "calibration": calib,
             # whole-map figures only where rank 0 ran the whole map (its programs cover its own members only)
@@ -548,7 +563,7 @@ def main():
             "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         barrier()   # rank 0 spends a few seconds more (per-op profile): leave together
         dist.destroy_process_group()
 

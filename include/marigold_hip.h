@@ -192,7 +192,8 @@ enum mg_op_kind {
    *   p[3] mad f32 [HW]|NULL  p[4] out f32 [2+2E] = min, max of the prediction and the raw member
    *   values d[.][argmin px], d[.][argmax px] (exact sub-gradient of the regulariser on the
    *   host)  p[5] scratch (>= 12288 B) ; i: E, reduction(0 median,1 mean), has_shift ; l[0] HW
-   * (DEPTH_STATS scratch: >= 128*E*35 doubles)
+   * (DEPTH_STATS scratch: >= 128*E*(E+3) doubles.  Any E >= 1: <= 32 members are selected in registers, <= 128 in LDS,
+   * larger ensembles by a bitwise selection over the members in memory - the reference has no limit, ensemble.py:39-49)
    * DEPTH_NORM  : out = (med - lo)/range ; unc /= range.  p[0] med p[1] mad|NULL p[2] minmax
    *   ; i[0] shift_invariant ; l[0] HW
    * NORMALS     : p[0] n f32 [E][3][HW] p[1] out f32 [3][HW] p[2] unc f32 [HW]|NULL ;
@@ -289,7 +290,7 @@ int mg_ens_align_cost_grad(int E, const double* s, const double* t, const double
 /* scipy.optimize.minimize(fn, x, jac=True, method="BFGS", tol=gtol, options={"maxiter": maxiter}) restated natively
  * (scipy 1.15: _minimize_bfgs, DCSRCH line search with the Wolfe-2 fall-back, one objective evaluation per distinct point;
  * csrc/bfgs.hip).  fn(user, n, x, &f, g) returns 0.  x in / out; status = scipy's warnflag (0 converged, 1 maxiter,
- * 2 precision loss, 3 NaN).  n <= 256. */
+ * 2 precision loss, 3 NaN).  Any n. */
 int mg_bfgs_minimize(int (*fn)(void* user, int n, const double* x, double* f, double* g), void* user, int n, double* x,
                      double gtol, int maxiter, double* fval, int* nit, int* nfev, int* status);
 /* The whole alignment of ensemble_depth (marigold/util/ensemble.py:154-173: compute_param + scipy BFGS) as one call: the

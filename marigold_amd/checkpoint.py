@@ -88,10 +88,12 @@ def load_pipeline(cls, path, variant=None, torch_dtype=None, **kw):
     # (or a field it does not know) raises instead of loading a model that would compute something else
     unet_cfg = CC.unet_config_from_json(_json(os.path.join(path, "unet", "config.json")))
     vae_cfg = CC.vae_config_from_json(_json(os.path.join(path, "vae", "config.json")))
-    if torch_dtype is not None and torch_dtype not in (torch.bfloat16,):
+    if torch_dtype is not None and torch_dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        raise ValueError(f"torch_dtype={torch_dtype}: expected torch.float32, torch.float16 or torch.bfloat16")
+    if torch_dtype is not None and torch_dtype is not torch.bfloat16:
         import logging
-        logging.warning(f"torch_dtype={torch_dtype} is ignored: the HIP engine computes in bf16 with fp32 accumulation "
-                        f"and keeps latents / predictions in fp32")
+        logging.warning(f"torch_dtype={torch_dtype}: the HIP engine computes in bf16 with fp32 accumulation whatever the checkpoint's "
+                        f"dtype and keeps latents / predictions in fp32; torch_dtype only selects the dtype of the noise draws")
     unet = UNet2DConditionModelHIP(_weights(os.path.join(path, "unet"), variant), unet_cfg)
     vae = AutoencoderKLHIP(_rename_legacy_vae_keys(_weights(os.path.join(path, "vae"), variant)), vae_cfg)
     scfg = _json(os.path.join(path, "scheduler", "scheduler_config.json"))
@@ -114,8 +116,12 @@ def load_pipeline(cls, path, variant=None, torch_dtype=None, **kw):
         extra.pop("shift_invariant", None)
     if cls.__name__ != "MarigoldIIDPipeline":
         extra.pop("target_properties", None)
-    return cls(unet=unet, vae=vae, scheduler=scheduler, text_encoder=text_encoder, tokenizer=tokenizer,
+    pipe = cls(unet=unet, vae=vae, scheduler=scheduler, text_encoder=text_encoder, tokenizer=tokenizer,
                empty_text_embed=empty, **extra)
+    # the reference draws its latents / LCM noise in the dtype the pipeline was loaded with (marigold_depth_pipeline.py:430-435)
+    if torch_dtype in (torch.float16, torch.bfloat16):
+        pipe.noise_dtype = torch_dtype
+    return pipe
 
 
 def save_synthetic_checkpoint(path, cls_name, unet_sd, vae_sd, unet_cfg, vae_cfg, scheduler, empty_text_embed,

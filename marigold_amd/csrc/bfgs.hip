@@ -486,7 +486,7 @@ int bfgs(Objective& o, double* x, double gtol, int maxiter, double* fval, int* n
 // tol=gtol, options={"maxiter": maxiter}) would.  fn returns 0 and fills (*f, g[n]).
 extern "C" int mg_bfgs_minimize(int (*fn)(void*, int, const double*, double*, double*), void* user, int n, double* x, double gtol,
                                 int maxiter, double* fval, int* nit, int* nfev, int* status) {
-  MG_REQUIRE(fn && x && n >= 1 && n <= 256 && fval && nit && nfev && status, "bfgs_minimize: bad arguments");
+  MG_REQUIRE(fn && x && n >= 1 && fval && nit && nfev && status, "bfgs_minimize: bad arguments");
   Objective o{fn, user, n};
   o.x.resize(n);
   o.g.resize(n);
@@ -514,12 +514,18 @@ const double FD_STEP = 1.4901161193847656e-08;
 int align_objective(void* user, int n, const double* p, double* f, double* g) {
   const AlignCtx& c = *(const AlignCtx*)user;
   const int E = c.E;
-  double s[128], t[128], gs[128], gt[128];
+  std::vector<double> buf((size_t)4 * E);   // any ensemble size (the reference's optimiser has no limit either)
+  double* const s = buf.data();
+  double* const t = s + E;
+  double* const gs = t + E;
+  double* const gt = gs + E;
   for (int i = 0; i < E; ++i) { s[i] = q32(p[i]); t[i] = c.affine ? q32(p[E + i]) : 0.0; }
   double cost;
   if (int rc = mg_ens_align_cost_grad(E, s, t, c.mean, c.C, &cost, gs, gt)) return rc;
   if (c.lam > 0) {
-    float s32[128], t32[128];
+    std::vector<float> fbuf((size_t)3 * E);
+    float* const s32 = fbuf.data();
+    float* const t32 = s32 + E;
     for (int i = 0; i < E; ++i) { s32[i] = (float)s[i]; t32[i] = (float)t[i]; c.st_host[i] = s32[i]; c.st_host[E + i] = t32[i]; }
     if (int rc = mg_launch(c.reg_op, (void*)c.stream)) return rc;
     if (hipStreamSynchronize(c.stream) != hipSuccess) return 3;
@@ -529,10 +535,10 @@ int align_objective(void* user, int n, const double* p, double* f, double* g) {
       const float* draw = c.mm_host + 2 + which * E;
       const double sign = which == 0 ? np_sign(mn) : -np_sign(1.0 - mx);
       if (c.reduction == 0) {   // lower-middle median: which member is it at that pixel? (stable argsort of the fp32 values)
-        float a[128];
-        int order[128];
+        float* const a = t32 + E;
+        std::vector<int> order((size_t)E);
         for (int i = 0; i < E; ++i) { a[i] = draw[i] * s32[i] + t32[i]; order[i] = i; }
-        std::stable_sort(order, order + E, [&](int u, int v) { return a[u] < a[v]; });
+        std::stable_sort(order.begin(), order.end(), [&](int u, int v) { return a[u] < a[v]; });
         const int e = order[(E - 1) / 2];
         gs[e] += c.lam * sign * (double)draw[e];
         gt[e] += c.lam * sign;
@@ -554,7 +560,7 @@ int align_objective(void* user, int n, const double* p, double* f, double* g) {
 extern "C" int mg_ens_align_minimize(const mg_op* reg_op, void* stream, int E, int affine, int reduction, double lam, const double* mean,
                                      const double* C, float* st_host, const float* mm_host, double* x, double gtol, int maxiter,
                                      double* fval, int* nit, int* nfev, int* status) {
-  MG_REQUIRE(E >= 1 && E <= 128 && mean && C && x && fval && nit && nfev && status, "ens_align_minimize: bad arguments");
+  MG_REQUIRE(E >= 1 && mean && C && x && fval && nit && nfev && status, "ens_align_minimize: bad arguments");
   MG_REQUIRE(!(lam > 0) || (reg_op && st_host && mm_host), "ens_align_minimize: the regulariser needs its device pass and host-mapped buffers");
   AlignCtx c{E, affine, reduction, lam, mean, C, reg_op, (hipStream_t)stream, st_host, mm_host};
   const int n = affine ? 2 * E : E;

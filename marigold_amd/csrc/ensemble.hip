@@ -17,13 +17,16 @@
 // All HBM-bound streaming kernels: E*HW*4 B read per pass, coalesced over pixels.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace {
 
 constexpr int EMAX = 32;        // members a thread keeps in registers (selection kernels) / columns per second-moment block
 constexpr int EMAX_LDS = 128;   // members of the LDS-resident selection (33 ... 128: any size the reference's users ask for in
-                                // practice - it warns above 15, script/depth/run.py:143-144)
+                                // practice - it warns above 15, script/depth/run.py:143-144); beyond: depth_median_big_kernel
+                                // (bitwise selection straight from memory - the reference accepts ANY ensemble size)
 constexpr int ENS_BLOCKS = 512;
 
 // grid (nblk, E, column chunks of 32): block (x, i, jc) accumulates columns [32 jc, 32 jc + 32) of row i of the raw
@@ -93,7 +96,8 @@ __global__ __launch_bounds__(256) void depth_stats_kernel(const float* __restric
 // one block; out = [min[E], max[E], mean[E], C[E][E]] (C centred)
 __global__ __launch_bounds__(256) void depth_stats_final_kernel(const double* __restrict__ part, double* __restrict__ out,
                                                                 int E, int nblk, long long HW) {
-  __shared__ double mean_s[EMAX_LDS];
+  // the member means: out[2E ..), written by this (single) block below and read back after the barrier
+  double* const mean_s = out + 2 * E;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < E * 3; idx += 256) {
     const int i = idx / 3, k = idx % 3;
@@ -106,8 +110,9 @@ __global__ __launch_bounds__(256) void depth_stats_final_kernel(const double* __
     }
     if (k == 0) out[i] = v;
     else if (k == 1) out[E + i] = v;
-    else { mean_s[i] = v / (double)HW; out[2 * E + i] = mean_s[i]; }
+    else mean_s[i] = v / (double)HW;
   }
+  __threadfence_block();
   __syncthreads();
   for (int idx = tid; idx < E * E; idx += 256) {
     const int i = idx / E, j = idx % E;
@@ -338,6 +343,83 @@ __global__ __launch_bounds__(256) void depth_median_lds_kernel(const float* __re
   }
 }
 
+// More than 128 members (the reference takes any ensemble size, marigold/util/ensemble.py:39-49): the order statistic of a pixel
+// is found by a bitwise selection over the members' values read straight from memory - 32 counting passes over E values per pixel
+// (monotone float -> uint32 key, most significant bit first), O(32 E) instead of the rank count's O(E^2), no per-pixel storage.
+// Same semantics and outputs as depth_median_kernel: the VALUE of rank (E - 1) / 2 does not depend on how ties are broken.
+__global__ __launch_bounds__(256) void depth_median_big_kernel(const float* __restrict__ d, const float* __restrict__ st,
+                                                               float* __restrict__ med, float* __restrict__ mad,
+                                                               float* __restrict__ blockmm, long long* __restrict__ blockpx,
+                                                               int E, long long HW, int reduction, int has_shift, int aligned) {
+  __shared__ float red[8];
+  __shared__ long long redp[8];
+  const int tid = threadIdx.x;
+  long long pmn = 0, pmx = 0;
+  float mn = 3.0e38f, mx = -3.0e38f;
+  const int k = (E - 1) >> 1;
+  auto key_of = [](float x) { const unsigned b = __float_as_uint(x); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); };
+  auto val_of = [](unsigned key) { return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key); };
+  for (long long p = (long long)blockIdx.x * 256 + tid; p < HW; p += (long long)gridDim.x * 256) {
+    auto aval = [&](int e) {   // reference: depth * s + t as two separately rounded fp32 ops (ensemble.py:112)
+      const float v = d[(long long)e * HW + p];
+      return aligned ? __fadd_rn(__fmul_rn(v, st[e]), has_shift ? st[E + e] : 0.f) : v;
+    };
+    auto select = [&](bool dev_, float centre) {
+      unsigned prefix = 0;
+      int kk = k;
+      for (int bit = 31; bit >= 0; --bit) {
+        const unsigned hi_mask = bit == 31 ? 0u : ~((2u << bit) - 1u);   // the bits already decided
+        int cnt0 = 0;
+        for (int e = 0; e < E; ++e) {
+          const float x = aval(e);
+          const unsigned key = key_of(dev_ ? fabsf(__fsub_rn(x, centre)) : x);
+          cnt0 += ((key & hi_mask) == prefix && !((key >> bit) & 1u)) ? 1 : 0;
+        }
+        if (kk >= cnt0) { kk -= cnt0; prefix |= 1u << bit; }
+      }
+      return val_of(prefix);
+    };
+    float pred, unc = 0.f;
+    if (reduction == 0) {
+      pred = select(false, 0.f);
+      if (mad) unc = select(true, pred);
+    } else {
+      float s = 0.f;
+      for (int e = 0; e < E; ++e) s += aval(e);
+      pred = s / (float)E;
+      if (mad) {
+        float q = 0.f;
+        for (int e = 0; e < E; ++e) { const float dd = aval(e) - pred; q += dd * dd; }
+        unc = sqrtf(q / (float)(E > 1 ? E - 1 : 1));
+      }
+    }
+    if (med) med[p] = pred;
+    if (mad) mad[p] = unc;
+    if (pred < mn) { mn = pred; pmn = p; }
+    if (pred > mx) { mx = pred; pmx = p; }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float omn = __shfl_xor(mn, o), omx = __shfl_xor(mx, o);
+    const long long opmn = __shfl_xor(pmn, o), opmx = __shfl_xor(pmx, o);
+    if (omn < mn || (omn == mn && opmn < pmn)) { mn = omn; pmn = opmn; }
+    if (omx > mx || (omx == mx && opmx < pmx)) { mx = omx; pmx = opmx; }
+  }
+  if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; redp[wave] = pmn; redp[4 + wave] = pmx; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) {
+      if (red[w] < red[0] || (red[w] == red[0] && redp[w] < redp[0])) { red[0] = red[w]; redp[0] = redp[w]; }
+      if (red[4 + w] > red[4] || (red[4 + w] == red[4] && redp[4 + w] < redp[4])) { red[4] = red[4 + w]; redp[4] = redp[4 + w]; }
+    }
+    blockmm[2 * blockIdx.x] = red[0];
+    blockmm[2 * blockIdx.x + 1] = red[4];
+    blockpx[2 * blockIdx.x] = redp[0];
+    blockpx[2 * blockIdx.x + 1] = redp[4];
+  }
+}
+
 // out = [min, max, d[0..E)[argmin px], d[0..E)[argmax px]]  (raw member values at the extremal
 // pixels of the prediction: the host derives the exact sub-gradient of the regulariser from them)
 __global__ __launch_bounds__(64) void minmax_final_kernel(const float* __restrict__ blockmm,
@@ -430,8 +512,9 @@ int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
     case MG_OP_ENS_DEPTH_STATS: {
       const int E = op->i[0];
       const long long HW = op->l[0];
-      MG_REQUIRE(E >= 1 && E <= EMAX_LDS, "ens_depth_stats: E %d out of range [1,%d]", E, EMAX_LDS);
-      const int nblk = (int)min((HW + 255) / 256, (long long)128);
+      MG_REQUIRE(E >= 1 && E <= 65535, "ens_depth_stats: E %d out of range [1,65535]", E);
+      // (the partial table is nblk x E x (E + 3) doubles: fewer pixel blocks for the ensembles beyond the kernels' usual range)
+      const int nblk = (int)min((HW + 255) / 256, (long long)(E > 256 ? 32 : 128));
       MG_LAUNCH(depth_stats_kernel, dim3(nblk, E, (E + EMAX - 1) / EMAX), dim3(256), 0, s, (const float*)op->p[0],
                          (double*)op->p[1], E, HW);
       MG_LAUNCH(depth_stats_final_kernel, dim3(1), dim3(256), 0, s, (const double*)op->p[1],
@@ -441,10 +524,14 @@ int mg_launch_ensemble(const mg_op* op, hipStream_t s) {
     case MG_OP_ENS_DEPTH_MEDIAN: {
       const int E = op->i[0];
       const long long HW = op->l[0];
-      MG_REQUIRE(E >= 1 && E <= EMAX_LDS, "ens_depth_median: E %d out of range [1,%d]", E, EMAX_LDS);
+      MG_REQUIRE(E >= 1, "ens_depth_median: E %d must be >= 1", E);
       MG_REQUIRE(op->p[4] && op->p[5], "ens_depth_median: minmax / scratch missing");
       const int nblk = (int)min((HW + 255) / 256, (long long)ENS_BLOCKS);
-      if (E > EMAX) {
+      if (E > EMAX_LDS) {
+        MG_LAUNCH(depth_median_big_kernel, dim3(nblk), dim3(256), 0, s, (const float*)op->p[0], (const float*)op->p[1],
+                  (float*)op->p[2], (float*)op->p[3], (float*)op->p[5], (long long*)((char*)op->p[5] + 8 * ENS_BLOCKS), E,
+                  op->l[0], op->i[1], op->i[2], op->p[1] != nullptr);
+      } else if (E > EMAX) {
         const size_t lds = ((size_t)E * 256 + 2 * E) * sizeof(float);
         static bool attr = false;
         if (!attr && !g_dry_run) {
@@ -516,13 +603,28 @@ double np_pairwise_sum(const double* a, int n) {
   n2 -= n2 % 8;
   return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
 }
+// np.add.reduce over a contiguous run of n doubles: numpy hands its inner loop at most `bufsize` (8192) elements at a time and
+// adds each piece's pairwise sum to the running result (numpy 2.2; checked against ndarray.sum() for n on both sides of 8192) -
+// the pair costs of more than 128 members are more than one piece
+double np_sum(const double* a, int n) {
+  double res = 0.;
+  for (int i = 0; i < n; i += 8192) res += np_pairwise_sum(a + i, n - i < 8192 ? n - i : 8192);
+  return res;
+}
 }  // namespace
 
 extern "C" int mg_ens_align_cost_grad(int E, const double* s, const double* t, const double* mean, const double* C,
                                       double* cost, double* gs, double* gt) {
-  MG_REQUIRE(E >= 1 && E <= 128 && s && t && mean && C && cost && gs && gt, "ens_align_cost_grad: bad arguments");
-  double u[128], s2d[128], sdc[128];
-  static thread_local double r[128 * 128], w[128 * 128], tmp[128 * 128];
+  MG_REQUIRE(E >= 1 && s && t && mean && C && cost && gs && gt, "ens_align_cost_grad: bad arguments");
+  // scratch: 3 E + 3 E^2 doubles, kept per thread (the optimiser calls this ~100 times per map); any ensemble size
+  static thread_local std::vector<double> scratch;
+  if (scratch.size() < (size_t)3 * E + (size_t)3 * E * E) scratch.resize((size_t)3 * E + (size_t)3 * E * E);
+  double* const u = scratch.data();
+  double* const s2d = u + E;
+  double* const sdc = s2d + E;
+  double* const r = sdc + E;
+  double* const w = r + (size_t)E * E;
+  double* const tmp = w + (size_t)E * E;
   for (int i = 0; i < E; ++i) {
     u[i] = s[i] * mean[i] + t[i];
     s2d[i] = (s[i] * s[i]) * C[i * E + i];
@@ -540,15 +642,15 @@ extern "C" int mg_ens_align_cost_grad(int E, const double* s, const double* t, c
   int n = 0;
   for (int i = 0; i < E; ++i)
     for (int j = i + 1; j < E; ++j) tmp[n++] = r[i * E + j];
-  *cost = np_pairwise_sum(tmp, n);
+  *cost = np_sum(tmp, n);
   for (int i = 0; i < E; ++i) {
     for (int j = 0; j < E; ++j) {
       const double du = u[i] - u[j];
       tmp[j] = w[i * E + j] * (((2.0 * sdc[i]) - ((2.0 * s[j]) * C[i * E + j])) + ((2.0 * du) * mean[i]));
     }
-    gs[i] = np_pairwise_sum(tmp, E);
+    gs[i] = np_sum(tmp, E);
     for (int j = 0; j < E; ++j) tmp[j] = (w[i * E + j] * 2.0) * (u[i] - u[j]);
-    gt[i] = np_pairwise_sum(tmp, E);
+    gt[i] = np_sum(tmp, E);
   }
   return 0;
 }

@@ -31,14 +31,16 @@ def members_per_rank(E, world, offset=0):
     return [shard_members(E, world, r, offset) for r in range(world)]
 
 
-def gather_members(local, E, chw, device, group=None, root=None, offset=0, dtype=torch.float32):
+def gather_members(local, E, chw, device, group=None, root=None, offset=0, dtype=torch.float32, force=False):
     """Collect every rank's member predictions into [E, C, H, W] in member order.
 
     root=None -> all ranks receive the full stack (all_gather); root=k -> only rank k does
     (returns None elsewhere).  Uneven shards are padded to ceil(E / world) rows for the collective.
+    ``force``: run the collective even in a group of ONE rank (a gather to self) - how the RCCL code path is
+    executed and tested on a single GPU (bench.py MARIGOLD_BENCH_FORCE_DIST=1).
     """
     G, r = world_size(group), rank(group)
-    if G == 1:
+    if G == 1 and not (force and is_on(group)):
         return local
     per = (E + G - 1) // G
     out_device = device

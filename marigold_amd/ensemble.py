@@ -42,21 +42,15 @@ _FD_STEP = 1.4901161193847656e-08   # scipy's forward-difference step (sqrt(eps)
 
 
 NATIVE_BFGS = os.environ.get("MARIGOLD_ENS_NATIVE_BFGS", "1") != "0"   # 0: scipy drives the alignment (A/B, parity of the native optimiser)
-MAX_ENSEMBLE_SIZE = 128   # depth / IID selection kernels: <= 32 members in registers, 33 ... 128 in LDS (csrc/ensemble.hip)
-
-
-def _check_members(E):
-    """The reference accepts any ensemble size (it warns above 15, script/depth/run.py:143-144); the per-pixel order
-    statistics of the depth / IID paths hold the members in registers (<= 32) or LDS (<= 128) - a larger ensemble is
-    refused here by name instead of by a launch error.  ``ensemble_normals`` loops over the members: no limit."""
-    if E > MAX_ENSEMBLE_SIZE:
-        raise ValueError(f"ensemble_size {E} exceeds the {MAX_ENSEMBLE_SIZE} members the HIP ensembling kernels support")
+# Any ensemble size, like the reference (marigold/util/ensemble.py:39-49; script/depth/run.py:143-144 only warns above 15): the
+# per-pixel order statistics hold <= 32 members in registers, 33 ... 128 in LDS, and beyond that select bitwise over the members
+# in memory (csrc/ensemble.hip::depth_median_big_kernel); ``ensemble_normals`` loops over the members.
+MAX_ENSEMBLE_SIZE = None
 
 
 def _check_depth_args(depth, reduction, scale_invariant, shift_invariant):
     if depth.dim() != 4 or depth.shape[1] != 1:
         raise ValueError(f"Expecting 4D tensor of shape [B,1,H,W]; got {depth.shape}.")
-    _check_members(depth.shape[0])
     if reduction not in ("mean", "median"):
         raise ValueError(f"Unrecognized reduction method: {reduction}.")
     if not scale_invariant and shift_invariant:
@@ -320,7 +314,6 @@ def ensemble_iid(targets, output_uncertainty=False, reduction="median"):
     if reduction not in ("median", "mean"):
         raise ValueError(f"Unrecognized reduction method: {reduction}.")
     E = targets.shape[0]
-    _check_members(E)
     n = targets[0].numel()
     t = targets.to(torch.float32).contiguous()
     dev = t.device

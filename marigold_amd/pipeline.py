@@ -86,6 +86,16 @@ class _MarigoldPipelineBase:
     # predictions - are fp32 like the reference's default pipeline (script/depth/run.py:203-215 loads fp32 unless
     # --fp16); the engine's boundary convolutions convert them on the fly, so nothing is rounded to bf16 on the way in.
     io_dtype = torch.float32
+    # The reference draws the initial latents and the LCM per-step noise in the MODEL dtype (:430-435:
+    # ``torch.randn(..., dtype=self.dtype, generator=generator)``): a pipeline loaded with
+    # ``from_pretrained(torch_dtype=torch.float16 | torch.bfloat16)`` (script/depth/run.py:203-214, ``--fp16``) consumes the
+    # generator as 16-bit draws - a different random stream from the fp32 one.  ``noise_dtype`` reproduces that choice:
+    # fp32 by default (the reference's default load), the caller's ``torch_dtype`` when one was given; the draws are
+    # widened to fp32 on their way into the engine's latent buffers (exact for both 16-bit types).
+    noise_dtype = torch.float32
+
+    def _randn(self, shape, generator):
+        return torch.randn(tuple(shape), device=self.device, dtype=self.noise_dtype, generator=generator).to(self.io_dtype)
 
     def to(self, device):
         self.unet.to(device)
@@ -103,11 +113,17 @@ class _MarigoldPipelineBase:
     def set_progress_bar_config(self, **kw):
         pass
 
-    def enable_member_parallel(self, group=None, root=None):
-        """Shard ensemble members over the ranks of ``group`` (torch.distributed; RCCL on GPUs)."""
+    def enable_member_parallel(self, group=None, root=None, force_collective=False):
+        """Shard ensemble members over the ranks of ``group`` (torch.distributed; RCCL on GPUs).  ``force_collective``:
+        take the sharded path - full-E noise draw sliced by member, ONE gather - even in a group of one rank (the RCCL
+        path on a single GPU; results are those of the plain path bit for bit)."""
         self._member_group = group
         self._member_parallel = True
         self._member_root = root
+        self._member_force = bool(force_collective) and mdist.is_on(group)
+
+    def _sharded(self):
+        return self._member_parallel and (mdist.world_size(self._member_group) > 1 or getattr(self, "_member_force", False))
 
     # ---- reference methods -------------------------------------------------------------------
     def _check_inference_step(self, n_step: int) -> None:
@@ -161,8 +177,7 @@ class _MarigoldPipelineBase:
         rgb_latent = self.encode_rgb(rgb_in)                       # [1|B,4,h,w] fp32
         h, w = rgb_latent.shape[-2:]
         if init_latents is None:
-            target_latent = torch.randn((B, self._target_latent_channels, h, w), device=device, dtype=self.io_dtype,
-                                        generator=generator)
+            target_latent = self._randn((B, self._target_latent_channels, h, w), generator)
         else:
             target_latent = init_latents.to(device)
         if self.empty_text_embed is None:
@@ -176,7 +191,7 @@ class _MarigoldPipelineBase:
             if step_noises is not None:
                 nz.copy_(step_noises[k])
             else:
-                nz.copy_(torch.randn(nz.shape, device=device, dtype=self.io_dtype, generator=generator))
+                nz.copy_(self._randn(nz.shape, generator))
         prog.run()
         return self._decode(prog.x)
 
@@ -188,23 +203,21 @@ class _MarigoldPipelineBase:
         E = ensemble_size
         members = list(range(E))
         step_noises_all = None
-        if self._member_parallel and mdist.world_size(self._member_group) > 1:
+        if self._sharded():
             # every rank draws the full [E,4,h,w] noise (same generator state) and keeps its slice, so results do not depend on
             # the number of GPUs: they are what ONE process draws when its batch holds all E members (batch_size >= E, the
             # default on this hardware).  With a smaller batch_size the reference draws batch by batch (:281-289), and so
             # does the single-process path below - the reference's own results depend on the batch size in that case
             if init_latents is None:
                 hh, ww = self._latent_hw(rgb_norm.shape[-2:])
-                init_latents = torch.randn((E, self._target_latent_channels, hh, ww), device=self.device, dtype=self.io_dtype,
-                                           generator=generator)
+                init_latents = self._randn((E, self._target_latent_channels, hh, ww), generator)
             # the LCM scheduler consumes the generator once per non-final step (:466-468): those draws are made for
             # all E members on every rank too, in the order a single process holding the E members in one batch makes
             # them (initial latents, then one [E,...] draw per step), and sliced by member
             self.scheduler.set_timesteps(denoising_steps)
             n_noise = sum(bool(self.scheduler.needs_noise(i)) for i in range(denoising_steps))
             if n_noise:
-                step_noises_all = [torch.randn(tuple(init_latents.shape), device=self.device, dtype=self.io_dtype,
-                                               generator=generator) for _ in range(n_noise)]
+                step_noises_all = [self._randn(init_latents.shape, generator) for _ in range(n_noise)]
             members = mdist.shard_members(E, mdist.world_size(self._member_group),
                                           mdist.rank(self._member_group))
         preds = []
@@ -215,7 +228,7 @@ class _MarigoldPipelineBase:
             nzs = None if step_noises_all is None else [nz[idx] for nz in step_noises_all]
             preds.append(self.single_infer(rgb, denoising_steps, generator, False, lat, step_noises=nzs))
         local = torch.cat(preds, dim=0) if preds else None
-        if self._member_parallel and mdist.world_size(self._member_group) > 1:
+        if self._sharded():
             C = self._pred_channels
             # decoded maps are latent size x 2^(levels-1), which is smaller than the image when its size is not a
             # multiple of 8 (KITTI 1242x375 -> 768x231 -> latent 96x28 -> decoded 768x224); ranks without members
@@ -223,7 +236,7 @@ class _MarigoldPipelineBase:
             f = 2 ** (len(self.vae.config.block_out_channels) - 1)
             hh, ww = (f * d for d in self._latent_hw(rgb_norm.shape[-2:]))
             return mdist.gather_members(local, E, (C, hh, ww), self.device, self._member_group,
-                                        getattr(self, "_member_root", None))
+                                        getattr(self, "_member_root", None), force=getattr(self, "_member_force", False))
         return local
 
     def _latent_hw(self, hw):

@@ -35,10 +35,10 @@ def run(device="cuda:0"):
                 color_map=None, show_progress_bar=False, init_latents=lat0[:1])
     e1 = omet.affine_invariant_depth_errors(members[0, 0].numpy(), out1.depth_np)
     print(f"[smoke] depth 64x128 E=1 T=2 vs CPU oracle: {e1}")
-    assert e1["rmse"] < 0.02, e1
+    assert e1["rmse"] < 8.5e-3 and e1["delta1"] > 0.99, e1   # measured 2.76e-3 / 0.9988 (GPUTEST_r04): 3x
     # E=2 ensemble: the reference's shift optimiser stops where its fp32 noise does (ensemble.py
     # docstring), so the ensembled maps agree loosely on these random-weight members
     err = omet.affine_invariant_depth_errors(ref.squeeze().numpy(), out.depth_np)
     print(f"[smoke] depth 64x128 E=2 T=2 vs CPU oracle: {err}")
-    assert err["rmse"] < 0.08 and err["scale"] > 0.5, err
+    assert err["rmse"] < 1.7e-2 and err["delta1"] > 0.98 and abs(err["scale"] - 1.0) < 0.02, err   # measured 5.7e-3 / 0.9973 / 0.9989: 3x
     return err

@@ -54,7 +54,8 @@ def test_c1_config_vs_cpu_oracle(full):
     ref, _, _ = opipe.predict("depth", ounet, ovae, ODDIM(**kw), img, lat0, full["ctx"], 1)
     m = omet.affine_invariant_depth_errors(ref.squeeze().numpy(), out.depth_np)
     print(f"[parity] C1 full-size depth 384x512 T=1 E=1 vs fp32 CPU oracle: {m}")
-    assert m["rmse"] < 0.03 and m["delta1"] > 0.95, m
+    # measured (profiles/r4_*, four builds): rmse 1.65e-3, delta1 0.99998-0.999995 -> bounds at 3x the measured error
+    assert m["rmse"] < 5e-3 and m["delta1"] > 0.999 and abs(m["scale"] - 1.0) < 3e-3, m
 
 
 def test_768_properties(full):

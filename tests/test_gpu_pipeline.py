@@ -326,6 +326,18 @@ def test_checkpoint_roundtrip_from_pretrained(tiny, tmp_path):
                                                          color_map=None, show_progress_bar=False,
                                                          init_latents=lat0[:1]).depth_np
     np.testing.assert_array_equal(a, ref)
+    # A4: with torch_dtype given, the initial latents are drawn in that dtype on the device (reference :430-435) - the prediction
+    # equals the one from caller-supplied latents drawn the same way, and differs from the default (fp32-stream) prediction
+    pb = M.MarigoldDepthPipeline.from_pretrained(path, torch_dtype=torch.bfloat16).to("cuda:0")
+    assert pb.noise_dtype is torch.bfloat16 and pipe.noise_dtype is torch.float32
+    gen = lambda: torch.Generator(device="cuda").manual_seed(77)   # noqa: E731
+    h, w = lat0.shape[-2:]
+    lat_bf = torch.randn((1, 4, h, w), device="cuda", dtype=torch.bfloat16, generator=gen()).float()
+    d_bf = pb(img, ensemble_size=1, color_map=None, show_progress_bar=False, generator=gen()).depth_np
+    d_bf_ref = pipe(img, ensemble_size=1, color_map=None, show_progress_bar=False, init_latents=lat_bf).depth_np
+    d_f32 = pipe(img, ensemble_size=1, color_map=None, show_progress_bar=False, generator=gen()).depth_np
+    np.testing.assert_array_equal(d_bf, d_bf_ref)
+    assert not np.array_equal(d_bf, d_f32)
 
 
 def test_graph_capture_matches_eager(tiny):
@@ -350,7 +362,7 @@ def test_graph_capture_matches_eager(tiny):
 
 
 def test_ensembles_above_32_members():
-    """More members than the register-resident selection holds (33 ... 128 run the LDS form; the reference accepts any
+    """More members than the register-resident selection holds (33 ... 128 run the LDS form, more the bitwise selection; the reference accepts any
     size, script/depth/run.py:143-144): the per-pixel passes against the oracle's torch restatement, the whole
     ensemble_depth against the stand-in backend that drives the same optimiser on the CPU."""
     import scipy.optimize
@@ -362,8 +374,9 @@ def test_ensembles_above_32_members():
     base = torch.rand(1, 1, H, W, generator=g)
     x = (base * (0.5 + torch.rand(E, 1, 1, 1, generator=g)) + 0.2 * torch.rand(E, 1, 1, 1, generator=g)
          + 0.02 * torch.randn(E, 1, H, W, generator=g)).clamp_min(1e-3)
-    # un-aligned median / MAD and mean / std over 40 and 100 members (ensemble_iid = the fused kernel without alignment)
-    for n in (40, 100):
+    # un-aligned median / MAD and mean / std over 40 and 100 members (ensemble_iid = the fused kernel without alignment), and
+    # beyond the LDS form's 128: the bitwise selection from memory (the reference accepts ANY size, ensemble.py:39-49)
+    for n in (40, 100, 129, 300):
         t = torch.rand(n, 3, 16, 24, generator=g)
         for red in ("median", "mean"):
             p, u = ens.ensemble_iid(t.cuda(), output_uncertainty=True, reduction=red)
@@ -381,6 +394,18 @@ def test_ensembles_above_32_members():
     lo, hi = ref.min(), ref.max()
     ref, ref_u = (ref - lo) / (hi - lo).clamp(min=1e-6), ref_u / (hi - lo).clamp(min=1e-6)
     assert (d.cpu() - ref).abs().max() < 1e-5 and (u.cpu() - ref_u).abs().max() < 1e-5
+    # the whole ensemble_depth at 150 members (statistics, native optimiser over 300 parameters, bitwise selection): the aligned
+    # median / MAD against the oracle's restatement with the device's own parameters, scales on the reference's fp32 grid
+    E2 = 150
+    x2 = (base * (0.5 + torch.rand(E2, 1, 1, 1, generator=g)) + 0.2 * torch.rand(E2, 1, 1, 1, generator=g)
+          + 0.02 * torch.randn(E2, 1, H, W, generator=g)).clamp_min(1e-3)
+    d2, u2, info2 = ens.ensemble_depth(x2.cuda(), True, True, output_uncertainty=True, return_info=True, max_iter=5)
+    assert np.array_equal(info2["param"][:E2], info2["aligner"].init_param()[:E2])
+    a2 = oens.depth_align(x2.float(), info2["param"], True, True)
+    ref2, ref2_u = oens.depth_reduce(a2, "median", True)
+    lo2, hi2 = ref2.min(), ref2.max()
+    ref2, ref2_u = (ref2 - lo2) / (hi2 - lo2).clamp(min=1e-6), ref2_u / (hi2 - lo2).clamp(min=1e-6)
+    assert (d2.cpu() - ref2).abs().max() < 1e-5 and (u2.cpu() - ref2_u).abs().max() < 1e-5
     nrm = torch.nn.functional.normalize(torch.randn(40, 3, 16, 16, generator=g), dim=1)
     o, un = ens.ensemble_normals(nrm.cuda(), output_uncertainty=True)
     ro, ru = oens.ensemble_normals(nrm, output_uncertainty=True)
@@ -479,6 +504,82 @@ def test_member_parallel_two_ranks_share_one_gpu(hw):
     m = omet.affine_invariant_depth_errors(ref, got)
     print(f"[parity] 2-rank member-parallel vs single process: max|diff| {np.abs(ref - got).max():.2e} {m}")
     assert np.abs(ref - got).max() < 2e-2 and m["rmse"] < 5e-3
+
+
+def _nccl_single_rank_worker(port, q):
+    """One rank, backend "nccl" (= RCCL): the member-parallel path with its collective forced (gather to self)."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import marigold_amd as M
+    from marigold_amd import dist as md, synthetic as syn
+    from marigold_amd.arch import TINY_UNET, TINY_VAE
+    try:
+        pipe = M.build_synthetic_pipeline("depth", TINY_UNET, TINY_VAE, default_processing_resolution=0).to("cuda:0")
+        img = syn.synthetic_image(64, 128, seed=0)
+        kw = dict(denoising_steps=2, ensemble_size=3, processing_res=0, color_map=None, show_progress_bar=False)
+        ref = pipe(img, generator=torch.Generator(device="cuda:0").manual_seed(5), **kw).depth_np
+        pipe.enable_member_parallel(root=0, force_collective=True)
+        assert pipe._sharded()
+        got = pipe(img, generator=torch.Generator(device="cuda:0").manual_seed(5), **kw).depth_np
+        # the collective itself: rooted gather and all_gather of a member stack on the RCCL backend
+        x = torch.rand(3, 1, 16, 24, device="cuda:0")
+        a = md.gather_members(x, 3, (1, 16, 24), torch.device("cuda:0"), None, 0, force=True)
+        b = md.gather_members(x, 3, (1, 16, 24), torch.device("cuda:0"), None, None, force=True)
+        q.put((dist.get_backend(), ref, got, bool(a is not x and torch.equal(a, x) and torch.equal(b, x))))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_member_parallel_nccl_single_rank():
+    """The RCCL code path on ONE GPU (no second device here, and RCCL cannot put two ranks on one device):
+    ``init_process_group("nccl", device_id=...)`` with world_size 1, ``enable_member_parallel(force_collective=True)`` - the
+    full-E noise draw sliced by member, the rooted ``dist.gather`` to self on the nccl backend - gives the plain
+    single-process map bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single_rank_worker, args=(port, q))
+    p.start()
+    backend, ref, got, coll_ok = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert backend == "nccl" and coll_ok
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_bench_nccl_path_single_rank(tmp_path):
+    """bench.py under ``python -m torch.distributed.run --nproc-per-node 1`` with MARIGOLD_BENCH_FORCE_DIST=1: the launch
+    line the driver uses for N > 1, the nccl process group, member-parallel pipeline, gather, max-over-ranks all-reduce of
+    the timing - executed end to end on one GPU (tiny architecture: the plumbing is what is under test)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--tiny",
+           "--res", "128", "--ensemble", "3", "--denoise", "2", "--no-cpu-baseline"]
+    env = dict(os.environ, MARIGOLD_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["collective"] == {"backend": "nccl", "world_size": 1, "forced_single_rank": True, "gathers_per_map": 1}
+    assert "gather" in line["stages"] and line["stages"]["gather"]["ms"] > 0
+    print(f"[parity] bench.py under torchrun, nccl world 1: {line['ms_per_step']} ms/step, gather {line['stages']['gather']}")
 
 
 def test_iid_pipeline_vs_oracle(tiny, tmp_path):

@@ -201,12 +201,77 @@ def test_ensemble_argument_validation_without_gpu():
         ens.ensemble_normals(torch.rand(3, 2, 8, 8))
     with pytest.raises(ValueError):
         ens.ensemble_normals(torch.rand(3, 3, 8, 8), reduction="median")
-    # the depth / IID order statistics hold <= 128 members (registers up to 32, LDS beyond): larger ensembles are refused
-    # by name, after the shape checks; ensemble_normals has no limit
-    with pytest.raises(ValueError, match="exceeds the 128 members"):
-        ens.ensemble_depth(torch.rand(129, 1, 8, 8), True, True)
+    # like the reference (marigold/util/ensemble.py:39-49) no ensemble size is refused: the shape checks are the only ones
+    assert ens.MAX_ENSEMBLE_SIZE is None
     with pytest.raises(ValueError, match="Expecting 4D tensor"):
         ens.ensemble_depth(torch.rand(200, 8, 8), True, True)
+
+
+def test_alignment_host_arithmetic_any_ensemble_size():
+    """mg_ens_align_cost_grad (the E x E closed form of the pairwise cost, numpy's summation order included) against the numpy
+    form it restates, bit for bit, beyond the 128 members the first version's fixed arrays held; and the native optimiser on an
+    objective of more than 256 variables."""
+    import ctypes
+    from marigold_amd import ensemble as ens, _lib as L
+
+    class _Stats:
+        def __init__(self, E, g):
+            x = torch.rand(E, 64, generator=g, dtype=torch.float64) + 0.1 * torch.arange(E, dtype=torch.float64)[:, None] / E
+            self.m = x.mean(1).numpy()
+            xc = x - x.mean(1, keepdim=True)
+            self.C = (xc @ xc.T / 64).numpy()
+            self.lo, self.hi = x.min(1).values.numpy(), x.max(1).values.numpy()
+
+        def stats(self):
+            return self.lo, self.hi, self.m, self.C
+
+    g = torch.Generator().manual_seed(3)
+    for E in (7, 129, 200):
+        al = ens.DepthAligner(torch.zeros(E, 1, 2, 2), True, True, "median", 0.0, backend=_Stats(E, g))
+        p = al.init_param() * (1.0 + 0.01 * np.random.RandomState(E).rand(2 * E))
+        c1, g1 = al.cost_and_grad(p)
+        c2, g2 = al.cost_and_grad_numpy(p)
+        assert c1 == c2 and np.array_equal(g1, g2), E
+    # the optimiser itself has no size limit either: a 300-variable convex quadratic ends at its minimum
+    n = 300
+    FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                          ctypes.POINTER(ctypes.c_double))
+    w = 1.0 + np.arange(n) / n
+
+    def fn(_u, nn, x, f, gr):
+        xv = np.ctypeslib.as_array(x, (nn,))
+        f[0] = float(0.5 * np.sum(w * (xv - 1.0) ** 2))
+        np.ctypeslib.as_array(gr, (nn,))[:] = w * (xv - 1.0)
+        return 0
+    cb = FN(fn)
+    x = np.zeros(n)
+    fval, nit, nfev, status = ctypes.c_double(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    rc = L.load().mg_bfgs_minimize(ctypes.cast(cb, ctypes.c_void_p), None, n, x.ctypes.data, 1e-8, 500, ctypes.byref(fval),
+                                   ctypes.byref(nit), ctypes.byref(nfev), ctypes.byref(status))
+    assert rc == 0 and status.value == 0 and np.abs(x - 1.0).max() < 1e-6
+
+
+def test_gather_members_forced_in_a_group_of_one():
+    """``force=True`` runs the collective in a one-rank group (how the RCCL path is executed on a single GPU,
+    bench.py MARIGOLD_BENCH_FORCE_DIST=1); here on gloo: rooted gather and all_gather to self return the members."""
+    import socket
+    import torch.distributed as dist
+    from marigold_amd import dist as md
+    x = torch.rand(3, 1, 4, 6)
+    assert md.gather_members(x, 3, (1, 4, 6), torch.device("cpu"), force=True) is x   # no process group: nothing to force
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert md.gather_members(x, 3, (1, 4, 6), torch.device("cpu")) is x
+        for root in (None, 0):
+            got = md.gather_members(x, 3, (1, 4, 6), torch.device("cpu"), None, root, force=True)
+            assert got is not x and torch.equal(got, x)
+    finally:
+        dist.destroy_process_group()
 
 
 def _gloo_worker(rank, world, port, E, q):
@@ -564,6 +629,28 @@ def test_encode_empty_text_with_a_real_text_encoder(tmp_path):
     pipe.unet.set_context(emb)            # accepted as the 2-token context; any other length is refused
     with pytest.raises(ValueError, match="2-token context"):
         pipe.unet.set_context(torch.zeros(1, 77, 64))
+
+
+def test_noise_draws_follow_the_loaded_dtype(tmp_path):
+    """A4 (marigold_depth_pipeline.py:430-435): the reference draws the initial latents (and the LCM per-step noise) with
+    ``dtype=self.dtype`` - fp32 for the default load, 16-bit draws for ``from_pretrained(torch_dtype=torch.float16 |
+    torch.bfloat16)`` (script/depth/run.py:203-214), a DIFFERENT random stream.  ``noise_dtype`` follows the loader's
+    ``torch_dtype``; the draws reach the engine widened to fp32."""
+    import marigold_amd as M
+    path = _tiny_checkpoint(tmp_path, with_text_encoder=False)
+    shape = (3, 4, 8, 16)
+    draws = {}
+    for dt in (None, torch.float32, torch.float16, torch.bfloat16):
+        pipe = M.MarigoldDepthPipeline.from_pretrained(path, torch_dtype=dt)
+        want_dt = torch.float32 if dt in (None, torch.float32) else dt
+        assert pipe.noise_dtype is want_dt
+        got = pipe._randn(shape, torch.Generator().manual_seed(5))
+        want = torch.randn(shape, dtype=want_dt, generator=torch.Generator().manual_seed(5))
+        assert got.dtype == torch.float32 and torch.equal(got, want.float())
+        draws[want_dt] = got
+    assert not torch.equal(draws[torch.float32], draws[torch.bfloat16])   # not the fp32 stream rounded: another stream
+    with pytest.raises(ValueError, match="torch_dtype"):
+        M.MarigoldDepthPipeline.from_pretrained(path, torch_dtype=torch.float64)
 
 
 def test_checkpoint_configs_are_validated_strictly(tmp_path):
