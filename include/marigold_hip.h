@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 3
+#define MG_ABI_VERSION 4
 
 enum mg_op_kind {
   /* conv3x3 / conv1x1 / Linear / batched GEMM as ONE implicit-GEMM bf16 MFMA kernel.
@@ -103,9 +103,6 @@ enum mg_op_kind {
    *  1280 (the deeper levels): the K-split kernel - 32-row workgroups whose four waves split K and the output channels,
    *  p[1] = weights.pack_rowgemm_xattn_ksplit.  p[8] (tuning only): per-wave phase cycle stamps | NULL. */
   MG_OP_ROWGEMM = 10,
-  /* LayerNorm over the last dim. p[0] x bf16 [M][C] p[1] gamma f32 p[2] beta f32 p[3] out;
-   * i: M,C ; f[0] eps */
-  MG_OP_LAYERNORM = 5,
   /* Self-attention core, head dim 64, bf16 MFMA flash attention with LDS-staged K / V^T
    * tiles (replaces diffusers Attention / SDPA / xformers, run.py:217-220).
    *  p[0] Q bf16 (row stride ldq)  p[1] K (row stride ldq)  p[2] Vt bf16 [B][heads*64][ldvt]
@@ -127,17 +124,12 @@ enum mg_op_kind {
    *  up to 32, pad columns zero)  p[3] O bf16 (row stride ldo); i: B, Ntok, ldq, ldo, ldvt ;
    *  l[0] q batch stride l[1] k batch stride l[2] vt batch stride l[3] o batch stride ; f[0] softmax scale */
   MG_OP_FLASH_ATTN512 = 11,
-  /* Row softmax fp32 -> bf16 (VAE single-head d=512 attention, materialised scores).
+  /* Row softmax fp32 -> bf16 (single-head attention of a width other than 512, materialised scores; the collapsed 2-token
+   * cross-attention of marigold_depth_pipeline.py:381-394, 438-442 needs no softmax op: scores = LN(x) Wqk^T with
+   * Wqk[(h,j)] = Wq_h^T k_{j,h}, p = softmax over the key pair, out = p VO + bias + x with VO[(h,j)] = Wo[:,h] v_{j,h} run as
+   * MG_EPI_XATTN2 / MG_OP_ROWGEMM form 3).
    *  p[0] S f32 [R][lds] p[1] P bf16 [R][ldp] ; i: R, ncols, lds, ldp (pad cols zeroed) */
   MG_OP_SOFTMAX_ROWS = 7,
-  /* Pairwise softmax for cross-attention against the 2-token empty-prompt context
-   * (marigold_depth_pipeline.py:381-394, 438-442).  With only 2 keys per head the attention
-   * collapses algebraically to  scores = LN(x) @ Wqk^T  (Wqk[(h,j)] = Wq_h^T k_{j,h}),
-   * p = softmax over the key pair, out = p @ VO + bias + x  (VO[(h,j)] = Wo[:,h] v_{j,h});
-   * the two thin GEMMs run on MG_OP_IGEMM, this op is the softmax between them.
-   *  p[0] S f32 [M][lds]  p[1] P bf16 [M][ldp] ; i: M, pairs(=heads), lds, ldp ;
-   *  f[0] softmax scale.  Columns >= 2*pairs of P are zero-filled up to ldp. */
-  MG_OP_SOFTMAX_PAIRS = 8,
   /* Scheduler update (DDIM / LCM, diffusers *.step at marigold_depth_pipeline.py:466-468):
    * out = f[0]*x + f[1]*model_out + f[2]*noise.  p[0] x f32 p[1] model_out f32
    * p[2] noise f32 | NULL  p[3] out f32 ; l[0] n elements */

@@ -9,11 +9,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MARIGOLD_HIP_LIB") or os.path.join(_HERE, "libmarigold_hip.so")   # (override: same-box A/B of two builds)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enum mg_op_kind
-OP_IGEMM, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_LAYERNORM = 1, 2, 3, 4, 5
-OP_FLASH_ATTN64, OP_SOFTMAX_ROWS, OP_SOFTMAX_PAIRS = 6, 7, 8
+OP_IGEMM, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY = 1, 2, 3, 4
+OP_FLASH_ATTN64, OP_SOFTMAX_ROWS = 6, 7
 OP_GN_SLAB = 9
 OP_ROWGEMM = 10
 OP_FLASH_ATTN512 = 11

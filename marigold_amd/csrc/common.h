@@ -149,6 +149,9 @@ extern void* g_splitk_ws;  // fp32 partial sums of split-K GEMM launches (mg_ini
     if (!g_dry_run) hipLaunchKernelGGL(__VA_ARGS__);     \
   } while (0)
 void mg_set_error(const char* fmt, ...);
+// Tuning switch `name` (an environment variable) if MARIGOLD_TUNING=1, else `dflt`: the library's only access to the
+// environment (runtime.hip).  Deployments run the compiled-in defaults.
+int mg_tuning_int(const char* name, int dflt);
 #define MG_CHECK_HIP(expr)                                                         \
   do {                                                                             \
     hipError_t _e = (expr);                                                        \

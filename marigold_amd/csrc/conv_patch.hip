@@ -475,7 +475,7 @@ int mg_conv3x3_auto_variant(int N, int subpix, int B, int H, int W, int has_ss, 
     // 1 141 vs 1 078; at 320 -> 320 the in-stream fix-up costs what the schedule gains); 16 x 16 x 256 for the plain
     // N = 256 k convolutions (512 -> 512 @96: 1 202 vs 1 050) and the 512-channel sub-pixel up-sampling (1 104 vs 1 031).
     // MARIGOLD_CP4W=0 switches them off (A/B).
-    static const int cp4 = [] { const char* e = getenv("MARIGOLD_CP4W"); return e ? atoi(e) : 1; }();
+    static const int cp4 = mg_tuning_int("MARIGOLD_CP4W", 1);
     const long long par = subpix ? 4 : 1;
     if (cp4 && allow4w && N % 320 == 0 && !subpix && (long long)B * ((H + 11) / 12) * ((W + 15) / 16) * (N / 320) >= 200 &&
         (!has_ss || (Cin >= 640 && Cin <= 1024)))
@@ -483,7 +483,7 @@ int mg_conv3x3_auto_variant(int N, int subpix, int B, int H, int W, int has_ss, 
     if (cp4 && allow4w && N % 256 == 0 && !has_ss && (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * (N / 256) * par >= 512 && (!subpix || N >= 512))
       return 10;
   }
-  static const int n320 = [] { const char* e = getenv("MARIGOLD_PATCH_N320"); return e ? atoi(e) : 0; }();   // A/B: 3 = the round-2 choice
+  static const int n320 = mg_tuning_int("MARIGOLD_PATCH_N320", 0);   // A/B: 3 = the round-2 choice
   const bool old = n320 == 3;
   // N = 256 / 512 (VAE): 12 x 16 x 256 on 12 waves (wave tile 64 x 64) where the GroupNorm is fused / the map is large
   // (512 -> 512 @192 with the fused norm: 668 vs 758 us; 256 -> 256 @384: 712 vs 741; plain @96: equal); the sub-pixel forms stay

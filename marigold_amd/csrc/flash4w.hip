@@ -359,7 +359,7 @@ void mg_flash4w_plan(FaArgs* a, int n_cu) {
   a->n_full = (int)nb;
   a->n_rem = 0;
   a->n_rem_wg = 0;
-  static const int split = [] { const char* e = getenv("MARIGOLD_FLASH4W_SPLIT"); return e ? atoi(e) : 1; }();
+  static const int split = mg_tuning_int("MARIGOLD_FLASH4W_SPLIT", 1);
   if (split && a->split != 2 && a->ws && nb % n_cu != 0 && (a->split == 1 || (nb > n_cu && (nb % n_cu) * 8 <= n_cu))) {
     const long long rem = nb % n_cu;
     const long long cap = (a->ws_bytes - F4_CTR_BYTES) / ((long long)F4_PIECES * F4_PART_BYTES);

@@ -119,7 +119,7 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
     // passes with it) but 25 ms per map SLOWER (igemm 110.5 -> 135.5 ms, profiles/r4_ab_splitk_fused.log): ONE workgroup then
     // reads splits x 256 KB of slabs per tile at the 60-100 GB/s a single workgroup gets, on the launch's critical path, where
     // the reduce launch spreads the same bytes over the whole chip in 13 us.
-    static const int fused = [] { const char* e = getenv("MARIGOLD_SPLITK_FUSED"); return e ? atoi(e) : 0; }();
+    static const int fused = mg_tuning_int("MARIGOLD_SPLITK_FUSED", 0);
     const bool fuse = fused && g_sk_counters && tiles <= MG_SK_COUNTERS;
     const long long per_split = fuse ? tiles * BM * BN * 4 : (long long)a.M * a.N * 4;
     while (sp > 1 && (long long)sp * per_split > MG_SPLITK_WS_BYTES) --sp;
@@ -260,7 +260,7 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.tw = a.taps == 9 ? 3 : (a.taps == 4 ? 2 : 1);
   a.subpix = a.taps == 4;
   {   // split-K only under the automatic tile choice (tuning sweeps: MARIGOLD_IGEMM_SPLITK_ANY=1 lets a forced tile split too)
-    static const int any = [] { const char* e = getenv("MARIGOLD_IGEMM_SPLITK_ANY"); return (e && e[0] == '1') ? 1 : 0; }();
+    static const int any = mg_tuning_int("MARIGOLD_IGEMM_SPLITK_ANY", 0);
     a.splits = (variant && !any) ? -1 : 0;
   }
   a.ln_out = (float2*)op->p[8];
@@ -288,10 +288,7 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   if (a.epi == MG_EPI_SOFTMAX2)
     MG_REQUIRE(trans_from < 0 && batch_z == 1 && a.sm_cols > 0 && a.sm_cols % 2 == 0 && a.sm_cols <= a.N && !a.res,
                "igemm: the pair-softmax epilogue takes an even number of score columns <= N, no residual / transposed section");
-  {
-    static const int erf_ab = [] { const char* e = getenv("MARIGOLD_GELU_ERF"); return (e && e[0] == '1') ? 1 : 0; }();
-    a.gelu_erf = erf_ab;
-  }
+  a.gelu_erf = 0;
   if (a.ln_out && a.epi == MG_EPI_XATTN2) {
     MG_REQUIRE((uintptr_t)a.ln_out % 8 == 0, "igemm: misaligned (mean, rstd) table");
     a.splits = -1;
@@ -403,7 +400,7 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
     // of the 12 row tiles re-reads the 30-59 MB of weights; 256 x 256 tiles read them 6 times and split-K (30 tiles x 8
     // splits) fills the chip: 77 -> 68 us (1280 -> 1280), 144 -> 105 us (2560 -> 1280), profiles/r3_deep_conv_tiles.log.
     // MARIGOLD_DEEP_TILE=<variant> | 0 (off) for A/B runs.
-    static const int deep = [] { const char* e = getenv("MARIGOLD_DEEP_TILE"); return e ? atoi(e) : 72; }();
+    static const int deep = mg_tuning_int("MARIGOLD_DEEP_TILE", 72);
     if (deep && !geglu && batch_z == 1 && M >= 1152 && M <= 2048 && K >= 5760 && N % 256 == 0) return deep;   // (E >= 8 at 12 x 12)
   }
   {
@@ -411,13 +408,13 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
     // whose tile count fits its ONE workgroup per CU - the 24 x 24 level (M = 5 760 at E = 10: 23 x 5 tiles x 2 K splits) and
     // the sub-pixel up-sampling convolutions (4 parities): 2560 -> 1280: 1 237 vs 981 TFLOP/s, 1280 -> 1280: 976 vs 957 with
     // three splits (profiles/r4_k4w_sweep.log).  MARIGOLD_K4W=0 switches it off (A/B).
-    static const int k4w = [] { const char* e = getenv("MARIGOLD_K4W"); return e ? atoi(e) : 1; }();
+    static const int k4w = mg_tuning_int("MARIGOLD_K4W", 1);
     const long long t = ((M + 255) / 256) * (N / 256) * batch_z;
     if (k4w && !geglu && N % 256 == 0 && K >= 4096 && ((batch_z == 1 && t >= 64 && t <= 128) || (t >= 200 && t <= 256) || (t >= 400 && t <= 512) || t >= 720)) return 72;
     // ... and its 192 x 320 sibling (variant 73) for the N = 320 k Linear layers and 1x1 convolutions with at least ten K tiles
     // and a chip's worth of tiles: ff.out of the 96 x 96 level 1280 -> 320: 661 vs 584 TFLOP/s, of the 48 x 48 level
     // 2560 -> 640: 997 vs 841, conv_shortcut 960 -> 320: 608 vs 550, 640 -> 640: 537 vs 506.  MARIGOLD_K4WB=0: off.
-    static const int k4wb = [] { const char* e = getenv("MARIGOLD_K4WB"); return e ? atoi(e) : 1; }();
+    static const int k4wb = mg_tuning_int("MARIGOLD_K4WB", 1);
     const long long tb = ((M + 191) / 192) * (N / 320) * batch_z;
     if (k4w && k4wb && !geglu && N % 320 == 0 && N % 256 != 0 && K >= 640 && tb >= 200) return 73;
   }

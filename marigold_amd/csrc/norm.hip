@@ -381,86 +381,6 @@ int launch_gn_slab(const GnSlabArgs& a, int B, hipStream_t s) {
   return 0;
 }
 
-// LayerNorm over the last dim: one wave per R rows, all R rows' 16-byte loads issued before any
-// reduction (with a single row in flight per wave the kernel sits at ~2.7 TB/s: bytes in flight =
-// waves x 640 B, Little's law).  C <= 64 * 8 * NV.
-template <int NV, int R>
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x,
-                                                        const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta,
-                                                        bf16_t* __restrict__ out, int M, int C,
-                                                        float eps) {
-  constexpr int G = 4;  // row groups per wave: gamma / beta are loaded once per G*R rows
-  const int lane = threadIdx.x & 63;
-  const int cv = C >> 3;
-  float gs[NV][8], bs[NV][8];
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int vc = lane + k * 64;
-    if (vc < cv) {
-      const float4 g0 = *(const float4*)(gamma + vc * 8), g1 = *(const float4*)(gamma + vc * 8 + 4);
-      const float4 b0 = *(const float4*)(beta + vc * 8), b1 = *(const float4*)(beta + vc * 8 + 4);
-      gs[k][0] = g0.x; gs[k][1] = g0.y; gs[k][2] = g0.z; gs[k][3] = g0.w;
-      gs[k][4] = g1.x; gs[k][5] = g1.y; gs[k][6] = g1.z; gs[k][7] = g1.w;
-      bs[k][0] = b0.x; bs[k][1] = b0.y; bs[k][2] = b0.z; bs[k][3] = b0.w;
-      bs[k][4] = b1.x; bs[k][5] = b1.y; bs[k][6] = b1.z; bs[k][7] = b1.w;
-    }
-  }
-  const int wrow0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (G * R);
-  for (int grp = 0; grp < G; ++grp) {
-    const int row0 = wrow0 + grp * R;
-    if (row0 >= M) return;
-    uint4 u[R][NV];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int row = min(row0 + r, M - 1);
-      const bf16_t* xr = x + (long long)row * C;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int vc = lane + k * 64;
-        u[r][k] = vc < cv ? *(const uint4*)(xr + vc * 8) : make_uint4(0, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (row0 + r >= M) break;
-      float v[NV][8];
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        v[k][0] = bflo(u[r][k].x); v[k][1] = bfhi(u[r][k].x); v[k][2] = bflo(u[r][k].y); v[k][3] = bfhi(u[r][k].y);
-        v[k][4] = bflo(u[r][k].z); v[k][5] = bfhi(u[r][k].z); v[k][6] = bflo(u[r][k].w); v[k][7] = bfhi(u[r][k].w);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[k][j];   // padding vectors are zero
-      }
-      const float mean = wave_sum_f(s) / (float)C;
-      float q = 0.f;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        if (lane + k * 64 < cv) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; q += d * d; }
-        }
-      }
-      const float rstd = rsqrtf(wave_sum_f(q) / (float)C + eps);
-      bf16_t* orow = out + (long long)(row0 + r) * C;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int vc = lane + k * 64;
-        if (vc < cv) {
-          float rr[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) rr[j] = (v[k][j] - mean) * rstd * gs[k][j] + bs[k][j];
-          uint4 o;
-          o.x = cvt_pk_bf16_f32(rr[0], rr[1]); o.y = cvt_pk_bf16_f32(rr[2], rr[3]);
-          o.z = cvt_pk_bf16_f32(rr[4], rr[5]); o.w = cvt_pk_bf16_f32(rr[6], rr[7]);
-          *(uint4*)(orow + vc * 8) = o;
-        }
-      }
-    }
-  }
-}
-
 }  // namespace
 
 int mg_launch_norm(const mg_op* op, hipStream_t s) {
@@ -543,20 +463,6 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
         rc = need <= 8 ? launch_gn_slab<256, 8>(a, B, s) : need <= 24 ? launch_gn_slab<256, 24>(a, B, s) : launch_gn_slab<256, 48>(a, B, s);
       }
       if (rc) return rc;
-      break;
-    }
-    case MG_OP_LAYERNORM: {
-      const int M = op->i[0], C = op->i[1];
-      const int cv = C / 8;
-      MG_REQUIRE(C % 8 == 0 && cv <= 256, "layernorm: unsupported C %d (multiple of 8, <= 2048)", C);
-#define LN_LAUNCH(NV, R)                                                                                   \
-  MG_LAUNCH((layernorm_kernel<NV, R>), dim3((M + 16 * R - 1) / (16 * R)), dim3(256), 0, s, (const bf16_t*)op->p[0], \
-            (const float*)op->p[1], (const float*)op->p[2], (bf16_t*)op->p[3], M, C, op->f[0])
-      if (cv <= 64) LN_LAUNCH(1, 4);
-      else if (cv <= 128) LN_LAUNCH(2, 4);
-      else if (cv <= 192) LN_LAUNCH(3, 2);
-      else LN_LAUNCH(4, 2);
-#undef LN_LAUNCH
       break;
     }
     default: MG_REQUIRE(false, "norm: bad op kind %d", op->kind);

@@ -20,25 +20,31 @@ from . import weights as Wm
 from .arch import UNetConfig, VAEConfig, unet_up_resnet_channels
 
 LATENT_SCALE = 0.18215  # marigold_depth_pipeline.py:118
-# A/B switches for tuning runs (defaults are the product configuration)
-USE_PATCH = os.environ.get("MARIGOLD_PATCH_CONV", "1") != "0"      # patch-resident conv3x3 kernel where eligible
-FUSE_GN = os.environ.get("MARIGOLD_FUSE_GN", "auto")               # auto | all | none: GroupNorm apply inside the conv
-FOLD_LN = os.environ.get("MARIGOLD_FOLD_LN", "1") != "0"
-XATTN_FUSED = os.environ.get("MARIGOLD_XATTN_FUSED", "1") != "0"   # collapsed cross-attention as one launch (A/B switch)
-VAE_ATTN_CHUNK_BYTES = int(os.environ.get("MARIGOLD_VAE_ATTN_CHUNK_MB", "0")) << 20   # fp32 scores per launch group; 0 = one batched launch per stage
-# (query chunks whose scores fit the 256 MB Infinity Cache measured no gain: vae.decode 62.1 vs 62.9 ms, profiles/r4_vae_attention_chunks.log)
-GN_BYPRODUCT = os.environ.get("MARIGOLD_GN_BYPRODUCT", "1") != "0"   # GroupNorm partial sums from the producing convolution's epilogue
-UNFUSE_320 = int(os.environ.get("MARIGOLD_UNFUSE_320", "0"))   # > 0: minimum Cin from which the 320-channel level's GroupNorm is NOT fused into its convolution
-VAE_FLASH_SMALL = os.environ.get("MARIGOLD_VAE_FLASH_SMALL", "1") != "0"   # ... also for launches of < 200 query blocks (the encoder)
-VAE_FLASH = os.environ.get("MARIGOLD_VAE_FLASH", "1") != "0"          # VAE mid-block attention as a flash kernel (off: materialised scores)
-IGEMM73_CONV = os.environ.get("MARIGOLD_IGEMM73_CONV", "1") != "0"   # plain N = 320 k convolutions on the hand-placed 192 x 320 GEMM tile
-IGEMM72_VAE = os.environ.get("MARIGOLD_IGEMM72_VAE", "1") != "0"    # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
-GN_SLAB = os.environ.get("MARIGOLD_GN_SLAB", "1") != "0"           # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
-FLASH_VT_PERM = os.environ.get("MARIGOLD_FLASH_VT_PERM", "1") != "0"   # permuted V^T + generation-3 attention (0: generation 2)
-ROWGEMM = os.environ.get("MARIGOLD_ROWGEMM", "1") != "0"           # row-resident GEMM (MG_OP_ROWGEMM) for the K = 320 token-local layers
-XATTN_KSPLIT = os.environ.get("MARIGOLD_XATTN_KSPLIT", "1") != "0"   # deep-level collapsed cross-attention as the K-split kernel
-ROWGEMM_WIDE = os.environ.get("MARIGOLD_ROWGEMM_WIDE", "1") != "0"   # ... and its K = 640 form for the 640-channel level's QKV / GEGLU
-ROWGEMM_MIN_M = int(os.environ.get("MARIGOLD_ROWGEMM_MIN_M", "9216"))   # below: the tile GEMM (one 96 x 96 member is 72 128-row workgroups)
+
+
+def _tune(name, default):
+    """Tuning switch ``name`` (an environment variable): honoured ONLY under MARIGOLD_TUNING=1 (same-box A/B runs, sweeps);
+    without it the engine builds the product configuration whatever else the environment holds.  The library's switches sit
+    behind the same gate (csrc/runtime.hip::mg_tuning_int)."""
+    if os.environ.get("MARIGOLD_TUNING") != "1":
+        return default
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    return v if isinstance(default, str) else type(default)(int(v))
+
+
+USE_PATCH = _tune("MARIGOLD_PATCH_CONV", True)          # patch-resident conv3x3 kernel where eligible
+FUSE_GN = _tune("MARIGOLD_FUSE_GN", "auto")             # auto | all | none: GroupNorm apply inside the conv
+GN_BYPRODUCT = _tune("MARIGOLD_GN_BYPRODUCT", True)     # GroupNorm partial sums from the producing convolution's epilogue
+VAE_FLASH_SMALL_MIN_BLOCKS = _tune("MARIGOLD_VAE_FLASH_MIN_BLOCKS", 0)   # flash512 only for launches of at least this many query blocks
+IGEMM73_CONV = _tune("MARIGOLD_IGEMM73_CONV", True)     # plain N = 320 k convolutions on the hand-placed 192 x 320 GEMM tile
+IGEMM72_VAE = _tune("MARIGOLD_IGEMM72_VAE", True)       # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
+GN_SLAB = _tune("MARIGOLD_GN_SLAB", True)               # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
+ROWGEMM = _tune("MARIGOLD_ROWGEMM", True)               # row-resident GEMM (MG_OP_ROWGEMM) for the K = 320 token-local layers
+XATTN_KSPLIT = _tune("MARIGOLD_XATTN_KSPLIT", True)     # deep-level collapsed cross-attention as the K-split kernel
+ROWGEMM_WIDE = _tune("MARIGOLD_ROWGEMM_WIDE", True)     # ... and its K = 640 form for the 640-channel level's QKV / GEGLU
+ROWGEMM_MIN_M = _tune("MARIGOLD_ROWGEMM_MIN_M", 9216)   # below: the tile GEMM (one 96 x 96 member is 72 128-row workgroups)
 
 
 class Act:
@@ -141,12 +147,6 @@ class WeightStore:
             return Wm.bf16(wp, self.device), kp
         return self._memo(("cim", name), f)
 
-    def geglu(self, name):
-        def f():
-            w, b = Wm.pack_geglu(self.sd[f"{name}.weight"].float(), self.sd[f"{name}.bias"].float())
-            return Wm.bf16(w, self.device), Wm.f32(b, self.device)
-        return self._memo(("gg", name), f)
-
     def qkv(self, prefix, with_bias):
         def f():
             w = Wm.pack_qkv(*(self.sd[f"{prefix}.{q}.weight"].float() for q in ("to_q", "to_k", "to_v")))
@@ -218,14 +218,6 @@ class WeightStore:
             return wp.to(self.device), Wm.f32(g, self.device), Wm.f32(c, self.device), Wm.bf16(vot, self.device), npad
         return self._memo(("x_ln", prefix), f)
 
-    def cross(self, prefix, ctx, heads):
-        def f():
-            wqk, vot, npad = Wm.cross_attention_tables(
-                self.sd[f"{prefix}.to_q.weight"], self.sd[f"{prefix}.to_k.weight"],
-                self.sd[f"{prefix}.to_v.weight"], self.sd[f"{prefix}.to_out.0.weight"], ctx, heads)
-            return Wm.bf16(wqk, self.device), Wm.bf16(vot, self.device), npad
-        return self._memo(("x", prefix), f)
-
 
 class Builder:
     """Emits ops into an OpSeq, allocating/recycling activation buffers from a Pool."""
@@ -262,6 +254,13 @@ class Builder:
                 x.gn = None
             self.pool.put(x.t if isinstance(x, Act) else x)
 
+    def drop_gn(self, x):
+        """Forget (and recycle) the GroupNorm partial table cached on ``x``: every op that WRITES into an existing Act calls this,
+        so that ``gn_scale_shift`` never finalizes statistics of values the tensor no longer holds."""
+        if isinstance(x, Act) and x.gn is not None:
+            self.pool.put(x.gn[0])
+            x.gn = None
+
     def zeros_persistent(self, key, nbytes):
         """A dedicated zero-initialised buffer (never recycled): V^T pad columns must stay 0."""
         if key not in self.persist:
@@ -277,7 +276,7 @@ class Builder:
         """Token-local Linear layers of this activation on MG_OP_ROWGEMM?  K = 320 is what the kernel is built for (a wave
         keeps 32 rows x 320 channels in 80 registers); whole 32-row tiles inside an image (the V^T section and the folded
         GroupNorm are per image), enough 384-row workgroups for the chip, and the permuted V^T the QKV form writes."""
-        return ROWGEMM and FLASH_VT_PERM and x.C == 320 and x.HW % 32 == 0 and x.M >= ROWGEMM_MIN_M
+        return ROWGEMM and x.C == 320 and x.HW % 32 == 0 and x.M >= ROWGEMM_MIN_M
 
     @staticmethod
     def rowgemm_wide_ok(x):
@@ -285,7 +284,7 @@ class Builder:
         only where the columns can be split over two workgroups per 256-row block - the QKV projection (97 -> 80 us) and GEGLU
         (216 -> 194 us); the whole-row-statistics layers stay on the tile GEMM (90 workgroups: 64 vs 49 us),
         profiles/r3_rowgemm_k640.log."""
-        return ROWGEMM and ROWGEMM_WIDE and FLASH_VT_PERM and x.C == 640 and x.HW % 32 == 0 and x.M >= 60 * 256
+        return ROWGEMM and ROWGEMM_WIDE and x.C == 640 and x.HW % 32 == 0 and x.M >= 60 * 256
 
     @staticmethod
     def rowgemm_cfg(M, N, whole_rows=False, xattn=False, K=320):
@@ -362,8 +361,6 @@ class Builder:
         # grows with the NUMBER of blocks (tickets, the last block's table reduction): 59 MB at E = 10 takes 16.3 us with 24-32
         # chunks per image against 23.5 with the 76 of round 2 (28.7 before the tail fix), profiles/r3_gn_stats_chunks.log
         chunks = max(1, min(HW // 32, 64, max(8, 288 // B)))
-        if os.environ.get("MARIGOLD_GN_CHUNKS_R2") == "1":   # A/B: the round-2 rule
-            chunks = max(1, min(HW // 32, max(16, 768 // B)))
         slots = chunks * len(srcs)
         part = self.raw(B * slots * self.groups * 2 * 4)
         ss = self.raw(B * 2 * C * 4)
@@ -425,8 +422,6 @@ class Builder:
         mode = FUSE_GN
         if mode != "auto":
             return mode == "all"
-        if UNFUSE_320 and N == 320 and Cin >= UNFUSE_320 and IGEMM73_CONV:
-            return False   # (A/B, round 4) the UNet's 320-channel level: one apply pass + the plain convolution on the 192 x 320 GEMM tile
         tiles_n = 1 if N in (128, 256, 320) else -(-N // (256 if N % 256 == 0 else 128))
         return tiles_n == 1 or B * H * W * Cin * 2 >= (192 << 20)
 
@@ -445,7 +440,8 @@ class Builder:
         # (round 4) the GroupNorm statistics of the output as a by-product of the 12-wave tiles' epilogue - the tensors of the
         # VAE's 768^2 / 384^2 levels are re-read at HBM speed otherwise (4.6 ms of statistics passes per decode at E = 10)
         cpg = cout // self.groups
-        if GN_BYPRODUCT and out.gn is None and cout % self.groups == 0 and cpg in (4, 8, 16, 32) and out.HW * cout * 2 >= (8 << 20):
+        self.drop_gn(out)   # this launch rewrites `out`: a table left by an earlier producer describes other values
+        if GN_BYPRODUCT and cout % self.groups == 0 and cpg in (4, 8, 16, 32) and out.HW * cout * 2 >= (8 << 20):
             slots = O.conv3x3_gn_slots(op)
             if slots > 0:
                 part = self.raw(x.B * slots * self.groups * 2 * 4)
@@ -464,6 +460,7 @@ class Builder:
             Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
         if out is None:
             out = self.new(x.B, Ho, Wo, cout)
+        self.drop_gn(out)
         # (round 4) plain 512-channel VAE convolutions with >= 720 tiles of 256 x 256: the hand-placed implicit-GEMM tile
         # (variant 72, picked by the library) runs them at 1 284 TFLOP/s against 1 202 / 1 050 for the patch kernels
         big_gemm = (IGEMM72_VAE and up is None and stride == 1 and pad == 1 and cout % 256 == 0 and x.C >= 512 and
@@ -529,17 +526,12 @@ class Builder:
         ctr = self.zeros_persistent("ln_counters", 4 * 65536) if ln_out is not None else None
         if out is None:
             out = Act(self.pool.get(M * n_out * out_dtype_bytes), x.B, x.H, x.W, n_out)
+        self.drop_gn(out)
         self.add(O.linear(x.t, wt, out.t, M=M, K=K, N=N, bias=bias, epi=epi,
                           residual=None if residual is None else residual.t,
                           a1=None if skip is None else skip.t, C0=x.C if skip is not None else 0, ln_out=ln_out, ln_counters=ctr,
                           ln_in=None if ln is None else ln[0], ln_g=None if ln is None else ln[1],
                           ln_c=None if ln is None else ln[2]), label)
-        return out
-
-    def layer_norm(self, x, name):
-        out = self.new(x.B, x.H, x.W, x.C)
-        self.add(O.layernorm(x.t, self.ws.vec(f"{name}.weight"), self.ws.vec(f"{name}.bias"), out.t,
-                             M=x.M, C=x.C, eps=1e-5), name)
         return out
 
     # ---- composite blocks ----------------------------------------------------------------
@@ -589,28 +581,23 @@ class Builder:
         vt = self.zeros_persistent(("vt", B, C, ldvt), B * C * ldvt * 2)
         # V^T with its keys in the QK^T accumulator order inside groups of 16: the QKV epilogue skips its lane regroup and
         # the attention kernel (generation 3) its v_permlane32_swap - a format private to this producer / consumer pair
-        perm = FLASH_VT_PERM and T % 16 == 0
-        rg = perm and st is not None and self.rowgemm_ok(h)
-        if rg or (perm and st is not None and self.rowgemm_wide_ok(h)):
+        perm = T % 16 == 0
+        rg = perm and self.rowgemm_ok(h)
+        if rg or (perm and self.rowgemm_wide_ok(h)):
             self.add(O.rowgemm(h.t, self.ws.rg_qkv_ln(prefix, norm), qk, M=M, K=C, N=3 * C, form=L.RG_QKV, ldo=2 * C,
                                ln_in=self.ln_mean_rstd(st, M, C), vt=vt, tokens=T, ldt=ldvt, trans_from=2 * C,
                                **self.rowgemm_cfg(M, 3 * C, K=C)), f"{prefix}.qkv")
-        elif st is not None:
+        else:
             wqkv, g, c = self.ws.qkv_ln(prefix, norm)
             self.add(O.igemm(h.t, wqkv, qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C, out2=vt,
                              trans_from=2 * C, ldt=ldvt, ln_in=self.ln_mean_rstd(st, M, C), ln_g=g, ln_c=c, trans_perm=perm), f"{prefix}.qkv")
-        else:   # A/B form: the LayerNorm as its own pass
-            y = self.layer_norm(h, norm)
-            self.add(O.igemm(y.t, self.ws.qkv(prefix, False)[0], qk, B=B, H=T, W=1, Cin=C, Ho=T, Wo=1, N=3 * C, ldo=2 * C,
-                             out2=vt, trans_from=2 * C, ldt=ldvt, trans_perm=perm), f"{prefix}.qkv")
-            self.free(y)
         o = self.new(h.B, h.H, h.W, C)
-        ws = self.zeros_persistent(("flash_ws",), O.FLASH_WS_BYTES)   # key-split blocks of the hand-placed kernel (tickets stay 0)
+        ws = self.zeros_persistent(("flash_ws",), O.FLASH_WS_BYTES_AUTO)   # key-split blocks of the hand-placed kernel (tickets stay 0)
         self.add(O.flash_attn64(qk, qk.data_ptr() + C * 2, vt, o.t, B=B, heads=heads, Ntok=T, ldq=2 * C,
                                 ldo=C, ldvt=ldvt, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C,
-                                scale=1.0 / math.sqrt(C // heads), vt_perm=perm, ws=ws, ws_bytes=O.FLASH_WS_BYTES), f"{prefix}.flash")
+                                scale=1.0 / math.sqrt(C // heads), vt_perm=perm, ws=ws, ws_bytes=O.FLASH_WS_BYTES_AUTO), f"{prefix}.flash")
         self.free(qk)
-        if rg and st_out is not None:
+        if rg:
             self.add(O.rowgemm(o.t, self.ws.rg_mat(f"{prefix}.to_out.0"), h.t, M=M, K=C, N=C, residual=h.t,
                                ln_out=self.ln_mean_rstd(st_out, M, C), **self.rowgemm_cfg(M, C, whole_rows=True)), f"{prefix}.to_out")
         else:
@@ -620,62 +607,47 @@ class Builder:
 
     def cross_attention2(self, h, st, prefix, norm, heads, ctx, st_out):
         """h += attn2(LN(h), ctx) with the 2-token context collapsed into two thin GEMMs and the LayerNorm folded into
-        the first one."""
+        the first one (``st``: row statistics of h, ``st_out``: of the new h for the next folded LayerNorm)."""
         C, M = h.C, h.M
-        if (st is not None and st_out is not None and XATTN_FUSED and XATTN_KSPLIT and ROWGEMM and 2 * heads <= 64 and C in (640, 1280)
-                and M % 32 == 0):
+        if XATTN_KSPLIT and ROWGEMM and 2 * heads <= 64 and C in (640, 1280) and M % 32 == 0:
             # the deep levels: 32-row workgroups whose four waves split K (scores) and the output channels (blend)
             self.add(O.rowgemm(h.t, self.ws.rg_cross_ln(prefix, ctx, heads, norm), h.t, M=M, K=C, N=64, form=L.RG_XATTN,
                                ln_in=self.ln_mean_rstd(st, M, C), ln_out=self.ln_mean_rstd(st_out, M, C),
                                sm_cols=2 * heads, sm_scale=1.0 / math.sqrt(C // heads)), f"{prefix}.scores+softmax2+blend")
             return
-        if st is not None and st_out is not None and XATTN_FUSED and 2 * heads <= 64 and self.rowgemm_ok(h):
+        if 2 * heads <= 64 and self.rowgemm_ok(h):
             # the same single launch in the row-resident form: the residual stream is read once (registers) and written once
             self.add(O.rowgemm(h.t, self.ws.rg_cross_ln(prefix, ctx, heads, norm), h.t, M=M, K=C, N=64, form=L.RG_XATTN,
                                ln_in=self.ln_mean_rstd(st, M, C), ln_out=self.ln_mean_rstd(st_out, M, C),
                                sm_cols=2 * heads, sm_scale=1.0 / math.sqrt(C // heads), **self.rowgemm_cfg(M, C, xattn=True)),
                      f"{prefix}.scores+softmax2+blend")
             return
-        if st is not None:
-            # ONE launch: scores GEMM with the LayerNorm folded in, the 2-key softmax on its accumulators, the probabilities
-            # as the register operand of the blend GEMM (x the context's values pushed through to_out), + bias + residual,
-            # in place on the residual stream, (mean, rstd) of the new rows for the next folded LayerNorm
-            wqk, g, c, vot, npad = self.ws.cross_ln(prefix, ctx, heads, norm)
-            if XATTN_FUSED and npad == 64 and C % 32 == 0:
-                self.add(O.linear(h.t, wqk, h.t, M=M, K=C, N=npad, epi=L.EPI_XATTN2, ln_in=self.ln_mean_rstd(st, M, C),
-                                  ln_g=g, ln_c=c, sm_scale=1.0 / math.sqrt(C // heads), sm_cols=2 * heads, out2=vot, c2=C, ldo=C,
-                                  bias=self.ws.bias(f"{prefix}.to_out.0"), residual=h.t, ldr=C,
-                                  ln_out=None if st_out is None else self.ln_mean_rstd(st_out, M, C)),
-                         f"{prefix}.scores+softmax2+blend")
-                return
-            p = self.raw(M * npad * 2)
-            self.add(O.linear(h.t, wqk, p, M=M, K=C, N=npad, epi=L.EPI_SOFTMAX2, ln_in=self.ln_mean_rstd(st, M, C), ln_g=g, ln_c=c,
-                              sm_scale=1.0 / math.sqrt(C // heads), sm_cols=2 * heads), f"{prefix}.scores+softmax2")
-            self.add(O.linear(p, vot, h.t, M=M, K=npad, N=C, bias=self.ws.bias(f"{prefix}.to_out.0"),
-                              residual=h.t, ln_out=st_out, ln_counters=self.zeros_persistent("ln_counters", 4 * 65536)), f"{prefix}.blend")
-            self.free(p)
+        # ONE launch on the tile GEMM: scores GEMM with the LayerNorm folded in, the 2-key softmax on its accumulators, the
+        # probabilities as the register operand of the blend GEMM (x the context's values pushed through to_out), + bias +
+        # residual, in place on the residual stream, (mean, rstd) of the new rows for the next folded LayerNorm
+        wqk, g, c, vot, npad = self.ws.cross_ln(prefix, ctx, heads, norm)
+        if npad == 64 and C % 32 == 0:
+            self.add(O.linear(h.t, wqk, h.t, M=M, K=C, N=npad, epi=L.EPI_XATTN2, ln_in=self.ln_mean_rstd(st, M, C),
+                              ln_g=g, ln_c=c, sm_scale=1.0 / math.sqrt(C // heads), sm_cols=2 * heads, out2=vot, c2=C, ldo=C,
+                              bias=self.ws.bias(f"{prefix}.to_out.0"), residual=h.t, ldr=C,
+                              ln_out=self.ln_mean_rstd(st_out, M, C)),
+                     f"{prefix}.scores+softmax2+blend")
             return
-        else:
-            wqk, vot, npad = self.ws.cross(prefix, ctx, heads)
-            s = self.raw(M * npad * 4)
-            y = self.layer_norm(h, norm)
-            self.add(O.linear(y.t, wqk, s, M=M, K=C, N=npad, epi=L.EPI_F32), f"{prefix}.scores")
-            self.free(y)
+        # more than 32 heads (no published checkpoint): two launches - scores + pair softmax, then the blend
         p = self.raw(M * npad * 2)
-        self.add(O.softmax_pairs(s, p, M=M, pairs=heads, lds=npad, ldp=npad,
-                                 scale=1.0 / math.sqrt(C // heads)), f"{prefix}.softmax2")
+        self.add(O.linear(h.t, wqk, p, M=M, K=C, N=npad, epi=L.EPI_SOFTMAX2, ln_in=self.ln_mean_rstd(st, M, C), ln_g=g, ln_c=c,
+                          sm_scale=1.0 / math.sqrt(C // heads), sm_cols=2 * heads), f"{prefix}.scores+softmax2")
         self.add(O.linear(p, vot, h.t, M=M, K=npad, N=C, bias=self.ws.bias(f"{prefix}.to_out.0"),
-                          residual=h.t, ln_out=st_out,
-                          ln_counters=None if st_out is None else self.zeros_persistent("ln_counters", 4 * 65536)), f"{prefix}.blend")
-        self.free(s, p)
+                          residual=h.t, ln_out=st_out, ln_counters=self.zeros_persistent("ln_counters", 4 * 65536)), f"{prefix}.blend")
+        self.free(p)
 
     def transformer(self, x, name, heads, ctx):
         """diffusers Transformer2DModel / BasicTransformerBlock.  The three LayerNorms never run as passes: each Linear
         that consumes one takes the raw residual stream and corrects in its epilogue (MG_OP_IGEMM ln_in), with the row
         statistics written by the epilogue of the GEMM that produced the stream (ln_out)."""
         C = x.C
-        st = [self.ln_table(x.M, C) if FOLD_LN else None for _ in range(3)]
-        rg = FOLD_LN and self.rowgemm_ok(x)
+        st = [self.ln_table(x.M, C) for _ in range(3)]
+        rg = self.rowgemm_ok(x)
         if rg:
             # the GroupNorm never runs as a pass: statistics only, its scale / shift applied while proj_in loads its rows
             if self.gn_slab_ok([x], False):
@@ -694,19 +666,14 @@ class Builder:
         b = f"{name}.transformer_blocks.0"
         self.self_attention(h, st[0], f"{b}.attn1", f"{b}.norm1", heads, st[1])
         self.cross_attention2(h, st[1], f"{b}.attn2", f"{b}.norm2", heads, ctx, st[2])
-        if rg or (FOLD_LN and self.rowgemm_wide_ok(h)):
+        if rg or self.rowgemm_wide_ok(h):
             ff = self.new(h.B, h.H, h.W, 4 * C)
             self.add(O.rowgemm(h.t, self.ws.rg_geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3"), ff.t, M=h.M, K=C, N=8 * C,
                                form=L.RG_GEGLU, ln_in=self.ln_mean_rstd(st[2], h.M, C), **self.rowgemm_cfg(h.M, 8 * C, K=C)), f"{b}.ff.geglu")
-        elif FOLD_LN:
+        else:
             wg, gg, cg = self.ws.geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3")
             ff = self.dense(h, wg, None, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu",
                             ln=(self.ln_mean_rstd(st[2], h.M, C), gg, cg))
-        else:
-            y = self.layer_norm(h, f"{b}.norm3")
-            wg, bg = self.ws.geglu(f"{b}.ff.net.0.proj")
-            ff = self.dense(y, wg, bg, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu")
-            self.free(y)
         self.free(*st)
         self.dense(ff, self.ws.mat(f"{b}.ff.net.2"), self.ws.bias(f"{b}.ff.net.2"), C, residual=h, out=h,
                    label=f"{b}.ff.out")
@@ -723,7 +690,8 @@ class Builder:
         return out
 
     def vae_attention(self, x, name):
-        """Single-head d=C attention of the VAE mid block: flash form for chip-filling batches, else materialised fp32 scores."""
+        """Single-head d=C attention of the VAE mid block: the flash form (MG_OP_FLASH_ATTN512) for the published width of
+        512 channels, the materialised fp32 scores for any other width (the tiny test architecture)."""
         C, B, T, M = x.C, x.B, x.HW, x.M
         g = self.group_norm(x, f"{name}.group_norm", 1e-6, False)
         wqkv, bqkv = self.ws.qkv(name, True)
@@ -735,46 +703,28 @@ class Builder:
                          out2=vt, trans_from=2 * C, ldt=ldp), f"{name}.qkv")
         self.free(g)
         o = self.new(x.B, x.H, x.W, C)
-        if VAE_FLASH and C == 512 and (VAE_FLASH_SMALL or B * ((T + 127) // 128) >= 200):
-            # round 4: flash form (MG_OP_FLASH_ATTN512) - the T x T scores (340 MB of fp32 per image at 96 x 96 latent pixels)
-            # never leave the registers.  One workgroup per 128 queries and CU: a launch that does not fill the chip (the
-            # encoder's single image: 72 workgroups) takes 0.93 ms against 0.50 ms for the three-stage form below
-            # (profiles/r4_flash512.log; two-wave workgroups of 64 queries were tried for such launches: 1.12 ms, the tile's
-            # LDS-DMA traffic per query doubles) - it runs here all the same, so that no score matrix is materialised anywhere
-            # (MARIGOLD_VAE_FLASH_SMALL=0: the three-stage form for such launches).
+        if C == 512 and B * ((T + 127) // 128) >= VAE_FLASH_SMALL_MIN_BLOCKS:
+            # round 4: flash form - the T x T scores (340 MB of fp32 per image at 96 x 96 latent pixels) never leave the
+            # registers.  One workgroup per 128 queries and CU: a launch that does not fill the chip (the encoder's single
+            # image: 72 workgroups) takes 0.93 ms against 0.50 ms for the three-stage form below (profiles/r4_flash512.log;
+            # two-wave workgroups of 64 queries were tried for such launches: 1.12 ms) - it runs here all the same, so that no
+            # score matrix is materialised anywhere on the product path
             self.add(O.flash_attn512(qk, qk.data_ptr() + C * 2, vt, o.t, B=B, Ntok=T, ldq=2 * C, ldo=C, ldvt=ldp,
                                      sq=T * 2 * C, sk=T * 2 * C, svt=C * ldp, so=T * C, scale=1.0 / math.sqrt(C)), f"{name}.flash")
             self.free(qk)
-            out = self.dense(o, self.ws.mat(f"{name}.to_out.0"), self.ws.bias(f"{name}.to_out.0"), C,
-                             residual=x, label=f"{name}.to_out")
-            self.free(o)
-            return out
-        # The fp32 score matrix of ONE image is T x T x 4 bytes (340 MB at 96 x 96 latent pixels, 3.4 GB for ten members).
-        # Optional (MARIGOLD_VAE_ATTN_CHUNK_MB, off): run the three stages per chunk of query rows whose scores fit the
-        # Infinity Cache - tried in round 4, no gain on MI355X.
-        rows = T
-        while VAE_ATTN_CHUNK_BYTES and rows * ldp * 4 > VAE_ATTN_CHUNK_BYTES and rows % 2 == 0 and (rows // 2) % 256 == 0:
-            rows //= 2
-        if not VAE_ATTN_CHUNK_BYTES or (rows == T and B * T * ldp * 4 <= VAE_ATTN_CHUNK_BYTES):
-            chunks = [(0, T, B)]            # everything in one batched launch (small maps)
         else:
-            chunks = [(b * T + r0, rows, 1) for b in range(B) for r0 in range(0, T, rows)]
-        nb = max(c[2] for c in chunks)
-        nr = max(c[1] for c in chunks)
-        s = self.raw(nb * nr * ldp * 4)
-        p = self.raw(nb * nr * ldp * 2)
-        for (row0, nrow, bz) in chunks:
-            b0 = row0 // T
-            tag = "" if len(chunks) == 1 else f"[{row0}]"
-            self.add(O.igemm(qk.data_ptr() + row0 * 2 * C * 2, qk.data_ptr() + b0 * T * 2 * C * 2 + C * 2, s, B=1, H=nrow, W=1,
-                             Cin=C, Ho=nrow, Wo=1, N=Tn, epi=L.EPI_F32, ldo=ldp, lda=2 * C, ldw=2 * C, batch_z=bz, n_alg=T,
-                             zstrides=(T * 2 * C, T * 2 * C, T * ldp, 0), scale=1.0 / math.sqrt(C)), f"{name}.scores{tag}")
-            self.add(O.softmax_rows(s, p, R=bz * nrow, ncols=T, lds=ldp, ldp=ldp), f"{name}.softmax{tag}")
-            self.add(O.igemm(p, vt.data_ptr() + b0 * C * ldp * 2, o.t.data_ptr() + row0 * C * 2, B=1, H=nrow, W=1, Cin=ldp, Ho=nrow,
-                             Wo=1, N=C, lda=ldp, ldw=ldp, batch_z=bz, zstrides=(T * ldp, C * ldp, T * C, 0)), f"{name}.pv{tag}")
-        self.free(qk)
-        self.free(s)
-        self.free(p)
+            # scores GEMM -> row softmax -> P V, everything in one batched launch per stage
+            sc = self.raw(B * T * ldp * 4)
+            self.add(O.igemm(qk, qk.data_ptr() + C * 2, sc, B=1, H=T, W=1, Cin=C, Ho=T, Wo=1, N=Tn, epi=L.EPI_F32, ldo=ldp,
+                             lda=2 * C, ldw=2 * C, batch_z=B, n_alg=T, zstrides=(T * 2 * C, T * 2 * C, T * ldp, 0),
+                             scale=1.0 / math.sqrt(C)), f"{name}.scores")
+            self.free(qk)
+            p = self.raw(B * T * ldp * 2)
+            self.add(O.softmax_rows(sc, p, R=B * T, ncols=T, lds=ldp, ldp=ldp), f"{name}.softmax")
+            self.free(sc)   # (the fp32 scores and the bf16 probabilities never live side by side beyond this launch)
+            self.add(O.igemm(p, vt, o.t, B=1, H=T, W=1, Cin=ldp, Ho=T, Wo=1, N=C, lda=ldp, ldw=ldp, batch_z=B,
+                             zstrides=(T * ldp, C * ldp, T * C, 0)), f"{name}.pv")
+            self.free(p)
         out = self.dense(o, self.ws.mat(f"{name}.to_out.0"), self.ws.bias(f"{name}.to_out.0"), C,
                          residual=x, label=f"{name}.to_out")
         self.free(o)

@@ -107,11 +107,11 @@ def gn_slab(x0, out, ss, *, B, HW, C, groups, gamma, beta, eps, silu=False, x1=N
     return make_op(L.OP_GN_SLAB, i=[B, HW, C, C0, groups, int(silu)], f=[eps], p=[x0, x1, out, gamma, beta, ss])
 
 
-def layernorm(x, gamma, beta, out, *, M, C, eps=1e-5):
-    return make_op(L.OP_LAYERNORM, i=[M, C], f=[eps], p=[x, gamma, beta, out])
-
-
-FLASH_WS_BYTES = 4096 + 255 * 4 * 4 * (16384 + 1024)   # tickets + four partial results for up to 255 split blocks of queries
+FLASH_WS_BYTES = 4096 + 255 * 4 * 4 * (16384 + 1024)   # tickets + four partial results for up to 255 split blocks of queries (tests: split = 1)
+# What the engine allocates per program: the automatic rule (split = 0) only splits a left-over of at most CUs / 8 blocks (32 on
+# MI355X; 40 leaves room for a larger part) - 11 MB instead of 71 MB zeroed per Builder.  A smaller workspace than a launch could
+# use is safe: the plan then does not split (flash4w.hip::mg_flash4w_plan).
+FLASH_WS_BYTES_AUTO = 4096 + 40 * 4 * 4 * (16384 + 1024)
 
 
 def flash_attn64(q, k, vt, o, *, B, heads, Ntok, ldq, ldo, ldvt, sq, sk, svt, so, scale, variant=0, vt_perm=False, dbg=None,
@@ -142,10 +142,6 @@ def permute_vt_keys(vt):
 
 def softmax_rows(s, p, *, R, ncols, lds, ldp):
     return make_op(L.OP_SOFTMAX_ROWS, i=[R, ncols, lds, ldp], p=[s, p])
-
-
-def softmax_pairs(s, p, *, M, pairs, lds, ldp, scale):
-    return make_op(L.OP_SOFTMAX_PAIRS, i=[M, pairs, lds, ldp], f=[scale], p=[s, p])
 
 
 def sched_step(x, model_out, noise, out, *, n, cx, cm, cn=0.0):

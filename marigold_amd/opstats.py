@@ -10,8 +10,8 @@ HBM_PEAK_GBS = 8000.0       # HBM3E spec (6.29 TB/s measured streaming)
 
 CLASS = {
     L.OP_IGEMM: "igemm_mfma", L.OP_ROWGEMM: "rowgemm_mfma", L.OP_CONV3X3: "conv3x3_patch", L.OP_FLASH_ATTN64: "flash_attn64", L.OP_FLASH_ATTN512: "flash_attn512", L.OP_GN_STATS: "groupnorm",
-    L.OP_GN_FINALIZE: "groupnorm", L.OP_GN_APPLY: "groupnorm", L.OP_GN_SLAB: "groupnorm", L.OP_LAYERNORM: "layernorm",
-    L.OP_SOFTMAX_ROWS: "softmax", L.OP_SOFTMAX_PAIRS: "softmax",
+    L.OP_GN_FINALIZE: "groupnorm", L.OP_GN_APPLY: "groupnorm", L.OP_GN_SLAB: "groupnorm",
+    L.OP_SOFTMAX_ROWS: "softmax",
     L.OP_SCHED_STEP: "scheduler_step", L.OP_LINEAR_SMALL_M: "time_embedding",
     L.OP_LATENT_1X1: "boundary_conv", L.OP_POST_NCHW: "boundary_conv", L.OP_IM2COL_SMALL: "boundary_conv", L.OP_ENS_DEPTH_STATS: "ensemble", L.OP_ENS_DEPTH_MEDIAN: "ensemble",
     L.OP_ENS_DEPTH_NORM: "ensemble", L.OP_ENS_NORMALS: "ensemble", L.OP_RESIZE: "resize", L.OP_COLORIZE: "resize", L.OP_MEMSET: "memops", L.OP_COPY: "memops",
@@ -69,12 +69,8 @@ def op_cost(op):
         byts = 2 * i[0] * i[1] * i[2] * 2
     elif k == L.OP_GN_SLAB:
         byts = (2 if op.p[2] else 1) * i[0] * i[1] * i[2] * 2
-    elif k == L.OP_LAYERNORM:
-        byts = 2 * i[0] * i[1] * 2
     elif k == L.OP_SOFTMAX_ROWS:
         byts = i[0] * i[1] * 4 + i[0] * i[3] * 2
-    elif k == L.OP_SOFTMAX_PAIRS:
-        byts = i[0] * i[2] * 4 + i[0] * i[3] * 2
     elif k == L.OP_SCHED_STEP:
         byts = (4 if op.p[2] else 3) * l[0] * 4
     elif k == L.OP_LINEAR_SMALL_M:

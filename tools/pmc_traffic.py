@@ -32,7 +32,7 @@ def main():
     f = load(os.path.join(base, "pmc_fetch", "r2_counter_collection.csv"), "FETCH_SIZE")
     w = load(os.path.join(base, "pmc_write", "r2_counter_collection.csv"), "WRITE_SIZE")
     classes = {"igemm_mfma": "igemm2_", "rowgemm_mfma": "rowgemm_", "conv3x3_patch": "conv_patch", "flash_attn64": "flash_attn64",
-               "groupnorm": "gn_", "layernorm": "layernorm"}
+               "groupnorm": "gn_"}
     out = {}
     with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.csv"), "w") as c:
         c.write("kernel,launches,FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum,hbm_MB_per_launch_corrected\n")
