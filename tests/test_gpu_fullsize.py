@@ -242,12 +242,12 @@ def test_c2_heavy_tailed_weights_vs_oracle(full, golden_dir):
     channels at 30x in every layer that writes the transformer residual stream, norm gains at 8x, GEGLU gate rows at 4x) -
     the regime where the folded LayerNorm cancels large numbers, the polynomial GELU is clamped and the fused GroupNorm
     fix-up rounds large values to bf16 - against a freshly minted fp32 oracle golden (oracle/make_fullsize_golden.py
-    --heavy).  Run with the LayerNorm fold (product path) AND with the unfused MARIGOLD_FOLD_LN=0 chain: the fold may lose
-    at most 1.25x against it, else the operand needs centring.  Measured on MI355X (profiles/r3_parity_heavy_tailed_stress.log):
+    --heavy), with the LayerNorm fold of the product path: it may lose at most 1.25x against the unfused chain's recorded
+    error, else the operand needs centring.  Measured on MI355X (profiles/r3_parity_heavy_tailed_stress.log):
     final latent 2.66e-2 folded vs 2.54e-2 as a pass (1.1e-2 on well-conditioned weights), depth rmse 4.5e-3, delta1 0.99994;
     stated bounds: latent < 4e-2 (2 x LAT_REL_BOUND - outlier channels double the bf16 path's own error), depth as in C2."""
     import os
-    from marigold_amd import engine, synthetic as syn
+    from marigold_amd import synthetic as syn
     from marigold_amd.modules import UNet2DConditionModelHIP
     from marigold_amd.schedulers import DDIMScheduler
     from oracle import metrics as omet
@@ -260,29 +260,26 @@ def test_c2_heavy_tailed_weights_vs_oracle(full, golden_dir):
     lat0 = syn.synthetic_latents(4, 96, 96, seed=7)
     rgb = (img.float() / 255.0 * 2.0 - 1.0)
     rl = full["vae"].encode_rgb_latent(rgb.cuda())
-    finals = {}
-    saved = engine.FOLD_LN
-    try:
-        for fold in (True, False):
-            engine.FOLD_LN = fold
-            unet = UNet2DConditionModelHIP(usd, full["ucfg"]).to("cuda:0")
-            unet.set_context(full["ctx"])
-            sched = DDIMScheduler()
-            sched.set_timesteps(10)
-            prog = unet.denoise_program(1, 96, 96, sched, 10, rgb_broadcast=True)
-            prog.rgb_latent.copy_(rl)
-            prog.x.copy_(lat0[:1])
-            errs = _stepwise(prog, 10, gold["ddim10_trace_m0"], f"C2 heavy-tailed weights, LayerNorm {'folded' if fold else 'as a pass'}")
-            finals[fold] = (errs, prog.x.clone())
-            del prog, unet
-            torch.cuda.empty_cache()
-    finally:
-        engine.FOLD_LN = saved
-    e_fold, e_pass = finals[True][0][-1], finals[False][0][-1]
-    print(f"[parity] heavy-tailed C2: final latent rmse/rms - folded LayerNorm {e_fold:.3e}, LayerNorm pass {e_pass:.3e}")
-    assert e_fold < 2 * LAT_REL_BOUND and e_fold <= max(1.25 * e_pass, LAT_REL_BOUND)
+    unet = UNet2DConditionModelHIP(usd, full["ucfg"]).to("cuda:0")
+    unet.set_context(full["ctx"])
+    sched = DDIMScheduler()
+    sched.set_timesteps(10)
+    prog = unet.denoise_program(1, 96, 96, sched, 10, rgb_broadcast=True)
+    prog.rgb_latent.copy_(rl)
+    prog.x.copy_(lat0[:1])
+    errs = _stepwise(prog, 10, gold["ddim10_trace_m0"], "C2 heavy-tailed weights, LayerNorm folded")
+    final = prog.x.clone()
+    del prog, unet
+    torch.cuda.empty_cache()
+    e_fold = errs[-1]
+    # the unfused chain (LayerNorm as its own pass; removed from the engine in round 5) measured 2.54e-2 on the same golden
+    # (profiles/r3_parity_heavy_tailed_stress.log): the fold may lose at most 1.25 x against that, else the operand needs
+    # centring; the kernel-level form of the comparison stays in tests/test_gpu_kernels.py::test_layernorm_fold_heavy_tailed
+    E_PASS_R3 = 2.54e-2
+    print(f"[parity] heavy-tailed C2: final latent rmse/rms - folded LayerNorm {e_fold:.3e} (LayerNorm as a pass, round 3: {E_PASS_R3:.3e})")
+    assert e_fold < 2 * LAT_REL_BOUND and e_fold <= max(1.25 * E_PASS_R3, LAT_REL_BOUND)
     from marigold_amd import _lib as L
-    d = full["vae"].decode(finals[True][1], post=L.POST_DEPTH)
+    d = full["vae"].decode(final, post=L.POST_DEPTH)
     m = omet.affine_invariant_depth_errors(gold["ddim10_depth_m0"].astype(np.float32), d[0, 0].float().cpu().numpy())
     print(f"[parity] heavy-tailed C2 depth 768x768 vs fp32 CPU oracle: {m}")
     assert m["rmse"] < DEPTH_RMSE_BOUND and m["delta1"] > DEPTH_D1_BOUND, m
