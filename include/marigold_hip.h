@@ -59,6 +59,8 @@ enum mg_op_kind {
    *  i[26] 1 = the transposed section stores its tokens in accumulator order inside groups of 16 (MG_OP_FLASH_ATTN64 i[7])
    *  i[29], i[30] low / high 32 bits of the device address of the caller's row-block tickets for the p[8] statistics
    *  hand-off (65536 zeroed uint32, one buffer per program / stream; 0 = the library's global buffer: single stream only)
+   *  i[31] split-K: 0 = automatic (few output tiles x long K: fp32 partials + a fixed-order reduce launch), n >= 1 = exactly n
+   *  K ranges per tile (1 = none) - bf16 epilogue without row statistics / folded LayerNorm / batching only
    *  l[0..3] z-strides (elements) of A, Wt, out, residual      f[0] scale on the accumulator */
   MG_OP_IGEMM = 1,
   /* GroupNorm, 3 launches (stats partials -> per-(b,c) scale/shift -> apply [+SiLU]).

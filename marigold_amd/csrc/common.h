@@ -139,8 +139,6 @@ extern void* g_zero_page;  // MG_ZERO_BYTES zero bytes in device memory (mg_init
 extern thread_local bool g_dry_run;
 #define MG_SPLITK_WS_BYTES (64ll * 1024 * 1024)
 #define MG_LN_COUNTERS 65536
-#define MG_SK_COUNTERS 4096
-extern unsigned* g_sk_counters;  // MG_SK_COUNTERS zeroed tickets (mg_init): one per output tile of a split-K GEMM launch (stream-ordered reuse)
 extern unsigned* g_ln_counters;  // MG_LN_COUNTERS zeroed tickets (mg_init): one per row block of a GEMM launch that writes row
                                  // statistics (the last column tile of a row block reduces them); self-resetting, stream-ordered
 extern void* g_splitk_ws;  // fp32 partial sums of split-K GEMM launches (mg_init); stream-ordered reuse

@@ -107,27 +107,29 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   b.splits = 1;
   b.kps = b.KT;
   b.ws = nullptr;
-  b.sk_ctr = nullptr;
   const long long tiles = (long long)b.tiles_m * b.tiles_n;
-  if (!TRANS && a.splits == 0 && batch_z == 1 && a.epi == MG_EPI_BF16 && a.n_begin == 0 && a.n_end == a.N &&
-      tiles < 160 && b.KT >= 32 && g_splitk_ws) {   // (a wider window, < 256 tiles, measured no gain)
-    int sp = (int)min((long long)8, (320 + tiles - 1) / tiles);
-    if constexpr (BIG == 2 || BIG == 3) sp = (int)min((long long)8, max(1ll, 256 / tiles));   // one workgroup per CU: a single round of <= 256
-    sp = min(sp, b.KT / 12);
-    // (round 4, tried and NOT the default) MARIGOLD_SPLITK_FUSED=1: combined in the launch by the tile's last split
-    // (igemm2_body.h: slabs of whole tiles, one ticket per tile) instead of the splitk_reduce launch.  Correct (the parity suite
-    // passes with it) but 25 ms per map SLOWER (igemm 110.5 -> 135.5 ms, profiles/r4_ab_splitk_fused.log): ONE workgroup then
+  // a.splits: -1 = never (forced tile / epilogues the reduce launch cannot finish), 0 = the automatic rule, n >= 1 = exactly n
+  // (op i[31]: the tuning sweeps and the per-batch rules of mg_igemm_auto_split)
+  const bool sk_ok = !TRANS && a.splits >= 0 && batch_z == 1 && a.epi == MG_EPI_BF16 && a.n_begin == 0 && a.n_end == a.N && g_splitk_ws;
+  if (sk_ok && (a.splits > 1 || (a.splits == 0 && tiles < 160 && b.KT >= 32))) {   // (a wider window, < 256 tiles, measured no gain at E = 10)
+    int sp;
+    if (a.splits > 1) {
+      sp = min(a.splits, max(1, b.KT / 2));
+    } else {
+      sp = (int)min((long long)8, (320 + tiles - 1) / tiles);
+      if constexpr (BIG == 2 || BIG == 3) sp = (int)min((long long)8, max(1ll, 256 / tiles));   // one workgroup per CU: a single round of <= 256
+      sp = min(sp, b.KT / 12);
+    }
+    // (round 4, tried and NOT kept) combining the splits inside the launch by the tile's last split instead of the splitk_reduce
+    // launch: correct, but 25 ms per map SLOWER (igemm 110.5 -> 135.5 ms, profiles/r4_ab_splitk_fused.log) - ONE workgroup then
     // reads splits x 256 KB of slabs per tile at the 60-100 GB/s a single workgroup gets, on the launch's critical path, where
     // the reduce launch spreads the same bytes over the whole chip in 13 us.
-    static const int fused = mg_tuning_int("MARIGOLD_SPLITK_FUSED", 0);
-    const bool fuse = fused && g_sk_counters && tiles <= MG_SK_COUNTERS;
-    const long long per_split = fuse ? tiles * BM * BN * 4 : (long long)a.M * a.N * 4;
+    const long long per_split = (long long)a.M * a.N * 4;
     while (sp > 1 && (long long)sp * per_split > MG_SPLITK_WS_BYTES) --sp;
     if (sp > 1) {
       b.kps = (b.KT + sp - 1) / sp;
       b.splits = (b.KT + b.kps - 1) / b.kps;
       b.ws = (float*)g_splitk_ws;
-      b.sk_ctr = fuse ? g_sk_counters : nullptr;
     }
   }
   const long long grid = tiles * b.splits * batch_z;
@@ -137,7 +139,7 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   b.fd_tiles_n = mg_make_fastdiv(b.tiles_n);
   b.fd_cpt = mg_make_fastdiv(b.cpt);
   MG_LAUNCH(kern, dim3((unsigned)grid), dim3(NT), LDS, s, b);
-  if (b.splits > 1 && !b.sk_ctr) {
+  if (b.splits > 1) {
     const long long nvec = (long long)a.M * (a.N / 8);
     MG_LAUNCH(splitk_reduce_kernel, dim3((unsigned)min((nvec + 255) / 256, (long long)4096)), dim3(256), 0, s, b);
   }
@@ -259,10 +261,9 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.up2 = (a.Hu == 2 * a.H) && (a.Wu == 2 * a.W);
   a.tw = a.taps == 9 ? 3 : (a.taps == 4 ? 2 : 1);
   a.subpix = a.taps == 4;
-  {   // split-K only under the automatic tile choice (tuning sweeps: MARIGOLD_IGEMM_SPLITK_ANY=1 lets a forced tile split too)
-    static const int any = mg_tuning_int("MARIGOLD_IGEMM_SPLITK_ANY", 0);
-    a.splits = (variant && !any) ? -1 : 0;
-  }
+  // split-K: i[31] = n >= 1 asks for exactly n K ranges per tile (1 = none); 0 = the automatic rule, which only applies under
+  // the automatic tile choice (a forced tile runs unsplit unless i[31] says otherwise)
+  a.splits = op->i[31] > 0 ? op->i[31] : (variant ? -1 : 0);
   a.ln_out = (float2*)op->p[8];
   a.ln_in = (const float2*)op->p[9];
   a.ln_g = (const float*)op->p[10];
@@ -306,7 +307,6 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   }
   a.kps = 0;
   a.ws = nullptr;
-  a.sk_ctr = nullptr;
   a.ctr = 0;
   a.fd_rpi = mg_make_fastdiv(a.rows_per_img > 0 ? a.rows_per_img : 1);
   a.fd_wo = mg_make_fastdiv(a.Wo > 0 ? a.Wo : 1);

@@ -26,9 +26,7 @@ struct Igemm2Args {
   int M, rows_per_img, tiles_m, tiles_n, cpt, KT, rv_stride, up2, ctr;
   int n_begin, n_end;  // output-column range of this launch (tiles start at n_begin, bound n_end <= N)
   int splits, kps;     // split-K: `splits` workgroups per tile, each `kps` K steps; partials go to `ws`
-  float* ws;           // fp32 [splits][M][N] (scale / bias / residual are applied by the reduce kernel), or with sk_ctr:
-  unsigned* sk_ctr;    // accumulator-layout slabs [splits][tiles][BM x BN] + one zeroed ticket per tile: the tile's LAST split
-                       // to arrive sums the slabs in split order and runs the ordinary epilogue (no reduce launch)
+  float* ws;           // fp32 [splits][M][N] (scale / bias / residual are applied by the reduce kernel)
   long long sA, sW, sO, sR;
   float scale;
   // LayerNorm folded into this GEMM (Linear layers that consume LN(x)): A = the RAW rows x, weights = W * gamma, and
@@ -941,63 +939,6 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     }
   }
   bool single = a.splits <= 1;   // this workgroup holds the tile's complete sums
-  if constexpr (!TRANS) {
-    if (!single && a.sk_ctr) {
-      // ---- split-K, combined in the launch (round 4; the splitk_reduce launches were 4 ms of 13 us kernels per map) ----
-      // Hand-off per cdna_hip_programming.md's split-K slab recipe in its write-through form (as flash4w.hip): every split
-      // stores its accumulators as they lie in the registers (16-byte sc1 stores, 1 KB per instruction) -> every wave drains
-      // vmcnt -> barrier -> one relaxed agent-scope ticket per tile; the last split to arrive adds ALL slabs - its own read back
-      // like the others - in split order (bit-reproducible whichever is last) and goes on into the ordinary epilogue.
-      typedef __attribute__((ext_vector_type(4))) unsigned sk_u32x4;
-      const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, 0x7fffffff, 0x00020000);
-      constexpr unsigned SLAB = (unsigned)BM * BN * 4;
-      const unsigned mine = ((unsigned)split * (unsigned)tiles + (unsigned)t) * SLAB + (unsigned)wave * (TM * TN * 4) + lane * 16;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const sk_u32x4 v = {__float_as_uint(acc[ni][mi][4 * j]), __float_as_uint(acc[ni][mi][4 * j + 1]),
-                                __float_as_uint(acc[ni][mi][4 * j + 2]), __float_as_uint(acc[ni][mi][4 * j + 3])};
-            __builtin_amdgcn_raw_buffer_store_b128(v, wsr, mine + ((ni * MI + mi) * 4 + j) * 1024, 0, 16);
-          }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();   // (also: every wave is past the K loop - the ring is free)
-      int* const flag = (int*)smem;
-      if (tid == 0) {
-        unsigned* ctr = a.sk_ctr + t;
-        const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = ticket == (unsigned)(a.splits - 1);
-        if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // stream-ordered reuse
-        *flag = last ? 1 : 0;
-      }
-      __syncthreads();
-      const bool last = *flag != 0;
-      __syncthreads();
-      if (!last) return;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-      for (int sp = 0; sp < a.splits; ++sp) {
-        const unsigned other = ((unsigned)sp * (unsigned)tiles + (unsigned)t) * SLAB + (unsigned)wave * (TM * TN * 4) + lane * 16;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const sk_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wsr, other + ((ni * MI + mi) * 4 + j) * 1024, 0, 16);
-              acc[ni][mi][4 * j] += __uint_as_float(v.x); acc[ni][mi][4 * j + 1] += __uint_as_float(v.y);
-              acc[ni][mi][4 * j + 2] += __uint_as_float(v.z); acc[ni][mi][4 * j + 3] += __uint_as_float(v.w);
-            }
-      }
-      single = true;
-    }
-  }
   if constexpr (!TRANS) {
     const bool interior = m0 + BM <= a.M && (a.n_end & 15) == 0 && single && !a.subpix;
     const int lrow = wm * TM + l31;          // the lane's first row inside the tile

@@ -15,7 +15,6 @@
 void* g_zero_page = nullptr;
 void* g_splitk_ws = nullptr;
 unsigned* g_ln_counters = nullptr;
-unsigned* g_sk_counters = nullptr;
 thread_local bool g_dry_run = false;
 static thread_local char g_err[512] = "";
 static std::mutex g_init_mutex;
@@ -98,8 +97,6 @@ int mg_init(int device) {
   MG_CHECK_HIP(hipMalloc(&g_splitk_ws, MG_SPLITK_WS_BYTES));
   MG_CHECK_HIP(hipMalloc((void**)&g_ln_counters, MG_LN_COUNTERS * sizeof(unsigned)));
   MG_CHECK_HIP(hipMemset(g_ln_counters, 0, MG_LN_COUNTERS * sizeof(unsigned)));
-  MG_CHECK_HIP(hipMalloc((void**)&g_sk_counters, MG_SK_COUNTERS * sizeof(unsigned)));
-  MG_CHECK_HIP(hipMemset(g_sk_counters, 0, MG_SK_COUNTERS * sizeof(unsigned)));
   g_device = device;
   return 0;
 }

@@ -16,6 +16,7 @@ import torch
 
 from . import _lib as L
 from . import ops as O
+from . import tuning
 from . import weights as Wm
 from .arch import UNetConfig, VAEConfig, unet_up_resnet_channels
 
@@ -41,6 +42,8 @@ VAE_FLASH_SMALL_MIN_BLOCKS = _tune("MARIGOLD_VAE_FLASH_MIN_BLOCKS", 0)   # flash
 IGEMM73_CONV = _tune("MARIGOLD_IGEMM73_CONV", True)     # plain N = 320 k convolutions on the hand-placed 192 x 320 GEMM tile
 IGEMM72_VAE = _tune("MARIGOLD_IGEMM72_VAE", True)       # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
 GN_SLAB = _tune("MARIGOLD_GN_SLAB", True)               # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
+GN_SLAB_MIN_WG = _tune("MARIGOLD_GN_SLAB_MIN_WG", 64)   # ... from this many (image, channel window) workgroups,
+GN_SLAB_SMALL_KB = _tune("MARIGOLD_GN_SLAB_SMALL_KB", 48)   # or fewer when a workgroup's share of the tensor is at most this (small ensembles)
 ROWGEMM = _tune("MARIGOLD_ROWGEMM", True)               # row-resident GEMM (MG_OP_ROWGEMM) for the K = 320 token-local layers
 XATTN_KSPLIT = _tune("MARIGOLD_XATTN_KSPLIT", True)     # deep-level collapsed cross-attention as the K-split kernel
 ROWGEMM_WIDE = _tune("MARIGOLD_ROWGEMM_WIDE", True)     # ... and its K = 640 form for the 640-channel level's QKV / GEGLU
@@ -268,7 +271,7 @@ class Builder:
         return self.persist[key]
 
     def add(self, op, label):
-        self.seq.add(op, label)
+        self.seq.add(tuning.apply(op), label)   # (MG_OP_IGEMM: the measured tile / split-K choice where the table has one)
 
     # ---- primitive layers ----------------------------------------------------------------
     @staticmethod
@@ -318,7 +321,10 @@ class Builder:
             return False
         cpg = C // self.groups
         cw = cpg * (4 // math.gcd(cpg, 4))
-        if not (16 <= cw <= 128) or HW > 16384 or B * (C // cw) < 64:
+        nwg = B * (C // cw)
+        # (round 5) few workgroups are fine while each one's share is small: a single member's 24 x 24 / 12 x 12 maps (368 KB -
+        # 1.5 MB) took a statistics launch (13-16 us: tickets, last-block finalize) + an apply launch (8-9 us) for lack of 64 of them
+        if not (16 <= cw <= 128) or HW > 16384 or (nwg < GN_SLAB_MIN_WG and B * HW * C * 2 > nwg * GN_SLAB_SMALL_KB * 1024):
             return False
         # measured per layer (profiles/r3_groupnorm_slab_vs_chunked.log): a slab pass beats statistics + apply only while
         # the tensor is small enough that the chunked passes are launch/latency-bound (<= 16 MiB: UNet levels 2-3), or

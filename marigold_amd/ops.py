@@ -44,7 +44,7 @@ def igemm(a, w, out, *, B, H, W, Cin, Ho, Wo, N, taps=1, stride=1, pad=0, up=Non
           rowvec=None, residual=None, epi=L.EPI_BF16, ldo=None, out2=None, trans_from=-1, ldt=0,
           batch_z=1, ldr=0, lda=0, ldw=0, zstrides=(0, 0, 0, 0), scale=1.0, variant=0,
           rowvec_bcast=False, n_alg=0, k_alg=0, a1=None, C0=0, lda1=0, ln_out=None, ln_in=None, ln_g=None, ln_c=None,
-          ln_eps=1e-5, sm_scale=0.0, sm_cols=0, c2=0, trans_perm=False, ln_counters=None):
+          ln_eps=1e-5, sm_scale=0.0, sm_cols=0, c2=0, trans_perm=False, ln_counters=None, splits=0):
     hu, wu = up if up else (0, 0)
     cp = _ptr(ln_counters) or 0   # the program's own row-block tickets (two int32 halves of the device address)
     c_lo, c_hi = cp & 0xffffffff, (cp >> 32) & 0xffffffff
@@ -54,7 +54,7 @@ def igemm(a, w, out, *, B, H, W, Cin, Ho, Wo, N, taps=1, stride=1, pad=0, up=Non
     return make_op(L.OP_IGEMM,
                    i=[B, H, W, Cin, Ho, Wo, N, taps, stride, pad, hu, wu, epi, ldo, trans_from,
                       batch_z, ldr, lda, ldt, variant, ldw, int(rowvec_bcast), n_alg, k_alg, C0, lda1,
-                      int(trans_perm), sm_cols, c2, c_lo, c_hi],
+                      int(trans_perm), sm_cols, c2, c_lo, c_hi, splits],
                    f=[scale, ln_eps, sm_scale], p=[a, w, out, bias, rowvec, residual, out2, a1, ln_out, ln_in, ln_g, ln_c],
                    l=list(zstrides))
 
