@@ -147,47 +147,22 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   return 0;
 }
 
+// The tiles mg_igemm_auto_variant and the tuning table (marigold_amd/tuning) can name.  (Rounds 1-4 carried ~35 variants for
+// the sweeps - 20-28, 30-34, 37-39, 47-53, 60-63, 70-71, the ablation forms 40-45; their numbers are in profiles/r1_sweep* ...
+// r4_k4w_sweep.log.  Round 5 pruned the list to what a launch can actually run on.)
 template <bool TRANS>
 int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) {
   switch (variant) {
-    case 20: return launch2<256, 128, 4, 2, 3, TRANS>(a, batch_z, s);
-    case 21: return launch2<128, 128, 2, 2, 2, TRANS>(a, batch_z, s);
     case 22: return launch2<128, 128, 4, 2, 3, TRANS>(a, batch_z, s);
     case 23: return launch2<64, 64, 2, 2, 2, TRANS>(a, batch_z, s);
-    case 24: return launch2<256, 64, 4, 2, 3, TRANS>(a, batch_z, s);
-    case 25: return launch2<128, 64, 2, 2, 3, TRANS>(a, batch_z, s);
-    case 26: return launch2<256, 128, 4, 2, 2, TRANS>(a, batch_z, s);
-    case 27: return launch2<128, 128, 2, 2, 3, TRANS>(a, batch_z, s);
-    case 28: return launch2<128, 128, 2, 2, 4, TRANS>(a, batch_z, s);
     case 29: return launch2<128, 32, 4, 1, 3, TRANS>(a, batch_z, s);  // N <= 32 (4 <-> C boundary convs)
     case 54: return launch2<128, 64, 4, 1, 3, TRANS, true>(a, batch_z, s);   // one wave = 32 rows x all 64 columns (MG_EPI_XATTN2)
-    case 30: return launch2<256, 256, 2, 4, 2, TRANS>(a, batch_z, s);
-    case 31: return launch2<256, 128, 4, 2, 2, TRANS, true>(a, batch_z, s);
     case 32: return launch2<128, 128, 2, 2, 2, TRANS, true>(a, batch_z, s);
-    case 33: return launch2<256, 128, 4, 2, 3, TRANS, true>(a, batch_z, s);
-    case 34: return launch2<256, 256, 2, 4, 2, TRANS, true>(a, batch_z, s);
     case 35: return launch2<128, 64, 2, 2, 3, TRANS, true>(a, batch_z, s);
-    case 36: return launch2<256, 128, 4, 2, 3, TRANS, true, true>(a, batch_z, s);   // half-K-step pipelined loops
-    case 37: return launch2<128, 64, 2, 2, 3, TRANS, true, true>(a, batch_z, s);
-    case 38: return launch2<128, 128, 2, 2, 3, TRANS, true, true>(a, batch_z, s);
-    case 39: return launch2<128, 128, 4, 2, 3, TRANS, true, true>(a, batch_z, s);
-    case 50: return launch2<256, 128, 2, 2, 2, TRANS, true, false, 0, 32>(a, batch_z, s);  // BK = 32: 4 waves, wave tile 128x64
-    case 51: return launch2<256, 128, 2, 2, 3, TRANS, true, false, 0, 32>(a, batch_z, s);
-    case 52: return launch2<128, 128, 1, 2, 3, TRANS, true, false, 0, 32>(a, batch_z, s);  // 2 waves, wave tile 128x64
-    case 53: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 0, 32>(a, batch_z, s);  // 8 waves, wave tile 64x64
-    case 60: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 0>(a, batch_z, s);   // ping-pong schedule
-    case 61: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 1>(a, batch_z, s);   //   without s_setprio
-    case 62: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 4>(a, batch_z, s);   //   2nd DMA piece among the MFMAs
-    case 63: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 5>(a, batch_z, s);   //   both
-    case 70:   // 128 x 128 wave tile, one wave per SIMD (igemm2_big.hip): 32-deep K tiles x 4 stages / 64-deep x 2
-      if constexpr (!TRANS) return launch2<256, 256, 2, 2, 4, false, true, false, 0, 32, -1, 0>(a, batch_z, s);
-      else MG_REQUIRE(false, "igemm: tile variant 70 has no transposed section");
-      return 0;
-    case 71:
-      if constexpr (!TRANS) return launch2<256, 256, 2, 2, 2, false, true, false, 0, 64, -1, 1>(a, batch_z, s);
-      else MG_REQUIRE(false, "igemm: tile variant 71 has no transposed section");
-      return 0;
-    case 72:   // the same tile, K loop placed by hand (LOOP == 3): offsets are 32-bit, relative to the operand bases
+    case 36: return launch2<256, 128, 4, 2, 3, TRANS, true, true>(a, batch_z, s);   // half-K-step pipelined loop
+    case 51: return launch2<256, 128, 2, 2, 3, TRANS, true, false, 0, 32>(a, batch_z, s);  // BK = 32: 4 waves, wave tile 128x64
+    case 62: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 4>(a, batch_z, s);   // ping-pong schedule, 2nd DMA piece among the MFMAs
+    case 72:   // 256 x 256 on four waves (one per SIMD, 128 x 128 wave tile), K loop placed by hand (LOOP == 3): offsets are 32-bit, relative to the operand bases
       if constexpr (!TRANS) {
         MG_REQUIRE((long long)(a.M / a.rows_per_img) * a.H * a.W * max(a.lda, a.lda1) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30),
                    "igemm: tile variant 72 addresses its operands with 31-bit byte offsets");
@@ -202,22 +177,7 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
       } else MG_REQUIRE(false, "igemm: tile variant 73 has no transposed section");
       return 0;
     case 46: return launch2<128, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);   // full-width tiles for N = 320
-    case 47:   // (no transposed instantiation: 160 accumulators + the token-major epilogue do not fit 256 VGPRs)
-      if constexpr (!TRANS) return launch2<256, 320, 4, 2, 2, false, true>(a, batch_z, s);
-      else MG_REQUIRE(false, "igemm: tile variant 47 has no transposed section");
-      return 0;
-    case 48: return launch2<128, 320, 4, 2, 2, TRANS, false>(a, batch_z, s);
-    // EXPERIMENTAL (gated tests only): 128x320 with 32-deep K tiles and 4 waves (wave tile 64x160) - 56 KB of LDS, two
-    // workgroups per CU, for the K = C linears of the 320-channel level (one workgroup per CU runs them at half the
-    // streaming bandwidth: load, compute and store phases of a 5-step K loop do not overlap)
-    case 49: return launch2<128, 320, 2, 2, 2, TRANS, true, false, 0, 32>(a, batch_z, s);
-    case 40: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 1>(a, batch_z, s);  // ablations (sweep only)
-    case 41: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 2>(a, batch_z, s);
-    case 42: return launch2<256, 128, 4, 2, 3, TRANS, true, false, 3>(a, batch_z, s);
-    case 43: return launch2<128, 64, 2, 2, 3, TRANS, true, false, 1>(a, batch_z, s);
-    case 44: return launch2<128, 64, 2, 2, 3, TRANS, true, false, 2>(a, batch_z, s);
-    case 45: return launch2<128, 64, 2, 2, 3, TRANS, true, false, 3>(a, batch_z, s);
-    default: MG_REQUIRE(false, "igemm: unknown v2 tile variant %d", variant);
+    default: MG_REQUIRE(false, "igemm: unknown tile variant %d (22, 23, 29, 32, 35, 36, 46, 51, 54, 62, 72, 73)", variant);
   }
   return 0;
 }

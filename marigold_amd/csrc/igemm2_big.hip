@@ -8,12 +8,7 @@
 
 namespace {
 
-template <int NSTAGE, int BK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void igemm2_big_kernel(const Igemm2Args a) {
-  igemm2_body<256, 256, 2, 2, NSTAGE, false, true, 0, 0, BK>(a);
-}
-
-// The same tile with the K loop placed by hand (igemm2_body.h, LOOP == 3; gen_k4w.py): buffer-load LDS-DMA on SGPR bases,
+// The tile with the K loop placed by hand (igemm2_body.h, LOOP == 3; gen_k4w.py): buffer-load LDS-DMA on SGPR bases,
 // whole-tile fragment sets, the next-but-one K tile in flight.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void igemm2_k4w_kernel(const Igemm2Args a) {
   igemm2_body<256, 256, 2, 2, 2, false, false, 3, 0, 64>(a);
@@ -26,10 +21,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace
 
-// which: 0 = 32-deep K tiles, 4 stages (128 KB of LDS); 1 = 64-deep K tiles, 2 stages; 2 = the hand-placed K loop.  The argument struct has the same
-// layout in every translation unit (igemm2_body.h); the pointer is launched by igemm2.hip::launch2.
+// which: 2 = the hand-placed 256 x 256 tile, 3 = its 192 x 320 sibling.  The argument struct has the same layout in every
+// translation unit (igemm2_body.h); the pointer is launched by igemm2.hip::launch2.
 void* mg_igemm2_big_kernel(int which) {
-  if (which == 2) return (void*)igemm2_k4w_kernel;
-  if (which == 3) return (void*)igemm2_k4wb_kernel;
-  return which == 0 ? (void*)igemm2_big_kernel<4, 32> : (void*)igemm2_big_kernel<2, 64>;
+  return which == 3 ? (void*)igemm2_k4wb_kernel : (void*)igemm2_k4w_kernel;
 }

@@ -56,50 +56,39 @@ CONV_CASES = [
     ("up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 0),
     ("up_to_size", 1, 4, 6, 64, 64, 1, 1, (7, 11), 0),
     ("auto_big", 4, 32, 32, 192, 256, 1, 1, None, 0),
-    # every tile variant of the implicit-GEMM kernel (LDS ring + counted vmcnt + 16-byte epilogue)
-    ("g2_256x128x3", 2, 16, 24, 128, 128, 1, 1, None, 20),
-    ("g2_128x128x2", 2, 12, 20, 64, 128, 1, 1, None, 21),
+    # every tile of the implicit-GEMM kernel a launch can name (igemm2.hip::dispatch_tile): LDS ring + counted vmcnt + 16-byte epilogue
+    ("g2_256x128x3", 2, 16, 24, 128, 128, 1, 1, None, 36),
+    ("g2_128x128x2", 2, 12, 20, 64, 128, 1, 1, None, 32),
     ("g2_128x128w8", 2, 12, 20, 64, 192, 1, 1, None, 22),
     ("g2_64x64", 1, 9, 7, 64, 64, 1, 1, None, 23),
-    ("g2_256x64", 2, 16, 24, 128, 320, 1, 1, None, 24),
-    ("g2_128x64", 2, 12, 20, 192, 64, 1, 1, None, 25),
-    ("g2_256x128x2", 1, 24, 24, 64, 128, 1, 1, None, 26),
-    ("g2_128x128x3", 2, 12, 20, 320, 320, 1, 1, None, 27),
-    ("g2_128x128x4", 2, 12, 20, 320, 320, 1, 1, None, 28),
-    ("g2_kt1_stride2", 2, 16, 16, 64, 64, 2, 1, None, 20),
-    ("g2_stride2_pad0", 1, 16, 24, 128, 128, 2, 0, None, 27),
-    ("g2_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 20),
+    ("g2_256x64", 2, 16, 24, 128, 320, 1, 1, None, 35),
+    ("g2_128x64", 2, 12, 20, 192, 64, 1, 1, None, 35),
+    ("g2_256x128x2", 1, 24, 24, 64, 128, 1, 1, None, 36),
+    ("g2_128x128x3", 2, 12, 20, 320, 320, 1, 1, None, 32),
+    ("g2_kt1_stride2", 2, 16, 16, 64, 64, 2, 1, None, 36),
+    ("g2_stride2_pad0", 1, 16, 24, 128, 128, 2, 0, None, 32),
+    ("g2_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 36),
     ("g2_up_to_size", 1, 4, 6, 64, 64, 1, 1, (7, 11), 23),
-    ("g2_big_k", 1, 12, 12, 1280, 128, 1, 1, None, 20),
-    ("g2_256x256", 2, 16, 24, 128, 320, 1, 1, None, 30),
-    ("g2_split_256x128", 2, 16, 24, 128, 192, 1, 1, None, 31),
-    ("g2_split_128x128", 2, 12, 20, 320, 320, 1, 1, None, 32),
-    ("g2_split_3stage", 2, 16, 24, 128, 128, 2, 1, None, 33),
-    ("g2_split_256x256", 2, 16, 24, 192, 320, 1, 1, (32, 48), 34),
+    ("g2_big_k", 1, 12, 12, 1280, 128, 1, 1, None, 36),
+    ("g2_256x256", 2, 16, 24, 128, 320, 1, 1, None, 62),
+    ("g2_split_256x128", 2, 16, 24, 128, 192, 1, 1, None, 36),
+    ("g2_split_3stage", 2, 16, 24, 128, 128, 2, 1, None, 36),
+    ("g2_split_256x256", 2, 16, 24, 192, 320, 1, 1, (32, 48), 62),
     ("g2_split_128x64", 1, 9, 7, 128, 64, 1, 1, None, 35),
-    ("g2_pipe_256x128", 2, 16, 24, 128, 192, 1, 1, None, 36),
-    ("g2_pipe_128x64_kt1", 2, 12, 12, 64, 320, 2, 1, None, 37),
-    ("g2_pipe_128x128", 1, 14, 14, 320, 128, 1, 1, None, 38),
-    ("g2_pipe_128x128w8_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 39),
+    ("g2_pipe_128x64_kt1", 2, 12, 12, 64, 320, 2, 1, None, 35),
+    ("g2_pipe_128x128", 1, 14, 14, 320, 128, 1, 1, None, 32),
+    ("g2_pipe_128x128w8_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 22),
     ("g2_auto_split_n320", 10, 72, 72, 64, 320, 1, 1, None, 0),   # 128k+64 columns: main + 64-wide tail launch
     ("g2_auto_small_m", 2, 12, 12, 128, 640, 1, 1, None, 0),
-    ("g2_bk32_256x128_w4", 2, 16, 24, 128, 192, 1, 1, None, 50),
+    ("g2_bk32_256x128_w4", 2, 16, 24, 128, 192, 1, 1, None, 51),
     ("g2_bk32_3stage_stride2", 2, 16, 16, 64, 128, 2, 1, None, 51),
-    ("g2_bk32_128x128_w2", 1, 14, 14, 320, 128, 1, 1, None, 52),
-    ("g2_bk32_w8_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 53),
-    ("g2_pingpong_up_nedge", 2, 16, 24, 192, 320, 1, 1, (32, 48), 60),   # 27 K tiles over 9 taps, N edge, 12 M tiles
-    ("g2_pingpong_kt9_stride2", 2, 16, 16, 64, 64, 2, 1, None, 60),
-    ("g2_pingpong_big_k_medge", 1, 13, 12, 1280, 256, 1, 1, None, 60),   # 180 K tiles, M = 156 (one partial tile)
-    ("g2_pingpong_mid_up_nedge", 2, 16, 24, 192, 320, 1, 1, (32, 48), 62),   # 2nd DMA piece issued among the MFMAs
-    ("g2_pingpong_mid_kt9_stride2", 2, 16, 16, 64, 64, 2, 1, None, 63),
-    ("g2_big_bk32_up_nedge", 2, 16, 24, 192, 320, 1, 1, (32, 48), 70),   # 128 x 128 wave tile (igemm2_big.hip), 4 stages of 32
-    ("g2_big_bk32_kt9_stride2", 2, 16, 16, 64, 64, 2, 1, None, 70),
-    ("g2_big_bk64_big_k_medge", 1, 13, 12, 1280, 256, 1, 1, None, 71),   # 2 stages of 64, M = 156 (one partial tile)
-    ("g2_big_bk64_up_nedge", 2, 16, 24, 192, 320, 1, 1, (32, 48), 71),
+    ("g2_bk32_w8_up2", 2, 6, 10, 64, 128, 1, 1, (12, 20), 51),
+    ("g2_pingpong_kt9_stride2", 2, 16, 16, 64, 64, 2, 1, None, 62),
+    ("g2_pingpong_big_k_medge", 1, 13, 12, 1280, 256, 1, 1, None, 62),   # 180 K tiles, M = 156 (one partial tile)
+    ("g2_big_bk32_up_nedge", 2, 16, 24, 192, 320, 1, 1, (32, 48), 72),   # 128 x 128 wave tile (igemm2_big.hip), 4 stages of 32
+    ("g2_big_bk32_kt9_stride2", 2, 16, 16, 64, 64, 2, 1, None, 72),
+    ("g2_big_bk64_big_k_medge", 1, 13, 12, 1280, 256, 1, 1, None, 72),   # 2 stages of 64, M = 156 (one partial tile)
     # the hand-placed one-wave-per-SIMD K loop (buffer-load LDS-DMA: padding rows / M / N edges are out-of-range offsets)
-    ("g2_k4w_up_nedge", 2, 16, 24, 192, 320, 1, 1, (32, 48), 72),       # 27 K tiles over 9 taps, N edge, 12 M tiles
-    ("g2_k4w_kt9_stride2", 2, 16, 16, 64, 64, 2, 1, None, 72),           # one K tile per tap: a segment per tile
-    ("g2_k4w_big_k_medge", 1, 13, 12, 1280, 256, 1, 1, None, 72),        # 180 K tiles, M = 156 (one partial tile)
     ("g2_k4w_up_to_size", 1, 4, 6, 64, 64, 1, 1, (7, 11), 72),
     ("g2_k4w_stride2_pad0", 1, 16, 24, 128, 128, 2, 0, None, 72),
     ("g2_k4wb_up_nedge", 2, 16, 24, 192, 640, 1, 1, (32, 48), 73),       # 192 x 320 tile: 27 K tiles over 9 taps, 16 M tiles
@@ -107,8 +96,8 @@ CONV_CASES = [
     ("g2_k4wb_big_k_medge", 1, 13, 12, 1280, 320, 1, 1, None, 73),       # 180 K tiles, M = 156 (one partial tile)
     ("g2_k4wb_nedge", 1, 14, 14, 128, 256, 1, 1, None, 73),              # N = 256 < 320: out-of-range weight rows
     ("g2_128x320", 2, 12, 20, 128, 320, 1, 1, None, 46),
-    ("g2_256x320", 2, 12, 20, 64, 640, 1, 1, None, 47),
-    ("g2_128x320_burst", 1, 12, 12, 320, 320, 1, 1, None, 48),
+    ("g2_256x320", 2, 12, 20, 64, 640, 1, 1, None, 46),
+    ("g2_128x320_burst", 1, 12, 12, 320, 320, 1, 1, None, 46),
     ("g2_auto_splitk", 1, 12, 12, 1280, 128, 1, 1, None, 0),        # 6 tiles x 8 K-splits + reduce kernel
     ("g2_auto_splitk_n320", 1, 9, 7, 640, 320, 1, 1, None, 0),
     ("g2_auto_splitk_up2", 1, 6, 6, 1280, 256, 1, 1, (12, 12), 0),
@@ -395,7 +384,7 @@ def test_igemm_two_sources_and_gn_channel_windows(dev):
     xh = _nhwc(x)
     a0 = xh[..., :C0].contiguous().to(dev, torch.bfloat16)
     a1 = xh[..., C0:].contiguous().to(dev, torch.bfloat16)
-    for taps, variant in ((1, 0), (9, 0), (9, 62), (1, 53), (9, 33), (9, 72), (1, 72), (9, 73), (1, 73)):
+    for taps, variant in ((1, 0), (9, 0), (9, 62), (1, 51), (9, 36), (9, 72), (1, 72), (9, 73), (1, 73)):
         w = _bf(torch.randn(N, Cin, 3, 3, generator=g) / math.sqrt(taps * Cin)) if taps == 9 else _bf(torch.randn(N, Cin, 1, 1, generator=g) / math.sqrt(Cin))
         ref = F.conv2d(x, w, None, padding=1 if taps == 9 else 0)
         wd = (Wm.pack_conv3x3(w) if taps == 9 else w.reshape(N, Cin)).to(dev, torch.bfloat16)
@@ -459,7 +448,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = torch.randn(N, generator=g) * 0.1
     ref = x @ w.t() + b
-    for variant in (0, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 46, 50, 51, 52, 53, 60, 61, 62, 63, 70, 71, 72, 73):
+    for variant in (0, 22, 23, 32, 35, 36, 46, 51, 62, 72, 73):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N,
                         bias=b.to(dev), variant=variant))
@@ -471,7 +460,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     xg = _bf(torch.randn(200, C, generator=g))
     u, gt = (xg @ wg.t() + bg).chunk(2, dim=-1)
     ref = u * F.gelu(gt)
-    for group, variants in ((32, (20, 23, 24, 27, 34, 53, 60, 62, 70, 71, 72, 73, 0)),):
+    for group, variants in ((32, (22, 23, 32, 35, 36, 51, 62, 72, 73, 0)),):
         wp, bp = Wm.pack_geglu(wg, bg, group)
         for variant in variants:
             out = torch.full((200, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
@@ -488,7 +477,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     qk = torch.full((B * T, 3 * C), float("nan"), device=dev, dtype=torch.bfloat16)
     vt = torch.zeros((B, C, ldt), device=dev, dtype=torch.bfloat16)
     refv = refq[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1)
-    for variant in (0, 20, 23, 27, 60, 62):
+    for variant in (0, 23, 32, 35, 62):
         qk.fill_(float("nan"))
         vt.zero_()
         _run(ops.igemm(xq.to(dev, torch.bfloat16), wqkv.to(dev, torch.bfloat16), qk, B=B, H=T, W=1, Cin=C,
@@ -516,7 +505,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     refS = torch.einsum("ztd,zsd->zts", qkv[..., :D], qkv[..., D:2 * D]) * 0.25
     qd = qkv.to(dev, torch.bfloat16)
     S = torch.full((Z, T, T), float("nan"), device=dev, dtype=torch.float32)
-    for variant in (0, 20, 27, 60):
+    for variant in (0, 23, 32, 62):
         S.fill_(float("nan"))
         _run(ops.igemm(qd, qd[:, :, D:], S, B=1, H=T, W=1, Cin=D, Ho=T, Wo=1, N=T, epi=L.EPI_F32, ldo=T,
                        lda=3 * D, ldw=3 * D, batch_z=Z, zstrides=(T * 3 * D, T * 3 * D, T * T, 0),
@@ -543,7 +532,7 @@ def test_igemm_layernorm_fold(dev):
     b0 = torch.randn(C, generator=g) * 0.1
     res = _bf(torch.randn(M, C, generator=g))
     ref0 = a @ w0.t() + b0 + res
-    for variant in (0, 46, 53, 35, 62, 70, 71, 72, 73):
+    for variant in (0, 46, 51, 35, 62, 72, 73):
         out = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
         st = torch.full((M * (C // 32 + 1), 2), float("nan"), device=dev)
         for rep_ in range(3):   # the tickets reset themselves: every launch finalizes again
@@ -566,7 +555,7 @@ def test_igemm_layernorm_fold(dev):
     b = torch.randn(N, generator=g) * 0.1
     wp, gv, cv = Wm.fold_layernorm(w, b, gamma, beta)
     ref = y @ w.t() + b
-    for variant in (0, 20, 46, 53, 62, 70, 71, 72, 73):
+    for variant in (0, 36, 46, 51, 62, 72, 73):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(xd, wp.to(dev), out, M=M, K=C, N=N, ln_in=stx, ln_g=gv.to(dev), ln_c=cv.to(dev), variant=variant))
         _close(f"ln_fold/bf16/v{variant}", out, ref, tol=2e-2)
@@ -580,7 +569,7 @@ def test_igemm_layernorm_fold(dev):
     refg = u * F.gelu(gt)
     wpk, bpk = Wm.pack_geglu(wg, bg)
     wpg, gg, cg = Wm.fold_layernorm(wpk, bpk, gamma, beta)
-    for variant in (0, 53, 62, 70, 71, 72, 73):
+    for variant in (0, 51, 62, 72, 73):
         og = torch.full((M, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(xd, wpg.to(dev), og, M=M, K=C, N=8 * C, epi=L.EPI_GEGLU, ln_in=stx, ln_g=gg.to(dev), ln_c=cg.to(dev),
                         variant=variant))
@@ -948,7 +937,7 @@ def test_igemm_row_statistics_bit_stable_at_scale(dev):
     object is built with -fno-slp-vectorize since; tools/det_stress.py is the long form of this test.)"""
     from marigold_amd import ops
     g = torch.Generator().manual_seed(3)
-    for M, K, N, variants in ((5760, 1280, 1280, (35, 0)), (23040, 640, 640, (35, 21)), (92160, 64, 320, (35, 0))):
+    for M, K, N, variants in ((5760, 1280, 1280, (35, 0)), (23040, 640, 640, (35, 32)), (92160, 64, 320, (35, 0))):
         a = (torch.randn(M, K, generator=g) * 0.5).to(dev, torch.bfloat16)
         w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev, torch.bfloat16)
         b = torch.randn(N, generator=g).to(dev)
@@ -1048,7 +1037,7 @@ def test_igemm_fused_cross_attention(dev):
 
 
 def test_igemm_pingpong_short_k_and_repeatability(dev):
-    """Tile variant 60 (two wave groups one barrier apart, four phases per K tile): the one- and two-tile K loops
+    """Tile variant 62 (two wave groups one barrier apart, four phases per K tile): the one- and two-tile K loops
     (prologue / drain only), and a many-tile problem launched repeatedly - every launch must give the same bits
     (a staged half tile read before its DMA landed would show up as run-to-run differences)."""
     from marigold_amd import ops
@@ -1059,9 +1048,9 @@ def test_igemm_pingpong_short_k_and_repeatability(dev):
         b = torch.randn(N, generator=g) * 0.1
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N, bias=b.to(dev),
-                        variant=60))
+                        variant=62))
         _close(f"pingpong/linear K={K}", out, x @ w.t() + b)
-        for v in (62, 63, 72, 73):
+        for v in (72, 73):
             out.fill_(float("nan"))
             _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N, bias=b.to(dev),
                             variant=v))
@@ -1071,15 +1060,25 @@ def test_igemm_pingpong_short_k_and_repeatability(dev):
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     xd, wd = x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16)
     ref = x @ w.t()
-    out34 = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
-    _run(ops.linear(xd, wd, out34, M=M, K=K, N=N, variant=34))
-    _close("linear 8192x2304x768 v34", out34, ref)
-    for v in (60, 61, 62, 63, 72):
+    out62 = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    _run(ops.linear(xd, wd, out62, M=M, K=K, N=N, variant=62))
+    _close("linear 8192x2304x768 v62", out62, ref)
+    for v in (62, 72):
         for rep in range(4):
             out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
             _run(ops.linear(xd, wd, out, M=M, K=K, N=N, variant=v))
-            # same MFMA sequence per accumulator as the one-barrier 256x256 tile -> identical bits, every launch
-            assert torch.equal(out, out34), f"v{v} launch {rep} differs from the one-barrier tile"
+            # same MFMA sequence per accumulator in the ping-pong and the hand-placed 256 x 256 tiles -> identical bits, every launch
+            assert torch.equal(out, out62), f"v{v} launch {rep} differs from the first ping-pong launch"
+    # split-K named by the op (i[31]; the tuning table's second field): fp32 partials + the fixed-order reduce launch, any tile
+    for v, sp in ((36, 2), (73, 3), (72, 4), (23, 8), (0, 6)):
+        first = None
+        for rep in range(2):
+            out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+            _run(ops.linear(xd, wd, out, M=M, K=K, N=N, variant=v, splits=sp))
+            if first is None:
+                first = out.clone()
+                _close(f"linear 8192x2304x768 v{v} split {sp}", out, ref)
+            assert torch.equal(out, first), f"v{v} split {sp}: launches differ"
 
 
 # --------------------------------------------------------------------------- norms

@@ -444,6 +444,23 @@ def test_ensemble_depth_metric_config_vs_reference(golden_dir):
     assert m["rmse"] < 8e-3 and m["delta1"] > 0.99 and m["abs_rel"] < 2e-2
     assert diff.mean() < 1e-2 and diff.max() < 5e-2
     assert du.max() < 5e-2
+    # The yardstick (round 5): the reference does not reproduce ITSELF more closely than this.  Its optimiser stops where the
+    # fp32 summation noise of its cost swamps the finite differences, and that noise changes with the CPU thread count:
+    # oracle/ref_ensemble_spread.py ran the reference on these members with 4, 8 and 16 threads (8 = the golden above, bit for
+    # bit) - the three outputs differ from one another by max 1.2-1.6e-2, mean 4.3-4.9e-3, delta1 0.9959-0.9976
+    # (profiles/r5_reference_ensemble_thread_spread.log).  The engine's deterministic output must sit inside that band:
+    # its mean deviation from EVERY reference run at most 1.5 x the largest mean deviation between two reference runs.
+    thr = np.load(os.path.join(golden_dir, "ensemble_ref_768_threads.npz"))
+    refs = {8: ref, 4: thr["d_real_e10_768_out_t4"].astype(np.float32), 16: thr["d_real_e10_768_out_t16"].astype(np.float32)}
+    keys = sorted(refs)
+    spread_mean = max(float(np.abs(refs[a] - refs[b]).mean()) for i, a in enumerate(keys) for b in keys[i + 1:])
+    spread_max = max(float(np.abs(refs[a] - refs[b]).max()) for i, a in enumerate(keys) for b in keys[i + 1:])
+    ours = {k: np.abs(got - v) for k, v in refs.items()}
+    print(f"[parity] ensemble_depth vs the reference run with 4 / 8 / 16 threads: mean |diff| " +
+          " / ".join(f"{ours[k].mean():.2e}" for k in keys) + ", max " + " / ".join(f"{ours[k].max():.2e}" for k in keys) +
+          f"; the reference runs among themselves: mean up to {spread_mean:.2e}, max up to {spread_max:.2e}")
+    assert max(float(v.mean()) for v in ours.values()) <= 1.5 * spread_mean
+    assert max(float(v.max()) for v in ours.values()) <= 2.0 * spread_max
 
 
 def _mp_worker(rank, world, port, q, hw=(64, 128)):

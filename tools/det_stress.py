@@ -9,7 +9,7 @@ for (M, K, N) in ((5760, 1280, 1280), (92160, 64, 320), (23040, 640, 640), (9216
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev, torch.bfloat16)
     b = torch.randn(N, generator=g).to(dev)
     h0 = torch.randn(M, N, generator=g).to(dev, torch.bfloat16)
-    for variant in (35, 0, 32, 21, 33, 51):
+    for variant in (35, 0, 32, 36, 51):
         for mode in ("ln_out", "plain"):
             first, nd = None, 0
             for it in range(10):

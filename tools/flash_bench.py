@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from marigold_amd import _lib as L, ops as O  # noqa: E402
 
-VARIANTS = tuple(int(v) for v in os.environ.get("FLASH_VARIANTS", "6,9,10").split(","))
+VARIANTS = tuple(int(v) for v in os.environ.get("FLASH_VARIANTS", "25,26,27").split(","))
 ROUNDS = int(os.environ.get("FLASH_ROUNDS", "5"))
 dev = torch.device("cuda:0")
 L.init(0)
@@ -61,7 +61,7 @@ def _case(B, heads, T, qscale=1.0):
         outs[v] = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
         vv = 26 if v == 27 else v     # 27 = variant 26 with the key-split workspace
         ops[v] = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25, 26, 27)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
-                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=vv, vt_perm=(13 <= v <= 20 or v in (22, 23, 25, 26, 27)),
+                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=vv, vt_perm=(v in (19, 20, 25, 26, 27)),
                                 ws=WS if v == 27 else None, ws_bytes=O.FLASH_WS_BYTES if v == 27 else 0)
     for rnd in range(ROUNDS):
         for v in VARIANTS:
@@ -101,7 +101,7 @@ def _case(B, heads, T, qscale=1.0):
             nwg = -(-T // (nw * 32)) * heads * B
             dbg = torch.zeros(nwg * nw * 8, dtype=torch.int64, device=dev)
             op = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25, 26)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
-                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(13 <= v <= 20 or v in (22, 23, 25, 26)), dbg=dbg)
+                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(v in (19, 20, 25, 26, 27)), dbg=dbg)
             O.launch(op)
             O.launch(op)
             torch.cuda.synchronize()

@@ -19,8 +19,8 @@ vt = qkv[:, :, 2 * C:].permute(0, 2, 1).contiguous()
 vtp = O.permute_vt_keys(vt)
 out = torch.empty(B, T, C, device=dev, dtype=torch.bfloat16)
 ws = torch.zeros(O.FLASH_WS_BYTES, dtype=torch.uint8, device=dev)
-for v in [int(x) for x in os.environ.get("FLASH_VARIANTS", "6,10,14,16,17").split(",")]:
-    perm = 13 <= v <= 20 or v in (22, 23, 25, 26)
+for v in [int(x) for x in os.environ.get("FLASH_VARIANTS", "25,26").split(",")]:
+    perm = v in (19, 20, 25, 26)
     op = O.flash_attn64(qkv, qkv[:, :, C:], vtp if perm else vt, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=T,
                         sq=T * 3 * C, sk=T * 3 * C, svt=C * T, so=T * C, scale=0.125, variant=v, vt_perm=perm,
                         ws=ws if v == 26 else None, ws_bytes=O.FLASH_WS_BYTES if v == 26 else 0)
