@@ -302,6 +302,10 @@ int mg_ens_align_minimize(const mg_op* reg_op, void* stream, int E, int affine, 
  * workgroups; tflops = the chain's rate (the clock-limited MFMA roof of this box on this data).  Synchronises the stream. */
 int mg_clock_probe(void* stream, int zero_operands, double* mhz, double* tflops);
 
+/* Tuning only (MARIGOLD_TUNING=1 MARIGOLD_IGEMM_STAMPS=1): the per-workgroup phase stamps of the last forced-tile MG_OP_IGEMM
+ * launch (8 x uint64 of the 100 MHz s_memrealtime per workgroup, in the split-K workspace) -> host.  tools/igemm_phases.py. */
+int mg_debug_read_workspace(void* host_dst, long long bytes);
+
 /* HIP-event timing helpers for bench.py (the kernels run on the caller's stream). */
 void* mg_event_create(void);
 int mg_event_record(void* ev, void* stream);

@@ -35,7 +35,7 @@ EXPORTS = [
     "mg_program_create", "mg_program_num_ops", "mg_program_run", "mg_program_validate", "mg_program_run_range",
     "mg_program_capture", "mg_program_profile", "mg_program_destroy", "mg_conv2d_igemm", "mg_conv3x3", "mg_conv3x3_gn_slots", "mg_flash4w_plan_test",
     "mg_sched_step", "mg_ensemble_normals", "mg_ens_align_cost_grad", "mg_bfgs_minimize", "mg_ens_align_minimize", "mg_event_create", "mg_event_record",
-    "mg_event_elapsed_ms", "mg_event_destroy", "mg_clock_probe",
+    "mg_event_elapsed_ms", "mg_event_destroy", "mg_clock_probe", "mg_debug_read_workspace",
 ]
 
 
@@ -93,6 +93,7 @@ def load():
     lib.mg_device_info.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                    ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_int]
     lib.mg_clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    lib.mg_debug_read_workspace.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
     lib.mg_event_create.restype = ctypes.c_void_p
     lib.mg_event_record.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.mg_event_elapsed_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]

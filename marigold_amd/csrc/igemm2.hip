@@ -233,6 +233,10 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.sm_cols = op->i[27];
   a.tperm = op->i[26];
   a.w2 = nullptr;
+  {   // tuning only: phase stamps of every workgroup into the (otherwise idle) split-K workspace - tools/igemm_phases.py
+    static const int st = mg_tuning_int("MARIGOLD_IGEMM_STAMPS", 0);
+    a.stamps = (st && op->i[31] <= 1 && variant) ? (unsigned long long*)g_splitk_ws : nullptr;
+  }
   a.c2 = 0;
   a.inv_c2 = 0.0;
   if (a.epi == MG_EPI_XATTN2) {

@@ -53,6 +53,8 @@ struct Igemm2Args {
   int tperm;         // transposed section: tokens stored in ACCUMULATOR order inside every group of 16 ([0-3, 8-11, 4-7, 12-15] -
                      // what flash_attn64's generation 3 consumes without a lane exchange; no regroup here either)
   const bf16_t* w2;  // MG_EPI_XATTN2: second-stage weights [c2][64]
+  unsigned long long* stamps;   // tuning only (MARIGOLD_IGEMM_STAMPS=1, tools/igemm_phases.py): per workgroup 8 x s_memrealtime (100 MHz)
+                                // at kernel entry / operands addressed / first tile landed / K loop done / outputs stored / exit
   int c2;
   double inv_c2;
 };
@@ -121,6 +123,10 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   const int l31 = lane & 31, half = lane >> 5;
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  auto stamp = [&](int k) {
+    if (a.stamps && tid == 0) a.stamps[(long long)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
+  };
+  stamp(0);
   const int tiles = a.tiles_m * a.tiles_n;
   const int per_z = tiles * a.splits;
   const int z = fdiv(bid, a.fd_per_z);
@@ -282,6 +288,8 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   if constexpr (!PP && !K4) {
     ln_publish();
     zero_acc();
+    stamp(1);
+    stamp(2);
   }
   int st_c = 0;                 // stage holding tile kt
   int st_i = D % NSTAGE;        // stage receiving tile kt + D
@@ -456,6 +464,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) fb4[ks][i] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
     }
+    stamp(1);
     stage_tile();                 // tile 0 -> buffer 0
     if (KT > 1) stage_tile();     // tile 1 -> buffer 1
     ln_publish();
@@ -463,6 +472,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     if (KT > 1) wait_vmcnt<A_IT + B_IT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    stamp(2);
 #define K4W_C(ni, mi) [c##ni##mi] "+a"(acc[ni][mi])
 #define K4W_A(ks, i) [a##ks##i] "+v"(fa4[ks][i])
 #define K4W_B(ks, i) [b##ks##i] "+v"(fb4[ks][i])
@@ -754,6 +764,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     for (; kt < KT; ++kt) k_step(std::false_type{}, std::false_type{});
   }
 
+  stamp(3);
   // ---------------- epilogue ----------------
   // Latency structure (round 2: the first version loaded bias / LayerNorm vectors / residual inside the innermost
   // (mi, ni, gp) iteration, behind branches and behind the previous iteration's stores - ~50 serialized L2 round trips
@@ -1125,7 +1136,9 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
         default: done = false;
       }
       if (done) {
+        stamp(4);
         if (fLNO) ln_out_finish();
+        stamp(5);
         return;
       }
     }

@@ -323,6 +323,15 @@ int mg_clock_probe(void* stream, int zero_operands, double* mhz, double* tflops)
   return 0;
 }
 
+// Tuning only: copy the first `bytes` of the split-K workspace (where MARIGOLD_IGEMM_STAMPS=1 launches leave their phase stamps)
+// to the host.  Synchronises the device.
+int mg_debug_read_workspace(void* host_dst, long long bytes) {
+  MG_REQUIRE(host_dst && bytes > 0 && bytes <= MG_SPLITK_WS_BYTES && g_splitk_ws, "mg_debug_read_workspace: bad arguments");
+  MG_CHECK_HIP(hipDeviceSynchronize());
+  MG_CHECK_HIP(hipMemcpy(host_dst, g_splitk_ws, (size_t)bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 void* mg_event_create(void) {
   hipEvent_t e = nullptr;
   if (hipEventCreate(&e) != hipSuccess) return nullptr;
