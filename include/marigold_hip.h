@@ -259,6 +259,42 @@ int mg_program_capture(mg_program* prog, void* stream);
 int mg_program_profile(mg_program* prog, void* stream, float* ms);
 void mg_program_destroy(mg_program* prog);
 
+/* Module-level entry points over a MODEL IMAGE: the pipeline's three native programs for one problem shape (image size,
+ * members per call, scheduler steps), their kernel-ready weights and a memory plan, written once by
+ * marigold_amd/image.py::export_model_image and run from any host language without Python.  They stand where single_infer's
+ * calls stand (marigold/marigold_depth_pipeline.py:396-477): encode_rgb (:479-496), the T-step unet + scheduler.step loop
+ * (:455-468), decode_depth / decode_normals (:498-516, :473-475).  All device pointers are the caller's (fp32, NCHW, contiguous);
+ * the model owns its weights and workspace (one device allocation, mg_model_device_bytes).  One stream at a time per model.
+ *  mg_model_load(path, device): device >= 0 binds the library to that GPU (mg_init) and uploads; device < 0 = host-only: the
+ *  image is parsed and relocated against fake addresses so that mg_model_validate can check every op's contract without a GPU.
+ *  mg_model_info: cfg16 = B, H, W, latent h, latent w, steps, prediction channels, MG_POST_*, step-noise tensors, sizeof(mg_op),
+ *  modalities, decoded H, decoded W.
+ *  mg_model_vae_encode: rgb [1,3,H,W] in [-1,1] -> latent [1,4,h,w] (x 0.18215, posterior mean).
+ *  mg_model_denoise: rgb_latent [1,4,h,w], x [B,C,h,w] in / out (the initial noise -> the denoised latent), step_noise
+ *  [n][B,C,h,w] for the LCM scheduler's n noisy steps (NULL for DDIM).
+ *  mg_model_vae_decode: latent [B*modalities,4,h,w] -> pred [B, channels, Hout, Wout] with the pipeline's pointwise tail. */
+typedef struct mg_model mg_model;
+mg_model* mg_model_load(const char* path, int device);
+void mg_model_destroy(mg_model* m);
+int mg_model_info(const mg_model* m, int* cfg16);
+long long mg_model_device_bytes(const mg_model* m);
+int mg_model_validate(mg_model* m);
+int mg_model_vae_encode(mg_model* m, const float* rgb, float* latent, void* stream);
+int mg_model_denoise(mg_model* m, const float* rgb_latent, float* x, const float* step_noise, void* stream);
+int mg_model_vae_decode(mg_model* m, const float* latent, float* pred, void* stream);
+
+/* ensemble_depth(depth[E,1,H,W], scale_invariant, shift_invariant, output_uncertainty, reduction, regularizer_strength, max_iter,
+ * tol, max_res) of marigold/util/ensemble.py:39-196 as ONE call on device pointers: member statistics, init_param, the native
+ * scipy-BFGS alignment (mg_ens_align_minimize), align -> median (+ MAD) | mean (+ std) -> min / max normalisation.  preds fp32
+ * [E][H*W]; depth_out [H*W]; unc_out [H*W] | NULL; reduction 0 median / 1 mean; max_res <= 0 = no down-sampling for the alignment;
+ * info4 (optional) = achieved cost, cost evaluations, BFGS iterations, scipy's status (0 converged, 1 maxiter, 2 precision loss,
+ * 3 NaN -> the alignment falls back to its starting point).  Same results as marigold_amd.ensemble.ensemble_depth, bit for bit
+ * (tests/test_gpu_pipeline.py).  The reference's ValueErrors come back as error messages with the reference's texts.
+ * Synchronises the stream. */
+int mg_ensemble_depth(const float* preds, int E, int H, int W, int scale_invariant, int shift_invariant, int reduction,
+                      double regularizer_strength, int max_iter, double tol, int max_res, float* depth_out, float* unc_out,
+                      double* info4, void* stream);
+
 /* Named wrappers - what a binding for the reference's seams would call directly. */
 int mg_conv2d_igemm(const mg_op* conv_desc, void* stream);   /* kind must be MG_OP_IGEMM */
 /* Host-only test hook (no device work): how MG_OP_FLASH_ATTN64's hand-placed kernel would share out B x heads sequences of Ntok

@@ -36,6 +36,8 @@ EXPORTS = [
     "mg_program_capture", "mg_program_profile", "mg_program_destroy", "mg_conv2d_igemm", "mg_conv3x3", "mg_conv3x3_gn_slots", "mg_flash4w_plan_test",
     "mg_sched_step", "mg_ensemble_normals", "mg_ens_align_cost_grad", "mg_bfgs_minimize", "mg_ens_align_minimize", "mg_event_create", "mg_event_record",
     "mg_event_elapsed_ms", "mg_event_destroy", "mg_clock_probe", "mg_debug_read_workspace",
+    "mg_model_load", "mg_model_destroy", "mg_model_info", "mg_model_device_bytes", "mg_model_validate", "mg_model_vae_encode",
+    "mg_model_denoise", "mg_model_vae_decode", "mg_ensemble_depth",
 ]
 
 
@@ -94,6 +96,19 @@ def load():
                                    ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_int]
     lib.mg_clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     lib.mg_debug_read_workspace.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+    lib.mg_model_load.restype = ctypes.c_void_p
+    lib.mg_model_load.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.mg_model_destroy.argtypes = [ctypes.c_void_p]
+    lib.mg_model_destroy.restype = None
+    lib.mg_model_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    lib.mg_model_device_bytes.argtypes = [ctypes.c_void_p]
+    lib.mg_model_device_bytes.restype = ctypes.c_longlong
+    lib.mg_model_validate.argtypes = [ctypes.c_void_p]
+    lib.mg_model_vae_encode.argtypes = [ctypes.c_void_p] * 4
+    lib.mg_model_denoise.argtypes = [ctypes.c_void_p] * 5
+    lib.mg_model_vae_decode.argtypes = [ctypes.c_void_p] * 4
+    lib.mg_ensemble_depth.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                      ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.mg_event_create.restype = ctypes.c_void_p
     lib.mg_event_record.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.mg_event_elapsed_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]

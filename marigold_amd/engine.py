@@ -38,7 +38,7 @@ def _tune(name, default):
 USE_PATCH = _tune("MARIGOLD_PATCH_CONV", True)          # patch-resident conv3x3 kernel where eligible
 FUSE_GN = _tune("MARIGOLD_FUSE_GN", "auto")             # auto | all | none: GroupNorm apply inside the conv
 GN_BYPRODUCT = _tune("MARIGOLD_GN_BYPRODUCT", True)     # GroupNorm partial sums from the producing convolution's epilogue
-VAE_FLASH_SMALL_MIN_BLOCKS = _tune("MARIGOLD_VAE_FLASH_MIN_BLOCKS", 0)   # flash512 only for launches of at least this many query blocks
+VAE_FLASH_SMALL_MIN_BLOCKS = _tune("MARIGOLD_VAE_FLASH_MIN_BLOCKS", 100)   # flash512 for launches of at least this many 128-query blocks
 IGEMM73_CONV = _tune("MARIGOLD_IGEMM73_CONV", True)     # plain N = 320 k convolutions on the hand-placed 192 x 320 GEMM tile
 IGEMM72_VAE = _tune("MARIGOLD_IGEMM72_VAE", True)       # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
 GN_SLAB = _tune("MARIGOLD_GN_SLAB", True)               # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
@@ -711,10 +711,10 @@ class Builder:
         o = self.new(x.B, x.H, x.W, C)
         if C == 512 and B * ((T + 127) // 128) >= VAE_FLASH_SMALL_MIN_BLOCKS:
             # round 4: flash form - the T x T scores (340 MB of fp32 per image at 96 x 96 latent pixels) never leave the
-            # registers.  One workgroup per 128 queries and CU: a launch that does not fill the chip (the encoder's single
-            # image: 72 workgroups) takes 0.93 ms against 0.50 ms for the three-stage form below (profiles/r4_flash512.log;
-            # two-wave workgroups of 64 queries were tried for such launches: 1.12 ms) - it runs here all the same, so that no
-            # score matrix is materialised anywhere on the product path
+            # registers.  One workgroup per 128 queries and CU: a launch that does not fill the chip (a single image: 72
+            # workgroups - the encoder always, the decoder of a one-member shard) takes 0.93 ms against 0.50 ms for the
+            # three-stage form below (profiles/r4_flash512.log; two-wave workgroups of 64 queries: 1.12 ms), so launches of
+            # fewer than 100 query blocks take the three-stage form (round 5: -0.5 ms per map at every ensemble size)
             self.add(O.flash_attn512(qk, qk.data_ptr() + C * 2, vt, o.t, B=B, Ntok=T, ldq=2 * C, ldo=C, ldvt=ldp,
                                      sq=T * 2 * C, sk=T * 2 * C, svt=C * ldp, so=T * C, scale=1.0 / math.sqrt(C)), f"{name}.flash")
             self.free(qk)

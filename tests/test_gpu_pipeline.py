@@ -599,6 +599,85 @@ def test_bench_nccl_path_single_rank(tmp_path):
     print(f"[parity] bench.py under torchrun, nccl world 1: {line['ms_per_step']} ms/step, gather {line['stages']['gather']}")
 
 
+def test_model_image_runs_the_pipeline_from_c(tiny, tmp_path):
+    """The module-level C ABI: a model image exported from the engine pipeline, loaded by
+    ``mg_model_load`` and driven through ``mg_model_vae_encode`` / ``mg_model_denoise`` / ``mg_model_vae_decode`` /
+    ``mg_ensemble_depth`` with raw device pointers gives the Python pipeline's tensors bit for bit."""
+    import ctypes
+    import marigold_amd as M
+    from marigold_amd import _lib as L, ensemble as ens, image, ops as O, schedulers as S
+    img, lat0, rgb = _inputs()
+    pipe = _engine_pipe(tiny, "depth", S.DDIMScheduler())
+    pipe.default_denoising_steps = 2
+    path = str(tmp_path / "tiny.mgimg")
+    info = image.export_model_image(pipe, path, ensemble_size=3, height=64, width=128)
+    print(f"[parity] model image: {info['file_bytes'] / 1e6:.1f} MB, ops {info['ops']}")
+    m = image.ModelImage(path, device=0)
+    rl_ref = pipe.vae.encode_rgb_latent(rgb.cuda())
+    rl = m.encode(rgb.cuda())
+    assert torch.equal(rl, rl_ref)
+    prog = pipe.unet.denoise_program(3, 8, 16, pipe.scheduler, 2, rgb_broadcast=True)
+    prog.rgb_latent.copy_(rl_ref)
+    prog.x.copy_(lat0.cuda())
+    prog.run()
+    x = m.denoise(rl, lat0.cuda())
+    assert torch.equal(x, prog.x)
+    pred_ref = pipe.decode_depth(prog.x)
+    pred = m.decode(x)
+    assert torch.equal(pred, pred_ref)
+    # ... twice: the image's zeroed state (tickets, V^T pads) is left as it was found
+    assert torch.equal(m.decode(m.denoise(m.encode(rgb.cuda()), lat0.cuda())), pred_ref)
+    # ensemble_depth as one C call == the Python form, with and without the max_res down-sampling of the alignment
+    lib = L.load()
+    for max_res, unc_on, red in ((1024, True, 0), (48, True, 0), (1024, False, 1)):
+        d_ref, u_ref, info_ref = ens.ensemble_depth(pred_ref, True, True, output_uncertainty=unc_on, reduction="median" if red == 0 else "mean",
+                                                    max_res=max_res, return_info=True)
+        d = torch.empty(64 * 128, device="cuda")
+        u = torch.empty(64 * 128, device="cuda") if unc_on else None
+        inf = (ctypes.c_double * 4)()
+        L.check(lib.mg_ensemble_depth(pred_ref.contiguous().data_ptr(), 3, 64, 128, 1, 1, red, 0.02, 50, 1e-6, max_res, d.data_ptr(),
+                                      None if u is None else u.data_ptr(), ctypes.addressof(inf), O.current_stream_handle()), "mg_ensemble_depth")
+        assert torch.equal(d.reshape(1, 1, 64, 128), d_ref), (max_res, red)
+        if unc_on:
+            assert torch.equal(u.reshape(1, 1, 64, 128), u_ref)
+        assert int(inf[1]) == info_ref["n_eval"] and int(inf[2]) == info_ref["n_iter"] and abs(inf[0] - info_ref["cost"]) <= 1e-12 * abs(info_ref["cost"])
+    rc = lib.mg_ensemble_depth(pred_ref.data_ptr(), 3, 64, 128, 0, 1, 0, 0.02, 50, 1e-6, 1024, d.data_ptr(), None, None, O.current_stream_handle())
+    assert rc != 0 and b"Pure shift-invariant ensembling is not supported." in lib.mg_last_error()
+    m.close()
+
+
+def test_model_image_from_a_c_host(tiny, tmp_path):
+    """examples/host_depth.cpp - a host program without Python (hipcc + libmarigold_hip.so only) - loads a model image and writes
+    the ensembled depth map of E = 2 members: identical to the Python pipeline's map for the same latents."""
+    import shutil
+    import subprocess
+    from marigold_amd import image, schedulers as S
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    img, lat0, rgb = _inputs()
+    pipe = _engine_pipe(tiny, "depth", S.DDIMScheduler())
+    pipe.default_denoising_steps = 2
+    path = str(tmp_path / "tiny.mgimg")
+    image.export_model_image(pipe, path, ensemble_size=2, height=64, width=128)
+    exe = str(tmp_path / "host_depth")
+    r = subprocess.run([hipcc, "-O2", os.path.join(root, "examples", "host_depth.cpp"), "-I" + os.path.join(root, "include"),
+                        "-L" + os.path.join(root, "marigold_amd"), "-lmarigold_hip", "-Wl,-rpath," + os.path.join(root, "marigold_amd"), "-o", exe],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rgb.numpy().astype(np.float32).tofile(str(tmp_path / "rgb.f32"))
+    lat0[:2].numpy().astype(np.float32).tofile(str(tmp_path / "noise.f32"))
+    r = subprocess.run([exe, path, str(tmp_path / "rgb.f32"), str(tmp_path / "noise.f32"), str(tmp_path / "depth.f32")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    print("[parity] C host: " + r.stdout.strip().replace("\n", " | "))
+    got = np.fromfile(str(tmp_path / "depth.f32"), dtype=np.float32).reshape(64, 128)
+    ref = pipe(img, denoising_steps=2, ensemble_size=2, processing_res=0, match_input_res=False, color_map=None, show_progress_bar=False,
+               init_latents=lat0[:2]).depth_np
+    np.testing.assert_array_equal(got, ref)
+
+
 def test_iid_pipeline_vs_oracle(tiny, tmp_path):
     """Third model family (marigold_iid_pipeline.py): 2 modalities -> UNet 12 -> 8 latent channels,
     per-modality VAE decode, ensemble_iid; engine vs the CPU oracle on the tiny architecture."""

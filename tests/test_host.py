@@ -631,6 +631,51 @@ def test_encode_empty_text_with_a_real_text_encoder(tmp_path):
         pipe.unet.set_context(torch.zeros(1, 77, 64))
 
 
+def test_model_image_round_trip_without_gpu(tmp_path):
+    """SURVEY section 8(b)'s module-level C entry points: ``export_model_image`` compiles the three native programs of a fixed
+    shape (VAE encode, the whole T-step denoising loop, VAE decode) + their kernel-ready weights + a memory plan into one file;
+    ``mg_model_load(path, device=-1)`` parses it, lays the buffers out and patches every pointer, and ``mg_model_validate`` runs
+    every op's contract check - all without a GPU (tests/test_gpu_pipeline.py runs the same image on the device)."""
+    import struct
+    import marigold_amd as M
+    from marigold_amd import image, _lib as L
+    from marigold_amd.arch import TINY_UNET, TINY_VAE
+    from marigold_amd.schedulers import LCMScheduler
+    pipe = M.build_synthetic_pipeline("depth", TINY_UNET, TINY_VAE, default_processing_resolution=0, default_denoising_steps=2)
+    path = str(tmp_path / "tiny.mgimg")
+    info = image.export_model_image(pipe, path, ensemble_size=3, height=64, width=128)
+    assert info["latent_hw"] == (8, 16) and info["ops"]["denoise"] > 100 and info["step_noises"] == 0
+    m = image.ModelImage(path, device=-1)
+    assert (m.B, m.H, m.W, m.h, m.w, m.steps, m.pred_channels, m.Hout, m.Wout) == (3, 64, 128, 8, 16, 2, 1, 64, 128)
+    assert L.load().mg_model_device_bytes(m.handle) >= info["data_bytes"] + info["zero_bytes"] + info["scratch_bytes"]
+    m.validate()
+    with pytest.raises(L.MarigoldHipError, match="host-only"):   # a host-only model cannot run
+        L.check(L.load().mg_model_vae_encode(m.handle, 1, 1, None), "mg_model_vae_encode")
+    m.close()
+    # the LCM scheduler draws noise in its non-final steps: the image carries one slot per draw
+    lcm = M.build_synthetic_pipeline("depth", TINY_UNET, TINY_VAE, scheduler=LCMScheduler(), default_processing_resolution=0)
+    info2 = image.export_model_image(lcm, str(tmp_path / "lcm.mgimg"), ensemble_size=1, height=64, width=64, denoising_steps=4)
+    assert info2["step_noises"] == 3
+    m2 = image.ModelImage(str(tmp_path / "lcm.mgimg"), device=-1)
+    assert m2.n_noise == 3
+    m2.validate()
+    m2.close()
+    # a file that is not an image, a truncated one, an image of another ABI: refused with a message
+    bad = str(tmp_path / "bad.mgimg")
+    open(bad, "wb").write(b"not an image" * 20)
+    with pytest.raises(L.MarigoldHipError, match="not a model image"):
+        image.ModelImage(bad, device=-1)
+    raw = open(path, "rb").read()
+    open(bad, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(L.MarigoldHipError, match="short read"):
+        image.ModelImage(bad, device=-1)
+    hdr = bytearray(raw[:88])
+    struct.pack_into("<I", hdr, 12, 3)   # the ABI field
+    open(bad, "wb").write(bytes(hdr) + raw[88:])
+    with pytest.raises(L.MarigoldHipError, match="ABI 3"):
+        image.ModelImage(bad, device=-1)
+
+
 def test_noise_draws_follow_the_loaded_dtype(tmp_path):
     """A4 (marigold_depth_pipeline.py:430-435): the reference draws the initial latents (and the LCM per-step noise) with
     ``dtype=self.dtype`` - fp32 for the default load, 16-bit draws for ``from_pretrained(torch_dtype=torch.float16 |
