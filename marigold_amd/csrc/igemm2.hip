@@ -87,14 +87,15 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int LDS = NSTAGE * (BM + BN) * BK * 2 + BM * 8;   // ring + (mean, rstd) of the tile's rows (folded LayerNorm)
   static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
-  static bool attr_set = false;
+  static bool attr_set[2] = {false, false};   // [1]: the instrumented instantiation (tuning only)
+  const int ai = a.stamps ? 1 : 0;
   void (*kern)(const Igemm2Args);
-  if constexpr (BIG >= 0) kern = (void (*)(const Igemm2Args))mg_igemm2_big_kernel(BIG);
+  if constexpr (BIG >= 0) kern = (void (*)(const Igemm2Args))mg_igemm2_big_kernel(a.stamps ? BIG + 2 : BIG);
   else if constexpr (PPOPT >= 0) kern = igemm2_pingpong_kernel<TRANS, PPOPT>;
   else kern = igemm2_kernel<BM, BN, WGM, WGN, NSTAGE, TRANS, SPLIT, PF, ABL, BK>;
-  if (!attr_set && !g_dry_run) {
+  if (!attr_set[ai] && !g_dry_run) {
     MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
+    attr_set[ai] = true;
   }
   Igemm2Args b = a;
   b.cpt = a.Cin / BK;
@@ -235,7 +236,7 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.w2 = nullptr;
   {   // tuning only: phase stamps of every workgroup into the (otherwise idle) split-K workspace - tools/igemm_phases.py
     static const int st = mg_tuning_int("MARIGOLD_IGEMM_STAMPS", 0);
-    a.stamps = (st && op->i[31] <= 1 && variant) ? (unsigned long long*)g_splitk_ws : nullptr;
+    a.stamps = (st && op->i[31] <= 1 && (variant == 72 || variant == 73)) ? (unsigned long long*)g_splitk_ws : nullptr;
   }
   a.c2 = 0;
   a.inv_c2 = 0.0;

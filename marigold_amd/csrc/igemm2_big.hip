@@ -19,10 +19,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   igemm2_body<192, 320, 2, 2, 2, false, false, 3, 0, 64>(a);
 }
 
+// the same two kernels with their phase stamps compiled in (tuning only: MARIGOLD_IGEMM_STAMPS=1, tools/igemm_phases.py)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void igemm2_k4w_stamped_kernel(const Igemm2Args a) {
+  igemm2_body<256, 256, 2, 2, 2, false, false, 3, 0, 64, 0, true>(a);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void igemm2_k4wb_stamped_kernel(const Igemm2Args a) {
+  igemm2_body<192, 320, 2, 2, 2, false, false, 3, 0, 64, 0, true>(a);
+}
+
 }  // namespace
 
 // which: 2 = the hand-placed 256 x 256 tile, 3 = its 192 x 320 sibling.  The argument struct has the same layout in every
 // translation unit (igemm2_body.h); the pointer is launched by igemm2.hip::launch2.
 void* mg_igemm2_big_kernel(int which) {
+  if (which >= 4) return which == 5 ? (void*)igemm2_k4wb_stamped_kernel : (void*)igemm2_k4w_stamped_kernel;   // + 2: instrumented
   return which == 3 ? (void*)igemm2_k4wb_kernel : (void*)igemm2_k4w_kernel;
 }

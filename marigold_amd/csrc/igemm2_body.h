@@ -53,7 +53,7 @@ struct Igemm2Args {
   int tperm;         // transposed section: tokens stored in ACCUMULATOR order inside every group of 16 ([0-3, 8-11, 4-7, 12-15] -
                      // what flash_attn64's generation 3 consumes without a lane exchange; no regroup here either)
   const bf16_t* w2;  // MG_EPI_XATTN2: second-stage weights [c2][64]
-  unsigned long long* stamps;   // tuning only (MARIGOLD_IGEMM_STAMPS=1, tools/igemm_phases.py): per workgroup 8 x s_memrealtime (100 MHz)
+  unsigned long long* stamps;   // tuning only (MARIGOLD_IGEMM_STAMPS=1, tools/igemm_phases.py; tile variants 72 / 73): per workgroup 8 x s_memrealtime (100 MHz)
                                 // at kernel entry / operands addressed / first tile landed / K loop done / outputs stored / exit
   int c2;
   double inv_c2;
@@ -90,7 +90,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // LDS-DMA piece of the half tile is issued in the middle of the MFMA segment instead of the load segment
 // (a piece costs its wave 60-185 issue cycles - two of them make the load segment longer than the partner's
 // eight MFMAs).
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, int LOOP, int ABL, int BK, int PPOPT = 0>
+// STAMP (tuning only): the instrumented instantiations of the hand-placed tiles (igemm2_big.hip) write their phase stamps.
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool TRANS, bool SPLIT, int LOOP, int ABL, int BK, int PPOPT = 0, bool STAMP = false>
 __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
   constexpr bool PF = LOOP == 1, PP = LOOP == 2, K4 = LOOP == 3;
   static_assert(!K4 || (((BM == 256 && BN == 256) || (BM == 192 && BN == 320)) && WGM == 2 && WGN == 2 && NSTAGE == 2 && BK == 64 &&
@@ -124,7 +125,10 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   auto stamp = [&](int k) {
-    if (a.stamps && tid == 0) a.stamps[(long long)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (STAMP) {
+      if (a.stamps && tid == 0) a.stamps[(long long)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
+    }
+    (void)k;
   };
   stamp(0);
   const int tiles = a.tiles_m * a.tiles_n;

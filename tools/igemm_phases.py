@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Where does a short-K MG_OP_IGEMM launch spend its time?  (tuning tool; run on the MI355X with MARIGOLD_TUNING=1
 MARIGOLD_IGEMM_STAMPS=1)  Every workgroup of a forced-tile launch stamps the 100 MHz s_memrealtime at: kernel entry, operands
-addressed, first K tile landed, K loop done, outputs stored, exit (csrc/igemm2_body.h::stamp).  Prints, per case, the launch's
+addressed, first K tile landed, K loop done, outputs stored, exit (csrc/igemm2_body.h::stamp; the instrumented instantiations of the
+hand-placed tiles, variants 72 / 73 - the compiled tiles were stamped the same way for profiles/r5_igemm_phase_stamps.log).  Prints, per case, the launch's
 wall time by HIP events and the distribution over workgroups of each phase and of the start / end times relative to the first
 workgroup's entry."""
 import ctypes
@@ -69,13 +70,8 @@ def case(name, M, N, K, variant, taps=1, res=True, ln_out=False, HW=None, B=1, s
 if __name__ == "__main__":
     case("lvl1 to_out (+res, +row stats)", 23040, 640, 640, 73, ln_out=True)
     case("lvl1 proj_out (+res)", 23040, 640, 640, 73)
-    case("lvl1 proj_out (+res) 128x128", 23040, 640, 640, 32)
-    for v in (23, 35):
-        case(f"lvl1 proj_out (+res) v{v}", 23040, 640, 640, v)
     case("lvl0 ff.out (+res)", 92160, 320, 1280, 73)
-    case("lvl0 ff.out (+res) 128x320", 92160, 320, 1280, 46)
     case("lvl1 ff.out (+res)", 23040, 640, 2560, 73)
-    case("lvl2 proj_out (+res) 128x128", 5760, 1280, 1280, 32)
     case("lvl2 proj_out (+res) 192x320", 5760, 1280, 1280, 73)
-    case("lvl2 ff.out (+res)", 5760, 1280, 5120, 36)
+    case("lvl2 ff.out (+res) 256x256", 5760, 1280, 5120, 72)
     case("lvl1 conv2 3x3 (+res)", 23040, 640, 5760, 73, taps=9, HW=48, B=10)
