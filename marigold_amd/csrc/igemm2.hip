@@ -382,6 +382,10 @@ int mg_igemm_auto_variant(long long M, int N, int K, int batch_z, int geglu) {
     static const int k4wb = mg_tuning_int("MARIGOLD_K4WB", 1);
     const long long tb = ((M + 191) / 192) * (N / 320) * batch_z;
     if (k4w && k4wb && !geglu && N % 320 == 0 && N % 256 != 0 && K >= 640 && tb >= 200) return 73;
+    // (round 5) the long-K convolutions of the N = 320 k levels keep the tile below a chip's worth of workgroups too (split-K fills
+    // the rest: launch2): 72 tiles x 3 splits 64.8 vs 88.5 us for the 256 x 128 tile (640 -> 640 @ 48 x 48, three members),
+    // 120 tiles 152 vs 171 us (1280 -> 640, five members) - profiles/r5_sweep_program_E3.tsv, _E5.tsv
+    if (k4w && k4wb && !geglu && batch_z == 1 && N % 320 == 0 && N % 256 != 0 && K >= 2560 && tb >= 64) return 73;
   }
   const long long tm256 = (M + 255) / 256;
   // short K (GEGLU projections, K = C linears): 256x128 with 32-deep K tiles - half the LDS per stage,

@@ -40,6 +40,7 @@ FUSE_GN = _tune("MARIGOLD_FUSE_GN", "auto")             # auto | all | none: Gro
 GN_BYPRODUCT = _tune("MARIGOLD_GN_BYPRODUCT", True)     # GroupNorm partial sums from the producing convolution's epilogue
 VAE_FLASH_SMALL_MIN_BLOCKS = _tune("MARIGOLD_VAE_FLASH_MIN_BLOCKS", 100)   # flash512 for launches of at least this many 128-query blocks
 IGEMM73_CONV = _tune("MARIGOLD_IGEMM73_CONV", True)     # plain N = 320 k convolutions on the hand-placed 192 x 320 GEMM tile
+IGEMM73_CONV_MIN_TILES = _tune("MARIGOLD_IGEMM73_CONV_MIN_TILES", 120)
 IGEMM72_VAE = _tune("MARIGOLD_IGEMM72_VAE", True)       # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
 GN_SLAB = _tune("MARIGOLD_GN_SLAB", True)               # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 GN_SLAB_MIN_WG = _tune("MARIGOLD_GN_SLAB_MIN_WG", 64)   # ... from this many (image, channel window) workgroups,
@@ -473,8 +474,10 @@ class Builder:
                     -(-x.M // 256) * (cout // 256) >= 720)
         # ... and the plain N = 320 k convolutions with a chip's worth of 192 x 320 tiles (the 640-channel level at 48 x 48) on
         # variant 73: 640 -> 640 1 193 vs 1 147-1 182 for the four-wave patch kernel, 1280 -> 640 1 303 vs 1 267-1 277
+        # (round 5: from 120 tiles - six members at 48 x 48; with eight the four-wave patch kernel ran these at 760-790 TFLOP/s
+        # where the GEMM tile does 1 170-1 300: the >= 200 of round 4 had been set at E = 10 only)
         big_gemm = big_gemm or (IGEMM73_CONV and up is None and stride == 1 and pad == 1 and cout % 320 == 0 and cout % 256 != 0 and
-                                x.C >= 320 and -(-x.M // 192) * (cout // 320) >= 200)
+                                x.C >= 320 and -(-x.M // 192) * (cout // 320) >= IGEMM73_CONV_MIN_TILES)
         if USE_PATCH and not big_gemm and stride == 1 and pad == 1 and self.patch_eligible(x.H, x.W, x.B, cout, up is not None):
             if up is None:
                 return self.conv3x3p([x], name, cout, rowvec=rowvec, residual=residual, out=out)

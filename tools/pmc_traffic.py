@@ -2,7 +2,7 @@
 """Turns the two rocprofv3 --pmc passes of bench.py (gpurun_out/pmc_fetch, gpurun_out/pmc_write; made by
 `scripts/gpu_round.sh pmc`) into profiles/<round>_pmc_hbm_traffic.{csv,json}: HBM bytes per launch per kernel,
 FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads - MI355X_MICROARCH.md, HBM).
-Usage: python tools/pmc_traffic.py [round tag, default r2]"""
+Usage: python tools/pmc_traffic.py [round tag, default r5]"""
 import collections
 import csv
 import json
@@ -27,10 +27,16 @@ def load(path, name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
     base = os.path.join(ROOT, "gpurun_out")
-    f = load(os.path.join(base, "pmc_fetch", "r2_counter_collection.csv"), "FETCH_SIZE")
-    w = load(os.path.join(base, "pmc_write", "r2_counter_collection.csv"), "WRITE_SIZE")
+    import glob
+
+    def one(d):
+        hits = glob.glob(os.path.join(base, d, "**", "*counter_collection.csv"), recursive=True)
+        assert hits, f"no counter_collection.csv under gpurun_out/{d}"
+        return max(hits, key=os.path.getmtime)   # (gpurun_out/ keeps the files of earlier rounds)
+    f = load(one("pmc_fetch"), "FETCH_SIZE")
+    w = load(one("pmc_write"), "WRITE_SIZE")
     classes = {"igemm_mfma": "igemm2_", "rowgemm_mfma": "rowgemm_", "conv3x3_patch": "conv_patch", "flash_attn64": "flash_attn64",
                "groupnorm": "gn_"}
     out = {}
