@@ -631,6 +631,43 @@ def test_encode_empty_text_with_a_real_text_encoder(tmp_path):
         pipe.unet.set_context(torch.zeros(1, 77, 64))
 
 
+def test_tuning_table_is_well_formed_and_applied():
+    """marigold_amd/tuning/gfx950.json (the measured tile / split-K choices of MG_OP_IGEMM): every entry names a tile the library
+    can dispatch and a split count it accepts, keys parse as the 13 integers ``tuning.key_of`` writes, every entry was worth at
+    least the 6 % its sweep demanded; ``engine.Builder.add`` applies an entry to a matching op and leaves a caller's own choice
+    alone; a full-size program built with the table validates."""
+    import re
+    from marigold_amd import _lib as L, ops as O, tuning
+    db = tuning.load()
+    assert len(db) >= 100
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "marigold_amd", "csrc", "igemm2.hip")).read()
+    tiles = {int(v) for v in re.findall(r"\n    case (\d+):", src)}
+    assert {23, 32, 35, 36, 46, 62, 72, 73} <= tiles
+    for key, (variant, splits, t_auto, t_best, where) in db.items():
+        parts = key.split(",")
+        assert len(parts) == 13 and all(re.fullmatch(r"-?\d+", x) for x in parts), key
+        assert variant in tiles and 1 <= splits <= 8, (key, variant, splits)
+        assert t_best <= 0.94 * t_auto + 0.11, (key, t_auto, t_best)   # (both are stored rounded to 0.1 us)
+        if int(parts[5]) != L.EPI_BF16 or int(parts[9]) or int(parts[10]) or int(parts[6]) or int(parts[7]) > 1:
+            assert splits == 1, f"{key}: split-K only for the plain bf16 epilogue"   # row statistics / folded LayerNorm / GEGLU / V^T
+    # an op matching a table entry gets the entry; variant / splits given by the caller are left alone
+    def usable(k):
+        p_ = k.split(",")
+        return (p_[3], p_[4], p_[5], p_[6], p_[7], p_[9], p_[10], p_[11]) == ("9", "1", "0", "0", "1", "0", "0", "0") and int(int(p_[0]) ** 0.5) ** 2 == int(p_[0])
+    key, (variant, splits, *_rest) = next((k, v) for k, v in db.items() if usable(k))
+    parts = key.split(",")
+    M_, N_, K_ = (int(x) for x in parts[:3])
+    HW = int(M_ ** 0.5)
+    a = torch.zeros(1)
+    kw = dict(B=1, H=HW, W=HW, Cin=K_ // 9, Ho=HW, Wo=HW, N=N_, taps=9, stride=1, pad=1, bias=a, residual=a if parts[8] == "1" else None,
+              rowvec=a if parts[12] == "1" else None)
+    op = O.igemm(a, a, a, **kw)
+    assert tuning.key_of(op) == key
+    assert (tuning.apply(op).i[19], op.i[31]) == (variant, splits)
+    op2 = O.igemm(a, a, a, variant=23, **kw)
+    assert (tuning.apply(op2).i[19], op2.i[31]) == (23, 0)
+
+
 def test_model_image_round_trip_without_gpu(tmp_path):
     """SURVEY section 8(b)'s module-level C entry points: ``export_model_image`` compiles the three native programs of a fixed
     shape (VAE encode, the whole T-step denoising loop, VAE decode) + their kernel-ready weights + a memory plan into one file;
