@@ -27,25 +27,7 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution): one v_rcp, one
-// bare v_exp and a 5-term Horner chain instead of libm's branchy erff (~3x fewer VALU issues in the
-// GEGLU epilogue, which produces 8C activations per token).
-__device__ __forceinline__ float erf_as_f(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
-  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-  p = __builtin_fmaf(p, t, 1.421413741f);
-  p = __builtin_fmaf(p, t, -0.284496736f);
-  p = __builtin_fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-  return copysignf(__builtin_fmaf(-p, e, 1.0f), x);
-}
-__device__ __forceinline__ float gelu_erf_f(float x) {  // exact-erf GELU (diffusers GEGLU: F.gelu default)
-  return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752f));
-}
-
-// The same GELU with the Gaussian CDF as an odd polynomial, Phi(x) = 1/2 + x P(x^2) on |x| <= 4 (degree 6 in x^2,
+// GELU (diffusers GEGLU: F.gelu, exact-erf form) with the Gaussian CDF as an odd polynomial, Phi(x) = 1/2 + x P(x^2) on |x| <= 4 (degree 6 in x^2,
 // |error| <= 1.1e-4 on Phi, <= 4e-4 on x Phi(x) inside the interval - an eighth of a bf16 rounding step of the result -
 // and <= 1e-4 relative beyond it, where x is clamped): 11 full-rate VALU operations, no transcendental.  The GEGLU
 // epilogue of the K = 320 projection issues more VALU than its K loop issues MFMAs; this is its cheapest form.

@@ -254,7 +254,6 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   if (a.epi == MG_EPI_SOFTMAX2)
     MG_REQUIRE(trans_from < 0 && batch_z == 1 && a.sm_cols > 0 && a.sm_cols % 2 == 0 && a.sm_cols <= a.N && !a.res,
                "igemm: the pair-softmax epilogue takes an even number of score columns <= N, no residual / transposed section");
-  a.gelu_erf = 0;
   if (a.ln_out && a.epi == MG_EPI_XATTN2) {
     MG_REQUIRE((uintptr_t)a.ln_out % 8 == 0, "igemm: misaligned (mean, rstd) table");
     a.splits = -1;

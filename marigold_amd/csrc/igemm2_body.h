@@ -44,7 +44,6 @@ struct Igemm2Args {
   float ln_eps;
   float sm_scale;  // MG_EPI_SOFTMAX2: softmax scale and the number of real score columns (2 x heads)
   int sm_cols;
-  int gelu_erf;   // A/B: 1 = GELU through the Abramowitz-Stegun erf (two transcendentals) instead of the polynomial CDF
   // Launch-time constants of the index arithmetic (common.h: fdiv) and the straight-row switch: `lin` = Linear layer /
   // conv1x1 (taps 1, stride 1, no padding / up-sampling), whose output row m reads input row m - no (image, y, x) split.
   mg_fastdiv fd_per_z, fd_tiles, fd_tiles_n, fd_rpi, fd_wo, fd_cpt;
@@ -1003,8 +1002,8 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
                 const float off = kLN ? __builtin_fmaf(l_mr[mi], gq[q4][j], bq[q4][j]) : bq[q4][j];
                 o4[q4] = __builtin_fmaf(acc[ni][mi][4 * q4 + j], l_sc[mi], off);
               }
-              const float o0 = o4[0] * (a.gelu_erf ? gelu_erf_f(o4[2]) : gelu_poly_f(o4[2]));  // channel 16i + 4h + j
-              const float o1 = o4[1] * (a.gelu_erf ? gelu_erf_f(o4[3]) : gelu_poly_f(o4[3]));  // channel 16i + 8 + 4h + j
+              const float o0 = o4[0] * gelu_poly_f(o4[2]);  // channel 16i + 4h + j
+              const float o1 = o4[1] * gelu_poly_f(o4[3]);  // channel 16i + 8 + 4h + j
               half_swap(o0, o1, r[j], r[4 + j]);
             }
             uint4 pk;
@@ -1190,8 +1189,8 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
             const float u1 = __builtin_fmaf(acc[ni][mi][4 + j], l_sc[mi], __builtin_fmaf(l_mr[mi], gq[1][j], bq[1][j]));
             const float t0 = __builtin_fmaf(acc[ni][mi][8 + j], l_sc[mi], __builtin_fmaf(l_mr[mi], gq[2][j], bq[2][j]));
             const float t1 = __builtin_fmaf(acc[ni][mi][12 + j], l_sc[mi], __builtin_fmaf(l_mr[mi], gq[3][j], bq[3][j]));
-            const float o0 = u0 * (a.gelu_erf ? gelu_erf_f(t0) : gelu_poly_f(t0));  // channel 16i + 4h + j
-            const float o1 = u1 * (a.gelu_erf ? gelu_erf_f(t1) : gelu_poly_f(t1));  // channel 16i + 8 + 4h + j
+            const float o0 = u0 * gelu_poly_f(t0);  // channel 16i + 4h + j
+            const float o1 = u1 * gelu_poly_f(t1);  // channel 16i + 8 + 4h + j
             half_swap(o0, o1, r[j], r[4 + j]);
           }
           if (m < a.M && nok) {

@@ -25,7 +25,7 @@
 // that a lane's accumulator registers 0-7 / 8-15 are channels 8h .. 8h+7 / 16+8h .. 16+8h+7 - 16-byte stores with no
 // lane exchange.  In the V^T section of the QKV projection the operand roles are swapped (x fragment as MFMA A, weights
 // as B - the register images are the same) and the accumulator then holds, per channel, tokens {4h..4h+3, 8+4h..} - the
-// key order MG_OP_FLASH_ATTN64 i[7] consumes (engine.FLASH_VT_PERM), again 16-byte stores.
+// key order MG_OP_FLASH_ATTN64 i[7] consumes, again 16-byte stores.
 //
 // Synchronisation: one s_barrier per stage.  A wave waits for its OWN LDS-DMA pieces of stage j with a counted vmcnt
 // before barrier j; vmcnt retires in order on gfx9 and counts stores, so the wait leaves exactly the younger operations in
@@ -51,14 +51,12 @@ struct RgArgs {
   int M, N, ldx, ldo, ldr, ldt, T, trans_stage;
   float ln_eps;
   double inv_n;
-  int gelu_erf;
   int prio;
   int spl;              // stages per workgroup (N / 64 unless the columns are split over gridDim.y)
   unsigned long long* dbg;   // tuning only: per-wave phase cycles [wave-tiles][4] (wait+barrier, issue, MFMA, epilogue) | NULL
 };
 
-enum { RG_BF16 = 0, RG_GEGLU = 1, RG_QKV = 2, RG_XATTN = 3,
-       RG_GEGLU_ERF = 5 /* template value only: GEGLU through the erf form (MARIGOLD_GELU_ERF=1 A/B runs) */ };
+enum { RG_BF16 = 0, RG_GEGLU = 1, RG_QKV = 2, RG_XATTN = 3 };
 
 // The stage trailer (per-channel constants) is read with hand-placed LDS instructions: hipcc's waitcnt pass makes every LDS
 // load it can see wait for ALL outstanding LDS-DMA (vmcnt(0)) - in the middle of the stage that would drain the weight
@@ -116,7 +114,7 @@ void rowgemm_kernel(const RgArgs a) {
   constexpr int KS = K / 16, TS = K <= 320 ? 2 : 1, SPS = 2 / TS;   // tiles per slot, slots per stage
   constexpr int PIECES = TS * KS + 1, STAGE = PIECES * 1024, NSTAGE = 3, TRL = TS * KS * 1024;
   constexpr int NWMIN = PIECES / NW, NWREM = PIECES - NWMIN * NW;   // LDS-DMA pieces per wave and stage: NWMIN (+1 for waves < NWREM)
-  constexpr bool GEGLU = EPI == RG_GEGLU || EPI == RG_GEGLU_ERF;
+  constexpr bool GEGLU = EPI == RG_GEGLU;
   constexpr int S = GEGLU ? 2 : 4;                         // stores per stage epilogue
   constexpr int XW = NWMIN + S + (RES ? 4 : 0);            // operations younger than stage j's pieces that may stay in flight
   static_assert((K == 320 || K == 640) && NWMIN >= 1, "geometry");
@@ -295,7 +293,7 @@ void rowgemm_kernel(const RgArgs a) {
           for (int i = 0; i < 8; ++i) {
             const float av = t == 0 ? acc0[8 * q + i] : acc1[8 * q + i];
             const float v = __builtin_fmaf(av, l_sc, LN ? __builtin_fmaf(l_mr, gg[i], cc[i]) : cc[i]);
-            if (t == 1) o[i] = EPI == RG_GEGLU_ERF ? gelu_erf_f(v) : gelu_poly_f(v);
+            if (t == 1) o[i] = gelu_poly_f(v);
             else o[i] = v * o[i];
           }
         }
@@ -712,7 +710,6 @@ int rg_dispatch(const RgArgs& a, int epi, hipStream_t s) {
   const bool ln = a.ln_in != nullptr, gn = a.gn_ss != nullptr, res = a.res != nullptr, lno = a.ln_out != nullptr;
   if (epi == RG_GEGLU) {
     MG_REQUIRE(!gn && !res && !lno, "rowgemm: the GEGLU form takes no GroupNorm input / residual / row statistics");
-    if (a.gelu_erf) return ln ? rg_launch<K, NW, RG_GEGLU_ERF, true, false, false, false>(a, s) : rg_launch<K, NW, RG_GEGLU_ERF, false, false, false, false>(a, s);
     return ln ? rg_launch<K, NW, RG_GEGLU, true, false, false, false>(a, s) : rg_launch<K, NW, RG_GEGLU, false, false, false, false>(a, s);
   }
   if (epi == RG_QKV) {
@@ -756,7 +753,6 @@ int mg_launch_rowgemm(const mg_op* op, hipStream_t s) {
   a.dbg = (unsigned long long*)op->p[8];
   a.inv_n = 1.0 / (double)(a.N > 0 ? a.N : 1);
   a.trans_stage = epi == RG_QKV ? trans_from / 64 : (1 << 30);
-  a.gelu_erf = 0;   // (the polynomial-CDF GELU; the exact-erf form is kept in common.h for the parity tests of the epilogue)
   a.prio = 1;
   {
     const int nsplit = op->i[12] > 1 ? op->i[12] : 1, nst = a.N >> 6;
