@@ -28,6 +28,17 @@ for l in sys.stdin:
 " >> gpurun_out/small_ensembles.log
 done
 echo "small ensembles done" >> gpurun_out/status.log
+# the other configurations of BASELINE.json on one GPU (C2: E = 1 is in the small-ensemble list above)
+: > gpurun_out/configs.log
+for cfg in "--scheduler lcm --denoise 4 --ensemble 1" "--kind normals --ensemble 4" "--ensemble 8" "--kind iid --ensemble 1 --denoise 4"; do
+  timeout 300 python bench.py $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-profile 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        j=json.loads(l); print('$cfg |', j['metric'], '|', j['value'], j['unit'], j['ms_per_step'], 'ms')
+" >> gpurun_out/configs.log
+done
+echo "configs done" >> gpurun_out/status.log
 rm -rf gpurun_out/prof
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r5 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $R/gpurun_out/rocprof_bench.log 2>&1)
 echo "rocprof rc=$?" >> gpurun_out/status.log
@@ -39,7 +50,7 @@ if [ "$1" == "pmc" ]; then
 fi
 find gpurun_out -name "*kernel_trace*" -size +30M -delete 2>/dev/null
 ls -la gpurun_out/prof/* gpurun_out/pmc_fetch/* gpurun_out/pmc_write/* 2>/dev/null | head -20 >> gpurun_out/status.log
-cat gpurun_out/status.log; cat gpurun_out/small_ensembles.log
+cat gpurun_out/status.log; cat gpurun_out/small_ensembles.log; cat gpurun_out/configs.log
 python -c "
 import json
 for n in ('bench_full','bench_nccl_world1'):
