@@ -59,6 +59,11 @@ enum mg_op_kind {
    *  i[26] 1 = the transposed section stores its tokens in accumulator order inside groups of 16 (MG_OP_FLASH_ATTN64 i[7])
    *  i[29], i[30] low / high 32 bits of the device address of the caller's row-block tickets for the p[8] statistics
    *  hand-off (65536 zeroed uint32, one buffer per program / stream; 0 = the library's global buffer: single stream only)
+   *  p[12] X0 bf16 [B][H][W][ldx0], p[13] X1 bf16 [B][H][W][ldx1] | NULL, i[32] = Cx, i[33] = Cx0, i[34] ldx0, i[35] ldx1: a 1x1 convolution
+   *  of a SECOND tensor folded in as extra K (diffusers ResnetBlock2D: conv2(h) + conv_shortcut(x) in ONE launch - no shortcut
+   *  launch, no residual round trip): K = taps * Cin + Cx, weight row n = [conv weights (taps * Cin) | shortcut weights (Cx)],
+   *  the extra K tiles read pixel (y, x) of X0 (channels [0, Cx0)) and X1 ([Cx0, Cx): the UNet's skip concat); taps = 9, stride 1,
+   *  pad 1 only; Cx, Cx0 multiples of 64; the bias is the two layers' sum
    *  i[31] split-K: 0 = automatic (few output tiles x long K: fp32 partials + a fixed-order reduce launch), n >= 1 = exactly n
    *  K ranges per tile (1 = none) - bf16 epilogue without row statistics / folded LayerNorm / batching only
    *  l[0..3] z-strides (elements) of A, Wt, out, residual      f[0] scale on the accumulator */
@@ -225,9 +230,9 @@ enum { MG_POST_NONE = 0, MG_POST_DEPTH = 1, MG_POST_NORMALS = 2, MG_POST_UNIT = 
 
 typedef struct mg_op {
   int32_t kind;
-  int32_t i[32];
+  int32_t i[40];
   float f[8];
-  void* p[12];
+  void* p[16];
   int64_t l[4];
 } mg_op;
 

@@ -42,8 +42,8 @@ EXPORTS = [
 
 
 class MgOp(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_int32), ("i", ctypes.c_int32 * 32), ("f", ctypes.c_float * 8),
-                ("p", ctypes.c_void_p * 12), ("l", ctypes.c_int64 * 4)]
+    _fields_ = [("kind", ctypes.c_int32), ("i", ctypes.c_int32 * 40), ("f", ctypes.c_float * 8),
+                ("p", ctypes.c_void_p * 16), ("l", ctypes.c_int64 * 4)]
 
 
 class MarigoldHipError(RuntimeError):

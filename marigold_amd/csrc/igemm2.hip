@@ -100,7 +100,9 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   Igemm2Args b = a;
   b.cpt = a.Cin / BK;
   b.c0t = a.A1 ? a.C0 / BK : b.cpt;
-  b.KT = a.taps * b.cpt;
+  b.xcpt = a.xcin / BK;                       // the folded 1x1 convolution's K tiles, behind the taps
+  b.xc0t = a.X1 ? a.xc0 / BK : b.xcpt;
+  b.KT = a.taps * b.cpt + b.xcpt;
   b.tiles_m = (a.M + BM - 1) / BM;
   b.tiles_n = (a.n_end - a.n_begin + BN - 1) / BN;
   // split-K for the deep UNet levels (a few hundred pixels x thousands of input channels): too few
@@ -165,14 +167,14 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
     case 62: return launch2<256, 256, 2, 4, 2, TRANS, false, false, 0, 64, 4>(a, batch_z, s);   // ping-pong schedule, 2nd DMA piece among the MFMAs
     case 72:   // 256 x 256 on four waves (one per SIMD, 128 x 128 wave tile), K loop placed by hand (LOOP == 3): offsets are 32-bit, relative to the operand bases
       if constexpr (!TRANS) {
-        MG_REQUIRE((long long)(a.M / a.rows_per_img) * a.H * a.W * max(a.lda, a.lda1) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30),
+        MG_REQUIRE((long long)(a.M / a.rows_per_img) * a.H * a.W * max(max(a.lda, a.lda1), max(a.ldx0, a.ldx1)) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30),
                    "igemm: tile variant 72 addresses its operands with 31-bit byte offsets");
         return launch2<256, 256, 2, 2, 2, false, false, false, 0, 64, -1, 2>(a, batch_z, s);
       } else MG_REQUIRE(false, "igemm: tile variant 72 has no transposed section");
       return 0;
     case 73:   // the hand-placed K loop on a 192 x 320 tile (wave tile 96 x 160): full width for the N = 320 k layers
       if constexpr (!TRANS) {
-        MG_REQUIRE((long long)(a.M / a.rows_per_img) * a.H * a.W * max(a.lda, a.lda1) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30),
+        MG_REQUIRE((long long)(a.M / a.rows_per_img) * a.H * a.W * max(max(a.lda, a.lda1), max(a.ldx0, a.ldx1)) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30),
                    "igemm: tile variant 73 addresses its operands with 31-bit byte offsets");
         return launch2<192, 320, 2, 2, 2, false, false, false, 0, 64, -1, 3>(a, batch_z, s);
       } else MG_REQUIRE(false, "igemm: tile variant 73 has no transposed section");
@@ -211,7 +213,7 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.c0t = 0;
   a.lda = op->i[17] > 0 ? op->i[17] : a.C0;
   a.ldt = op->i[18];
-  a.ldw = op->i[20] > 0 ? op->i[20] : a.taps * a.Cin;
+  a.ldw = op->i[20] > 0 ? op->i[20] : a.taps * a.Cin + (op->p[12] ? op->i[32] : 0);
   a.rv_stride = op->i[21] ? 0 : a.N;
   a.sA = op->l[0]; a.sW = op->l[1]; a.sO = op->l[2]; a.sR = op->l[3];
   a.scale = op->f[0] == 0.f ? 1.f : op->f[0];
@@ -234,6 +236,20 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   a.sm_cols = op->i[27];
   a.tperm = op->i[26];
   a.w2 = nullptr;
+  a.X0 = (const bf16_t*)op->p[12];
+  a.X1 = (const bf16_t*)op->p[13];
+  a.xcin = a.X0 ? op->i[32] : 0;
+  a.xc0 = a.X1 ? op->i[33] : a.xcin;
+  a.ldx0 = op->i[34] > 0 ? op->i[34] : a.xc0;
+  a.ldx1 = a.X1 ? (op->i[35] > 0 ? op->i[35] : a.xcin - a.xc0) : 0;
+  a.xcpt = a.xc0t = 0;
+  if (a.X0) {
+    MG_REQUIRE(a.taps == 9 && a.stride == 1 && a.pad == 1 && a.Hu == 0 && batch_z == 1 && trans_from < 0 && a.epi == MG_EPI_BF16,
+               "igemm: a folded 1x1 convolution (p[12]) rides on a plain 3x3 / stride 1 / pad 1 convolution");
+    MG_REQUIRE(a.xcin > 0 && a.xcin % 64 == 0 && a.xc0 > 0 && a.xc0 % 64 == 0 && a.xc0 <= a.xcin && (a.X1 != nullptr) == (a.xc0 < a.xcin) &&
+               a.ldx0 % 8 == 0 && a.ldx1 % 8 == 0 && (uintptr_t)a.X0 % 16 == 0 && (uintptr_t)a.X1 % 16 == 0 && a.ldw >= a.taps * a.Cin + a.xcin,
+               "igemm: bad folded source (Cx %d, Cx0 %d: multiples of 64; weight rows hold taps * Cin + Cx columns)", a.xcin, a.xc0);
+  }
   {   // tuning only: phase stamps of every workgroup into the (otherwise idle) split-K workspace - tools/igemm_phases.py
     static const int st = mg_tuning_int("MARIGOLD_IGEMM_STAMPS", 0);
     a.stamps = (st && op->i[31] <= 1 && (variant == 72 || variant == 73)) ? (unsigned long long*)g_splitk_ws : nullptr;
@@ -310,14 +326,14 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
   if (a.res && ((uintptr_t)a.res % 16 != 0)) return -1;
   int rc = 0;
   const int nmain = trans_from >= 0 ? trans_from : a.N;
-  const int K = a.taps * a.Cin;
+  const int K = a.taps * a.Cin + a.xcin;
   if (nmain > 0) {
     Igemm2Args m = a;
     m.N = nmain;
     m.n_begin = 0;
     m.n_end = nmain;
     int v = variant ? variant : mg_igemm_auto_variant(m.M, m.n_end, K, batch_z, geglu);
-    if (!variant && (v == 72 || v == 73) && !((long long)(a.M / a.rows_per_img) * a.H * a.W * max(a.lda, a.lda1) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30)))
+    if (!variant && (v == 72 || v == 73) && !((long long)(a.M / a.rows_per_img) * a.H * a.W * max(max(a.lda, a.lda1), max(a.ldx0, a.ldx1)) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30)))
       v = v == 72 ? 62 : 46;   // operands beyond the hand-placed loops' 31-bit byte offsets
     rc = dispatch_tile<false>(m, batch_z, v, s);
     if (rc) return rc;

@@ -14,6 +14,9 @@ struct Igemm2Args {
   const bf16_t* A;
   const bf16_t* A1;   // second channel source (channels [C0, Cin) of every tap; the UNet's skip concat) or nullptr
   int C0, lda1, c0t;  // channels / row stride of the sources; c0t = K tiles per tap that come from A (= cpt without A1)
+  const bf16_t* X0;   // a 1x1 convolution folded in as extra K (the ResNet block's conv_shortcut): K tiles [taps * cpt, + xcpt) read pixel
+  const bf16_t* X1;   // (y, x) of X0 (channels [0, xc0)) and X1 ([xc0, xcin)); nullptr = none
+  int xcin, xc0, ldx0, ldx1, xcpt, xc0t;
   const bf16_t* Wt;
   void* out;
   const float* bias;
@@ -216,12 +219,30 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
       a_ptr[it] = ok ? pv : zero;
     }
   };
-  int i_tap = kt0 ? fdiv(kt0, a.fd_cpt) : 0, i_c = kt0 - i_tap * a.cpt;  // (tap, channel tile) of the NEXT tile to issue
-  tap_setup(i_tap, i_c >= a.c0t);
-  if (const int skip = i_c >= a.c0t ? i_c - a.c0t : i_c) {
+  // the folded 1x1 convolution's K tiles (behind the taps): the window's centre pixel of X0 / X1 - i_tap == taps marks them
+  auto fold_setup = [&](bool second) {
+    const bf16_t* Sb = second ? a.X1 : a.X0;
+    const int ld = second ? a.ldx1 : a.ldx0;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it)
-      if (a_ptr[it] != zero) a_ptr[it] += skip * ROWB;
+    for (int it = 0; it < A_IT; ++it) {
+      const int iy = a_by[it] + a.pad, ix = a_bx[it] + a.pad;
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      a_ptr[it] = ok ? (const char*)(Sb + (long long)(a_img[it] + iy * a.W + ix) * ld + a_qoff[it]) : zero;
+    }
+  };
+  const int KTm = a.taps * a.cpt;   // K tiles of the taps
+  int i_tap = kt0 ? fdiv(kt0, a.fd_cpt) : 0, i_c = kt0 - i_tap * a.cpt;  // (tap, channel tile) of the NEXT tile to issue
+  if (kt0 >= KTm) { i_tap = a.taps; i_c = kt0 - KTm; }
+  {
+    const bool fold = i_tap >= a.taps;
+    const bool second = fold ? i_c >= a.xc0t : i_c >= a.c0t;
+    if (fold) fold_setup(second);
+    else tap_setup(i_tap, second);
+    if (const int skip = second ? i_c - (fold ? a.xc0t : a.c0t) : i_c) {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)
+        if (a_ptr[it] != zero) a_ptr[it] += skip * ROWB;
+    }
   }
   // LDS map: [stage][A rows | B rows]; the ping-pong schedule keeps [A stage 0 | A stage 1 | B stage 0 | B stage 1]
   // so that both stages of an operand are within the 16-bit immediate offset of one base address.
@@ -239,10 +260,15 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     }
   };
   auto advance = [&]() {
+    if (i_tap >= a.taps) {   // inside the folded 1x1 convolution: X0, then X1
+      if (++i_c == a.xc0t && a.xc0t < a.xcpt) fold_setup(true);
+      return;
+    }
     if (++i_c == a.cpt) {
       i_c = 0;
       ++i_tap;
       if (i_tap < a.taps) tap_setup(i_tap);
+      else if (a.xcpt) fold_setup(false);
     } else if (i_c == a.c0t) {
       tap_setup(i_tap, true);   // the remaining channel tiles of this tap come from the second source
     }
@@ -401,20 +427,46 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     };
     // The K tiles are staged in SEGMENTS (one tap of one source): inside a segment the per-lane offsets are fixed and a tile
     // costs two SALU adds; (j_tap, j_c) = the next tile to stage, seg_left = tiles left in its segment.
+    auto fold_setup4 = [&](bool second) {   // the folded 1x1 convolution's segments: the window's centre pixel of X0 / X1
+      const int ld = second ? a.ldx1 : a.ldx0;
+      const unsigned long long b = (unsigned long long)(uintptr_t)(second ? a.X1 : a.X0);
+      loA = sgpr((unsigned)b);
+      hiA = sgpr((unsigned)(b >> 32));
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) {
+        const int iy = a_by[it] + a.pad, ix = a_bx[it] + a.pad;
+        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        va[it] = ok ? (unsigned)((a_img[it] + iy * a.W + ix) * ld + a_qoff[it]) * 2u : OOB;
+      }
+    };
     int j_tap = kt0 ? fdiv(kt0, a.fd_cpt) : 0, j_c = kt0 - j_tap * a.cpt;
+    if (kt0 >= KTm) { j_tap = a.taps; j_c = kt0 - KTm; }
     int seg_left;
-    {
+    if (j_tap >= a.taps) {
+      const bool second = j_c >= a.xc0t;
+      fold_setup4(second);
+      add_base(loA, hiA, (unsigned)(second ? j_c - a.xc0t : j_c) * ROWB);
+      seg_left = second ? a.xcpt - j_c : a.xc0t - j_c;
+    } else {
       const bool second = j_c >= a.c0t;
       tap_setup4(j_tap, second);
       add_base(loA, hiA, (unsigned)(second ? j_c - a.c0t : j_c) * ROWB);
       seg_left = second ? a.cpt - j_c : a.c0t - j_c;
     }
     auto next_segment = [&]() {   // called with seg_left == 0 and at least one more tile to stage
-      if (j_c == a.cpt) {
+      if (j_tap >= a.taps) {        // inside the folded 1x1 convolution: X0 is done, X1 follows
+        fold_setup4(true);
+        seg_left = a.xcpt - a.xc0t;
+      } else if (j_c == a.cpt) {
         j_c = 0;
         ++j_tap;
-        tap_setup4(j_tap, false);
-        seg_left = a.c0t;
+        if (j_tap < a.taps) {
+          tap_setup4(j_tap, false);
+          seg_left = a.c0t;
+        } else {
+          fold_setup4(false);
+          seg_left = a.xc0t;
+        }
       } else {
         tap_setup4(j_tap, true);
         seg_left = a.cpt - a.c0t;

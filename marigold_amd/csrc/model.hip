@@ -92,7 +92,7 @@ int load_program(FILE* f, const ImgProgram& ip, mg_model* m, Prog* out) {
   for (const ImgReloc& r : rel) {
     MG_REQUIRE(r.op < ip.n_ops && r.buf < m->bufs.size(), "mg_model_load: relocation out of range (%s)", out->name.c_str());
     char* p = m->bufs[r.buf] + r.off;
-    if (r.slot < 12) {
+    if (r.slot < 16) {
       ops[r.op].p[r.slot] = p;
     } else {   // the (i[29], i[30]) address pair of MG_OP_IGEMM's row-statistics tickets
       MG_REQUIRE(r.slot == 100 && ops[r.op].kind == MG_OP_IGEMM, "mg_model_load: unknown relocation slot %u", r.slot);

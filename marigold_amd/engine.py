@@ -42,6 +42,7 @@ VAE_FLASH_SMALL_MIN_BLOCKS = _tune("MARIGOLD_VAE_FLASH_MIN_BLOCKS", 100)   # fla
 IGEMM73_CONV = _tune("MARIGOLD_IGEMM73_CONV", True)     # plain N = 320 k convolutions on the hand-placed 192 x 320 GEMM tile
 IGEMM73_CONV_MIN_TILES = _tune("MARIGOLD_IGEMM73_CONV_MIN_TILES", 120)
 IGEMM72_VAE = _tune("MARIGOLD_IGEMM72_VAE", True)       # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
+FOLD_SHORTCUT = _tune("MARIGOLD_FOLD_SHORTCUT", True)   # conv_shortcut as extra K of conv2 where conv2 runs on the implicit GEMM
 GN_SLAB = _tune("MARIGOLD_GN_SLAB", True)               # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 GN_SLAB_MIN_WG = _tune("MARIGOLD_GN_SLAB_MIN_WG", 64)   # ... from this many (image, channel window) workgroups,
 GN_SLAB_SMALL_KB = _tune("MARIGOLD_GN_SLAB_SMALL_KB", 48)   # or fewer when a workgroup's share of the tensor is at most this (small ensembles)
@@ -107,6 +108,16 @@ class WeightStore:
 
     def conv3x3(self, name):
         return self._memo(("c3", name), lambda: Wm.bf16(Wm.pack_conv3x3(self.sd[f"{name}.weight"].float()), self.device))
+
+    def conv3x3_fold(self, name, shortcut):
+        """conv3x3 ``name`` with the 1x1 convolution ``shortcut`` of another tensor folded in as extra K (MG_OP_IGEMM p[12]):
+        rows [Cout][9 Cin | Cx] bf16 and the two biases' sum."""
+        def f():
+            ws_ = self.sd[f"{shortcut}.weight"].float()
+            w = torch.cat([Wm.pack_conv3x3(self.sd[f"{name}.weight"].float()), ws_.reshape(ws_.shape[0], -1)], dim=1)
+            b = self.sd[f"{name}.bias"].float() + self.sd[f"{shortcut}.bias"].float()
+            return Wm.bf16(w, self.device), Wm.f32(b, self.device)
+        return self._memo(("c3f", name), f)
 
     def conv3x3_subpix(self, name):
         return self._memo(("c3s", name), lambda: Wm.bf16(Wm.pack_conv3x3_subpix(self.sd[f"{name}.weight"].float()), self.device))
@@ -457,7 +468,17 @@ class Builder:
         self.add(op, name)
         return out
 
-    def conv3x3(self, x, name, cout, *, stride=1, pad=1, up=None, rowvec=None, residual=None, out=None):
+    def conv_on_gemm(self, B, H, W, Cin, cout):
+        """Does a plain stride-1 3x3 convolution of this shape run on MG_OP_IGEMM (True) or on the patch-resident kernel?
+        (the rule of ``conv3x3`` below)"""
+        M = B * H * W
+        big = (IGEMM72_VAE and cout % 256 == 0 and Cin >= 512 and -(-M // 256) * (cout // 256) >= 720) or \
+              (IGEMM73_CONV and cout % 320 == 0 and cout % 256 != 0 and Cin >= 320 and -(-M // 192) * (cout // 320) >= IGEMM73_CONV_MIN_TILES)
+        return big or not (USE_PATCH and self.patch_eligible(H, W, B, cout, False))
+
+    def conv3x3(self, x, name, cout, *, stride=1, pad=1, up=None, rowvec=None, residual=None, out=None, fold=None):
+        """``fold`` = (shortcut layer name, x0, x1 | None): that 1x1 convolution of x0 (+ x1) rides as extra K (implicit GEMM only:
+        the caller asks ``conv_on_gemm`` first)."""
         H, W = (up if up else (x.H, x.W))
         if stride == 1:
             Ho, Wo = H, W
@@ -470,6 +491,15 @@ class Builder:
         self.drop_gn(out)
         # (round 4) plain 512-channel VAE convolutions with >= 720 tiles of 256 x 256: the hand-placed implicit-GEMM tile
         # (variant 72, picked by the library) runs them at 1 284 TFLOP/s against 1 202 / 1 050 for the patch kernels
+        if fold is not None:
+            sc, x0, x1 = fold
+            assert stride == 1 and pad == 1 and up is None and residual is None and self.conv_on_gemm(x.B, x.H, x.W, x.C, cout)
+            wf, bf = self.ws.conv3x3_fold(name, sc)
+            cx = x0.C + (x1.C if x1 is not None else 0)
+            self.add(O.igemm(x.t, wf, out.t, B=x.B, H=x.H, W=x.W, Cin=x.C, Ho=Ho, Wo=Wo, N=cout, taps=9, stride=1, pad=1, bias=bf,
+                             rowvec=rowvec, rowvec_bcast=rowvec is not None,
+                             fold=(x0.t, None if x1 is None else x1.t, x0.C, cx)), f"{name}+{sc.rsplit('.', 1)[-1]}")
+            return out
         big_gemm = (IGEMM72_VAE and up is None and stride == 1 and pad == 1 and cout % 256 == 0 and x.C >= 512 and
                     -(-x.M // 256) * (cout // 256) >= 720)
         # ... and the plain N = 320 k convolutions with a chip's worth of 192 x 320 tiles (the 640-channel level at 48 x 48) on
@@ -552,12 +582,13 @@ class Builder:
         Cin = sum(y.C for y in srcs)
         patch = USE_PATCH and self.patch_eligible(x.H, x.W, x.B, cout)
 
-        def norm_conv(inputs, norm, conv, rowvec=None, residual=None, out=None):
+        def norm_conv(inputs, norm, conv, rowvec=None, residual=None, out=None, fold=None):
             cin = sum(y.C for y in inputs)
             fused = patch and self.fuse_norm_into_conv(x.B, x.H, x.W, cin, cout)
+            assert fold is None or not fused
             if not fused and self.gn_slab_ok(inputs, True):   # statistics + normalisation (+ the concat) in one launch
                 ss, h = self.gn_slab(inputs, norm, eps, True, True)
-                y = self.conv3x3(h, conv, cout, rowvec=rowvec, residual=residual, out=out)
+                y = self.conv3x3(h, conv, cout, rowvec=rowvec, residual=residual, out=out, fold=fold)
                 self.free(h, ss)
                 return y
             ss = self.gn_scale_shift(inputs, norm, eps)
@@ -565,13 +596,19 @@ class Builder:
                 y = self.conv3x3p(inputs, conv, cout, ss=ss, silu=True, rowvec=rowvec, residual=residual, out=out)
             else:
                 h = self.gn_apply(inputs, ss, norm, True)
-                y = self.conv3x3(h, conv, cout, rowvec=rowvec, residual=residual, out=out)
+                y = self.conv3x3(h, conv, cout, rowvec=rowvec, residual=residual, out=out, fold=fold)
                 self.free(h)
             self.free(ss)
             return y
 
         h1 = norm_conv(srcs, f"{name}.norm1", f"{name}.conv1", rowvec=temb_row)
-        if self.ws.has(f"{name}.conv_shortcut"):
+        sc = f"{name}.conv_shortcut"
+        # (round 5) where conv2 runs on the implicit GEMM (the 48 x 48 ... 12 x 12 levels) its conv_shortcut - a 1x1 convolution of the
+        # block's INPUT - rides as extra K of conv2: one launch instead of two, no residual tensor written and read back
+        if (FOLD_SHORTCUT and self.ws.has(sc) and all(y.C % 64 == 0 for y in srcs) and cout % 64 == 0 and
+                not (patch and self.fuse_norm_into_conv(x.B, x.H, x.W, cout, cout)) and self.conv_on_gemm(x.B, x.H, x.W, cout, cout)):
+            out = norm_conv([h1], f"{name}.norm2", f"{name}.conv2", fold=(sc, x, skip))
+        elif self.ws.has(f"{name}.conv_shortcut"):
             res = self.dense(x, self.ws.mat(f"{name}.conv_shortcut"), self.ws.bias(f"{name}.conv_shortcut"),
                              cout, label=f"{name}.conv_shortcut", skip=skip)
             out = norm_conv([h1], f"{name}.norm2", f"{name}.conv2", residual=res, out=res)  # in-place residual add

@@ -27,7 +27,7 @@ from .modules import AutoencoderKLHIP, UNet2DConditionModelHIP
 MAGIC = b"MGIMG1\0\0"
 VERSION = 1
 KIND_SCRATCH, KIND_ZERO, KIND_DATA = 0, 1, 2
-SLOT_LN_COUNTERS = 100   # relocation slot of the (i[29], i[30]) address pair of MG_OP_IGEMM; slots 0..11 = p[k]
+SLOT_LN_COUNTERS = 100   # relocation slot of the (i[29], i[30]) address pair of MG_OP_IGEMM; slots 0..15 = p[k]
 _PRED = {"depth": (L.POST_DEPTH, 1), "normals": (L.POST_NORMALS, 3), "iid": (L.POST_UNIT, 3)}
 
 
@@ -133,7 +133,7 @@ def export_model_image(pipe, path, *, ensemble_size, height, width, denoising_st
             for k, op in enumerate(seq.ops):
                 c = L.MgOp()
                 ctypes.memmove(ctypes.addressof(c), ctypes.addressof(op), sz_op)
-                for s in range(12):
+                for s in range(16):
                     ptr = c.p[s]
                     if ptr:
                         hit = bufs.find(ptr)

@@ -44,7 +44,9 @@ def igemm(a, w, out, *, B, H, W, Cin, Ho, Wo, N, taps=1, stride=1, pad=0, up=Non
           rowvec=None, residual=None, epi=L.EPI_BF16, ldo=None, out2=None, trans_from=-1, ldt=0,
           batch_z=1, ldr=0, lda=0, ldw=0, zstrides=(0, 0, 0, 0), scale=1.0, variant=0,
           rowvec_bcast=False, n_alg=0, k_alg=0, a1=None, C0=0, lda1=0, ln_out=None, ln_in=None, ln_g=None, ln_c=None,
-          ln_eps=1e-5, sm_scale=0.0, sm_cols=0, c2=0, trans_perm=False, ln_counters=None, splits=0):
+          ln_eps=1e-5, sm_scale=0.0, sm_cols=0, c2=0, trans_perm=False, ln_counters=None, splits=0, fold=None):
+    """``fold`` = (x0, x1 | None, Cx0, Cx[, ldx0, ldx1]): a 1x1 convolution of a second tensor (the ResNet block's conv_shortcut)
+    as extra K of this 3x3 convolution; ``w`` rows are then [conv weights | shortcut weights]."""
     hu, wu = up if up else (0, 0)
     cp = _ptr(ln_counters) or 0   # the program's own row-block tickets (two int32 halves of the device address)
     c_lo, c_hi = cp & 0xffffffff, (cp >> 32) & 0xffffffff
@@ -54,8 +56,8 @@ def igemm(a, w, out, *, B, H, W, Cin, Ho, Wo, N, taps=1, stride=1, pad=0, up=Non
     return make_op(L.OP_IGEMM,
                    i=[B, H, W, Cin, Ho, Wo, N, taps, stride, pad, hu, wu, epi, ldo, trans_from,
                       batch_z, ldr, lda, ldt, variant, ldw, int(rowvec_bcast), n_alg, k_alg, C0, lda1,
-                      int(trans_perm), sm_cols, c2, c_lo, c_hi, splits],
-                   f=[scale, ln_eps, sm_scale], p=[a, w, out, bias, rowvec, residual, out2, a1, ln_out, ln_in, ln_g, ln_c],
+                      int(trans_perm), sm_cols, c2, c_lo, c_hi, splits] + ([fold[3], fold[2], fold[4] if len(fold) > 4 else 0, fold[5] if len(fold) > 5 else 0] if fold else []),
+                   f=[scale, ln_eps, sm_scale], p=[a, w, out, bias, rowvec, residual, out2, a1, ln_out, ln_in, ln_g, ln_c] + ([fold[0], fold[1]] if fold else []),
                    l=list(zstrides))
 
 

@@ -29,6 +29,8 @@ def op_cost(op):
         epi, bz = i[12], max(1, i[15])
         M, K = B * Ho * Wo, taps * Cin
         flops = 2 * M * (i[22] or N) * (i[23] or K) * bz   # i[22] / i[23]: un-padded N / K of the boundary convs
+        cx = i[32] if op.p[12] else 0                      # a folded 1x1 convolution: extra K, its input and weights read once
+        flops += 2 * M * N * cx
         n_out = N // 2 if epi == L.EPI_GEGLU else N
         osz = 4 if epi == L.EPI_F32 else 2   # bf16 for the plain, GEGLU and pair-softmax epilogues
         if taps == 4:   # sub-pixel up-sampling conv: the 4 parities share one input, each writes its own output pixels
@@ -41,6 +43,7 @@ def op_cost(op):
             byts = B * H * W * Cin * 2 + N * K * 2 + c2 * N * 2 + M * c2 * 2 + (M * c2 * 2 if op.p[5] else 0)
         elif op.p[5]:
             byts += bz * M * n_out * 2   # fused residual read
+        byts += (M + N) * cx * 2
     elif k == L.OP_ROWGEMM:
         M, K, N, form = i[0], i[1], i[2], i[6]
         flops = 2 * M * N * K

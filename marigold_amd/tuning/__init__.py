@@ -22,8 +22,9 @@ ENABLED = not (os.environ.get("MARIGOLD_TUNING") == "1" and os.environ.get("MARI
 def key_of(op):
     i = op.i
     M, K = i[0] * i[4] * i[5], i[7] * i[3]
-    return (f"{M},{i[6]},{K},{i[7]},{i[8]},{i[12]},{int(i[14] >= 0)},{max(1, i[15])},"
-            f"{int(bool(op.p[5]))},{int(bool(op.p[8]))},{int(bool(op.p[9]))},{int(bool(op.p[7]))},{int(bool(op.p[4]))}")
+    key = (f"{M},{i[6]},{K},{i[7]},{i[8]},{i[12]},{int(i[14] >= 0)},{max(1, i[15])},"
+           f"{int(bool(op.p[5]))},{int(bool(op.p[8]))},{int(bool(op.p[9]))},{int(bool(op.p[7]))},{int(bool(op.p[4]))}")
+    return key + (f",x{i[32]}" if op.p[12] else "")   # (a folded 1x1 convolution: its channel count)
 
 
 def load():

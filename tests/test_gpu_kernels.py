@@ -167,6 +167,68 @@ def test_igemm_conv3x3_dominant_shapes(dev, case):
     _close(f"conv3x3/{name}", out.float().permute(0, 3, 1, 2), ref)
 
 
+# conv2 + conv_shortcut of a ResNet block in one launch: the 1x1 convolution of the block's input (one tensor, or the
+# decoder's [x | skip] pair) as extra K tiles after the nine taps (MG_OP_IGEMM p[12] / p[13]).
+FOLD_CASES = [
+    # name, B, H, W, Cin, Cout, Cx0, Cx1, variant, splits
+    ("fold_auto_one_source", 2, 12, 12, 128, 128, 64, 0, 0, 0),
+    ("fold_auto_two_sources", 1, 24, 24, 320, 320, 320, 320, 0, 0),
+    ("fold_v36_two_sources_ragged", 1, 9, 7, 128, 192, 64, 128, 36, -1),
+    ("fold_v32", 2, 12, 20, 64, 128, 128, 0, 32, -1),
+    ("fold_v23", 1, 13, 12, 128, 128, 64, 64, 23, -1),
+    ("fold_v46", 2, 12, 20, 128, 320, 192, 128, 46, -1),
+    ("fold_v72", 1, 24, 24, 128, 256, 192, 64, 72, -1),
+    ("fold_v73_nedge", 1, 14, 14, 128, 256, 64, 128, 73, -1),
+    ("fold_v73_split3", 1, 24, 24, 640, 640, 640, 320, 73, 3),      # a split that starts inside the folded K range
+    ("fold_v36_split_in_fold", 1, 12, 12, 64, 128, 512, 256, 36, 4),   # most of K is the folded part
+    ("fold_v72_split2", 1, 12, 12, 1280, 256, 1280, 1280, 72, 2),
+    ("fold_auto_split", 1, 12, 12, 1280, 1280, 1280, 1280, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", FOLD_CASES, ids=[c[0] for c in FOLD_CASES])
+def test_igemm_conv3x3_folded_shortcut(dev, case):
+    from marigold_amd import ops, weights as Wm
+    name, B, H, W, Cin, Cout, Cx0, Cx1, variant, splits = case
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    Cx = Cx0 + Cx1
+    h = _bf(torch.randn(B, Cin, H, W, generator=g))
+    xs = _bf(torch.randn(B, Cx, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    wsc = _bf(torch.randn(Cout, Cx, 1, 1, generator=g) / math.sqrt(Cx))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(h, w, bias, padding=1) + F.conv2d(xs, wsc)
+    wd = torch.cat([Wm.pack_conv3x3(w), wsc.reshape(Cout, Cx)], dim=1).to(dev, torch.bfloat16).contiguous()
+    x0 = _nhwc(xs[:, :Cx0]).to(dev, torch.bfloat16).contiguous()
+    x1 = _nhwc(xs[:, Cx0:]).to(dev, torch.bfloat16).contiguous() if Cx1 else None
+    out = torch.full((B, H, W, Cout), float("nan"), device=dev, dtype=torch.bfloat16)
+    op = ops.igemm(_nhwc(h).to(dev, torch.bfloat16), wd, out, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, N=Cout, taps=9, stride=1, pad=1,
+                   bias=bias.to(dev), variant=variant, splits=splits, fold=(x0, x1, Cx0, Cx))
+    _run(op)
+    _close(f"conv3x3+shortcut/{name}", out.float().permute(0, 3, 1, 2), ref)
+    # the same through strided sources (the shortcut input as a channel window of a wider tensor)
+    wide = torch.full((B, H, W, Cx0 + 64), float("nan"), device=dev, dtype=torch.bfloat16)
+    wide[..., :Cx0] = x0
+    out2 = torch.full_like(out, float("nan"))
+    _run(ops.igemm(_nhwc(h).to(dev, torch.bfloat16), wd, out2, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, N=Cout, taps=9, stride=1, pad=1,
+                   bias=bias.to(dev), variant=variant, splits=splits, fold=(wide, x1, Cx0, Cx, Cx0 + 64, 0)))
+    assert torch.equal(out, out2)
+
+
+def test_igemm_fold_rejects_what_it_cannot_run(dev):
+    from marigold_amd import ops, _lib as L
+    x = torch.zeros(1, 8, 8, 64, device=dev, dtype=torch.bfloat16)
+    w = torch.zeros(64, 9 * 64 + 64, device=dev, dtype=torch.bfloat16)
+    out = torch.zeros(1, 8, 8, 64, device=dev, dtype=torch.bfloat16)
+    kw = dict(B=1, H=8, W=8, Cin=64, Ho=8, Wo=8, N=64, taps=9, stride=1, pad=1)
+    for bad in (dict(fold=(x, None, 64, 96)),            # Cx not a multiple of the K tile
+                dict(fold=(x, x, 64, 64)),               # a second source with nothing left for it
+                dict(fold=(x, None, 64, 64), epi=L.EPI_F32)):
+        with pytest.raises(L.MarigoldHipError):
+            _run(ops.igemm(x, w, out, **{**kw, **bad}))
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,variant", [(2, 6, 10, 64, 128, 0), (1, 16, 16, 192, 320, 0), (2, 24, 20, 128, 256, 62),
                                                      (1, 9, 7, 64, 64, 23), (2, 48, 48, 640, 640, 0)])
 def test_igemm_subpixel_upsample_conv(dev, B, H, W, Cin, Cout, variant):

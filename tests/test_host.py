@@ -26,7 +26,7 @@ def test_library_loads_and_exports_header_symbols():
     assert set(names) == set(_lib.EXPORTS)
     assert lib.mg_abi_version() == _lib.ABI_VERSION
     import ctypes
-    assert ctypes.sizeof(_lib.MgOp) == 296   # kind + i[32] + f[8] (+4 pad) + p[12] + l[4]
+    assert ctypes.sizeof(_lib.MgOp) == 360   # kind + i[40] + f[8] (+4 pad) + p[16] + l[4]
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -47,7 +47,7 @@ def time_op(op, iters, stream):
 
 
 def key_of(op):
-    return (op.kind,) + tuple(op.i[j] for j in range(31) if j != 19) + tuple(bool(op.p[j]) for j in range(12))
+    return (op.kind,) + tuple(op.i[j] for j in range(36) if j not in (19, 31)) + tuple(bool(op.p[j]) for j in range(16))
 
 
 def main():
@@ -93,7 +93,7 @@ def main():
                 continue
             seen[k] = [label, 1]
             B, H, W, Cin, Ho, Wo, N, taps = (op.i[j] for j in range(8))
-            Mrows, K = B * Ho * Wo, taps * Cin
+            Mrows, K = B * Ho * Wo, taps * Cin + (op.i[32] if op.p[12] else 0)
             epi = op.i[12]
             can_split = epi == L.EPI_BF16 and op.i[14] < 0 and op.i[15] <= 1 and not op.p[8] and not op.p[9]
             op = clone(op, 0, 0)   # the heuristic's choice is the baseline (whatever table the engine applied)
