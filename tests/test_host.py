@@ -645,15 +645,19 @@ def test_tuning_table_is_well_formed_and_applied():
     assert {23, 32, 35, 36, 46, 62, 72, 73} <= tiles
     for key, (variant, splits, t_auto, t_best, where) in db.items():
         parts = key.split(",")
+        if len(parts) == 14:   # conv2 + conv_shortcut in one launch: the folded 1x1 convolution's channel count
+            assert re.fullmatch(r"x\d+", parts[13]) and int(parts[13][1:]) % 64 == 0 and parts[3] == "9", key
+            parts = parts[:13]
         assert len(parts) == 13 and all(re.fullmatch(r"-?\d+", x) for x in parts), key
-        assert variant in tiles and 1 <= splits <= 8, (key, variant, splits)
+        assert variant in tiles and 1 <= splits <= 24, (key, variant, splits)
         assert t_best <= 0.94 * t_auto + 0.11, (key, t_auto, t_best)   # (both are stored rounded to 0.1 us)
         if int(parts[5]) != L.EPI_BF16 or int(parts[9]) or int(parts[10]) or int(parts[6]) or int(parts[7]) > 1:
             assert splits == 1, f"{key}: split-K only for the plain bf16 epilogue"   # row statistics / folded LayerNorm / GEGLU / V^T
     # an op matching a table entry gets the entry; variant / splits given by the caller are left alone
     def usable(k):
         p_ = k.split(",")
-        return (p_[3], p_[4], p_[5], p_[6], p_[7], p_[9], p_[10], p_[11]) == ("9", "1", "0", "0", "1", "0", "0", "0") and int(int(p_[0]) ** 0.5) ** 2 == int(p_[0])
+        return (len(p_) == 13 and (p_[3], p_[4], p_[5], p_[6], p_[7], p_[9], p_[10], p_[11]) == ("9", "1", "0", "0", "1", "0", "0", "0") and
+                int(int(p_[0]) ** 0.5) ** 2 == int(p_[0]))
     key, (variant, splits, *_rest) = next((k, v) for k, v in db.items() if usable(k))
     parts = key.split(",")
     M_, N_, K_ = (int(x) for x in parts[:3])
@@ -666,6 +670,13 @@ def test_tuning_table_is_well_formed_and_applied():
     assert (tuning.apply(op).i[19], op.i[31]) == (variant, splits)
     op2 = O.igemm(a, a, a, variant=23, **kw)
     assert (tuning.apply(op2).i[19], op2.i[31]) == (23, 0)
+    # a folded launch has its own entries (more K than the plain convolution of the same shape)
+    fkey, (fv, fs, *_r) = next((k, v) for k, v in db.items() if k.count(",") == 13 and int(int(k.split(",")[0]) ** 0.5) ** 2 == int(k.split(",")[0]))
+    fp = fkey.split(",")
+    HW, cx = int(int(fp[0]) ** 0.5), int(fp[13][1:])
+    opf = O.igemm(a, a, a, B=1, H=HW, W=HW, Cin=int(fp[2]) // 9, Ho=HW, Wo=HW, N=int(fp[1]), taps=9, stride=1, pad=1, bias=a,
+                  residual=a if fp[8] == "1" else None, rowvec=a if fp[12] == "1" else None, fold=(a, None, cx, cx))
+    assert tuning.key_of(opf) == fkey and (tuning.apply(opf).i[19], opf.i[31]) == (fv, fs)
 
 
 def test_model_image_round_trip_without_gpu(tmp_path):
