@@ -75,7 +75,8 @@ enum mg_op_kind {
    *            concat torch.cat([hidden, skip]) is normalised source by source, never materialised); block (chunk, b)
    *            writes slot slot0 + chunk.  With p[4] != NULL the image's last-arriving block also does FINALIZE's job
    *            (no finalize launch): p[2] gamma p[3] beta p[4] scale_shift [B][2][Ctot] p[5] uint32 [B] arrival counters
-   *            (zero before the first use; left zero) ; f[0] eps
+   *            (zero before the first use; left zero) ; f[0] eps.  p[6] x1 bf16 [B][HW][C1] | NULL, i[9] = C1: a second
+   *            source (channels [coff+C, +C1)) in the same launch - blocks [chunks, 2 chunks) write slots slot0 + chunks + ...
    *  FINALIZE: p[0] partials p[1] gamma f32 p[2] beta f32 p[3] scale_shift f32 [B][2][C];
    *            i: B,C,groups,slots,HW ; f[0] eps
    *  APPLY:    p[0] x  p[1] scale_shift  p[2] out bf16 [B][HW][C]  p[3] x1 | NULL ; i: B,HW,C,silu, C0 - with x1 the

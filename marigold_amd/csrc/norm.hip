@@ -75,13 +75,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
                                                        int chunks, int Ctot, int coff, int slot0, int slots,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ ss,
-                                                       unsigned* __restrict__ counters, int groups, float eps) {
+                                                       unsigned* __restrict__ counters, int groups, float eps,
+                                                       const bf16_t* __restrict__ x1, int C1) {
   extern __shared__ float lds[];  // [tyn][C][2] row-lane partials, then [C][2] channel totals
+  int chunk = blockIdx.x;
+  const int b = blockIdx.y;
+  if (chunk >= chunks) {   // the second source of the concat (blocks [chunks, 2 chunks)): channels [coff + C, +C1), the next slots
+    chunk -= chunks;
+    x = x1;
+    coff += C;
+    C = C1;
+    slot0 += chunks;
+  }
   const int cv = C >> 3;
   const int txn = cv < 256 ? cv : 256;
   const int tyn = 256 / txn;
   const int tx = threadIdx.x % txn, ty = threadIdx.x / txn;
-  const int chunk = blockIdx.x, b = blockIdx.y;
   const int rpc = (HW + chunks - 1) / chunks;
   const int r0 = chunk * rpc;
   const int r1 = min(HW, r0 + rpc);
@@ -394,14 +403,24 @@ int mg_launch_norm(const mg_op* op, hipStream_t s) {
       const int groups = op->i[6], slot0 = op->i[7], slots = op->i[8] > 0 ? op->i[8] : chunks;
       MG_REQUIRE(coff >= 0 && coff + C <= Ctot && coff % 8 == 0, "gn_stats: channel window [%d,+%d) outside %d", coff, C, Ctot);
       MG_REQUIRE(groups > 0 && Ctot % groups == 0, "gn_stats: %d channels not divisible into %d groups", Ctot, groups);
-      MG_REQUIRE(slot0 >= 0 && slot0 + chunks <= slots, "gn_stats: slots [%d,+%d) outside %d", slot0, chunks, slots);
+      // p[6] / i[9]: a second source (C1 channels right behind the first's) in the same launch - blocks [chunks, 2 chunks)
+      const bf16_t* x1 = (const bf16_t*)op->p[6];
+      const int C1 = x1 ? op->i[9] : 0;
+      const int nsrc = x1 ? 2 : 1;
+      MG_REQUIRE(!x1 || (C1 > 0 && C1 % 8 == 0 && C1 <= 256 * 8 * GN_NV && coff + C + C1 <= Ctot), "gn_stats: second source of %d channels", C1);
+      MG_REQUIRE(slot0 >= 0 && slot0 + nsrc * chunks <= slots, "gn_stats: slots [%d,+%d) outside %d", slot0, nsrc * chunks, slots);
       MG_REQUIRE((uintptr_t)op->p[1] % 8 == 0, "gn_stats: the partial table needs 8-byte alignment");
       // optional fused finalize: p[2] gamma p[3] beta p[4] scale_shift [B][2][Ctot] p[5] per-image arrival counters
       float* ssout = (float*)op->p[4];
       if (ssout) MG_REQUIRE(op->p[2] && op->p[3] && op->p[5], "gn_stats: fused finalize needs gamma, beta and counters");
-      MG_LAUNCH(gn_stats_kernel, dim3(chunks, B), dim3(256), (size_t)(tynn + 1) * 2 * C * sizeof(float), s,
+      size_t lds = (size_t)(tynn + 1) * 2 * C * sizeof(float);
+      if (x1) {
+        const int cv1 = C1 / 8, tyn1 = 256 / (cv1 < 256 ? cv1 : 256);
+        lds = max(lds, (size_t)(tyn1 + 1) * 2 * C1 * sizeof(float));
+      }
+      MG_LAUNCH(gn_stats_kernel, dim3(nsrc * chunks, B), dim3(256), lds, s,
                          (const bf16_t*)op->p[0], (float*)op->p[1], HW, C, chunks, Ctot, coff, slot0, slots,
-                         (const float*)op->p[2], (const float*)op->p[3], ssout, (unsigned*)op->p[5], groups, op->f[0]);
+                         (const float*)op->p[2], (const float*)op->p[3], ssout, (unsigned*)op->p[5], groups, op->f[0], x1, C1);
       break;
     }
     case MG_OP_GN_FINALIZE: {

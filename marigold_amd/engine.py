@@ -42,6 +42,7 @@ VAE_FLASH_SMALL_MIN_BLOCKS = _tune("MARIGOLD_VAE_FLASH_MIN_BLOCKS", 100)   # fla
 IGEMM73_CONV = _tune("MARIGOLD_IGEMM73_CONV", True)     # plain N = 320 k convolutions on the hand-placed 192 x 320 GEMM tile
 IGEMM73_CONV_MIN_TILES = _tune("MARIGOLD_IGEMM73_CONV_MIN_TILES", 120)
 IGEMM72_VAE = _tune("MARIGOLD_IGEMM72_VAE", True)       # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
+GN_STATS_ONE_LAUNCH = _tune("MARIGOLD_GN_STATS_ONE_LAUNCH", True)   # the two sources of a skip concat in one statistics launch
 FOLD_SHORTCUT = _tune("MARIGOLD_FOLD_SHORTCUT", True)   # conv_shortcut as extra K of conv2 where conv2 runs on the implicit GEMM
 GN_SLAB = _tune("MARIGOLD_GN_SLAB", True)               # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 GN_SLAB_MIN_WG = _tune("MARIGOLD_GN_SLAB_MIN_WG", 64)   # ... from this many (image, channel window) workgroups,
@@ -382,15 +383,18 @@ class Builder:
         slots = chunks * len(srcs)
         part = self.raw(B * slots * self.groups * 2 * 4)
         ss = self.raw(B * 2 * C * 4)
-        coff = 0
         counters = self.zeros_persistent("gn_counters", 4 * max(B, 1024))   # stream-ordered reuse; left zero by every use
-        for k, x in enumerate(srcs):
-            # the image's last-arriving statistics block turns the partial table into scale / shift (no finalize launch)
-            self.add(O.gn_stats(x.t, part, B=B, HW=HW, C=x.C, chunks=chunks, groups=self.groups, Ctot=C, coff=coff,
-                                slot0=k * chunks, slots=slots, gamma=self.ws.vec(f"{name}.weight"),
-                                beta=self.ws.vec(f"{name}.bias"), ss=ss, counters=counters, eps=eps),
-                     f"{name}.stats" + (f"{k}" if len(srcs) > 1 else ""))
-            coff += x.C
+        # the image's last-arriving statistics block turns the partial table into scale / shift (no finalize launch); the two
+        # sources of a skip concat share one launch
+        assert len(srcs) <= 2
+        coff = 0
+        for k, grp in enumerate([srcs] if GN_STATS_ONE_LAUNCH else [[x] for x in srcs]):
+            x1 = grp[1] if len(grp) > 1 else None
+            self.add(O.gn_stats(grp[0].t, part, B=B, HW=HW, C=grp[0].C, chunks=chunks, groups=self.groups, Ctot=C, coff=coff,
+                                slot0=k * chunks, slots=slots, gamma=self.ws.vec(f"{name}.weight"), beta=self.ws.vec(f"{name}.bias"),
+                                ss=ss, counters=counters, eps=eps, x1=x1.t if x1 else None, C1=x1.C if x1 else 0),
+                     f"{name}.stats" + (f"{k}" if len(srcs) > 1 and not GN_STATS_ONE_LAUNCH else ""))
+            coff += grp[0].C
         self.free(part)
         return ss
 

@@ -90,10 +90,11 @@ def linear(x, w, out, *, M, K, N, **kw):
 
 
 def gn_stats(x, partials, *, B, HW, C, chunks, groups, Ctot=0, coff=0, slot0=0, slots=0, gamma=None, beta=None, ss=None,
-             counters=None, eps=0.0):
-    """Partials [B][slots][groups][2]; with ``ss`` the image's last-arriving block also finalizes (MG_OP_GN_STATS)."""
-    return make_op(L.OP_GN_STATS, i=[B, HW, C, chunks, Ctot, coff, groups, slot0, slots], f=[eps],
-                   p=[x, partials, gamma, beta, ss, counters])
+             counters=None, eps=0.0, x1=None, C1=0):
+    """Partials [B][slots][groups][2]; with ``ss`` the image's last-arriving block also finalizes (MG_OP_GN_STATS).  ``x1``
+    ([B][HW][C1]): the concat's second source in the same launch (slots slot0 + chunks ...)."""
+    return make_op(L.OP_GN_STATS, i=[B, HW, C, chunks, Ctot, coff, groups, slot0, slots, C1], f=[eps],
+                   p=[x, partials, gamma, beta, ss, counters, x1])
 
 
 def gn_finalize(partials, gamma, beta, ss, *, B, C, groups, slots, HW, eps):

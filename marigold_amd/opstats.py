@@ -67,7 +67,7 @@ def op_cost(op):
         flops = 4 * B * T * T * 512
         byts = 4 * B * T * 512 * 2
     elif k == L.OP_GN_STATS:
-        byts = i[0] * i[1] * i[2] * 2
+        byts = i[0] * i[1] * (i[2] + (i[9] if op.p[6] else 0)) * 2
     elif k == L.OP_GN_APPLY:
         byts = 2 * i[0] * i[1] * i[2] * 2
     elif k == L.OP_GN_SLAB:

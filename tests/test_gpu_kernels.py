@@ -481,6 +481,24 @@ def test_igemm_two_sources_and_gn_channel_windows(dev):
         assert int(cnt.abs().sum()) == 0
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
     _close("groupnorm fused finalize vs finalize launch", runs[0], ss, tol=1e-5)
+    # both sources in ONE statistics launch (p[6]: what the engine emits for a skip concat): the same partial table and the same
+    # scale / shift, bit for bit - a block's arithmetic does not depend on which launch it belongs to
+    part_two = part.clone()
+    for C0_, C1_, s0, s1 in ((C0, C1, a0, a1), (C1, C0, a1, a0)):   # (the wider source first / second: the LDS size follows the max)
+        if s0 is a1:   # swapped order = another concat: its own two-launch reference
+            part_two.fill_(float("nan"))
+            ss_ref = torch.full((B, 2, Cin), float("nan"), device=dev)
+            for k, (src, C, coff) in enumerate(((s0, C0_, 0), (s1, C1_, C0_))):
+                _run(ops.gn_stats(src, part_two, B=B, HW=H * W, C=C, chunks=chunks, groups=groups, Ctot=Cin, coff=coff, slot0=k * chunks,
+                                  slots=2 * chunks, gamma=gd, beta=bd, ss=ss_ref, counters=cnt, eps=eps))
+        else:
+            ss_ref = runs[0]
+        part1 = torch.full_like(part, float("nan"))
+        ss1 = torch.full((B, 2, Cin), float("nan"), device=dev)
+        _run(ops.gn_stats(s0, part1, B=B, HW=H * W, C=C0_, chunks=chunks, groups=groups, Ctot=Cin, coff=0, slot0=0, slots=2 * chunks,
+                          gamma=gd, beta=bd, ss=ss1, counters=cnt, eps=eps, x1=s1, C1=C1_))
+        assert int(cnt.abs().sum()) == 0
+        assert torch.equal(part1, part_two) and torch.equal(ss1, ss_ref)
 
 
 def test_flash_attn64_benchmark_shape(dev):
