@@ -158,6 +158,9 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
   switch (variant) {
     case 22: return launch2<128, 128, 4, 2, 3, TRANS>(a, batch_z, s);
     case 23: return launch2<64, 64, 2, 2, 2, TRANS>(a, batch_z, s);
+    case 24: return launch2<64, 64, 2, 2, 4, TRANS>(a, batch_z, s);       // 23 / 35 / 32 with a deeper ring: the split-K launches of a
+    case 25: return launch2<128, 64, 2, 2, 4, TRANS, true>(a, batch_z, s);   // single member's 12^2 / 24^2 levels are bound by the
+    case 26: return launch2<128, 128, 2, 2, 3, TRANS, true>(a, batch_z, s);  // latency of a K step, not by bandwidth
     case 29: return launch2<128, 32, 4, 1, 3, TRANS>(a, batch_z, s);  // N <= 32 (4 <-> C boundary convs)
     case 54: return launch2<128, 64, 4, 1, 3, TRANS, true>(a, batch_z, s);   // one wave = 32 rows x all 64 columns (MG_EPI_XATTN2)
     case 32: return launch2<128, 128, 2, 2, 2, TRANS, true>(a, batch_z, s);
@@ -180,7 +183,7 @@ int dispatch_tile(const Igemm2Args& a, int batch_z, int variant, hipStream_t s) 
       } else MG_REQUIRE(false, "igemm: tile variant 73 has no transposed section");
       return 0;
     case 46: return launch2<128, 320, 4, 2, 2, TRANS, true>(a, batch_z, s);   // full-width tiles for N = 320
-    default: MG_REQUIRE(false, "igemm: unknown tile variant %d (22, 23, 29, 32, 35, 36, 46, 51, 54, 62, 72, 73)", variant);
+    default: MG_REQUIRE(false, "igemm: unknown tile variant %d (22 - 26, 29, 32, 35, 36, 46, 51, 54, 62, 72, 73)", variant);
   }
   return 0;
 }

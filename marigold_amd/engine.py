@@ -135,6 +135,14 @@ class WeightStore:
     def bias(self, name):
         return self.vec(f"{name}.bias") if f"{name}.bias" in self.sd else None
 
+    def time_emb_proj_all(self, names):
+        """The ResNet blocks' time_emb_proj layers stacked along N: fp32 [sum cout][temb_dim], bias [sum cout]."""
+        def f():
+            w = torch.cat([self.sd[f"{n}.time_emb_proj.weight"].float() for n in names], dim=0)
+            b = torch.cat([self.sd[f"{n}.time_emb_proj.bias"].float() for n in names], dim=0)
+            return Wm.f32(w, self.device), Wm.f32(b, self.device)
+        return self._memo(("tep", tuple(names)), f)
+
     def f32mat(self, name):
         return self._memo(("fm", name), lambda: Wm.f32(self.sd[f"{name}.weight"].reshape(self.sd[f"{name}.weight"].shape[0], -1), self.device))
 
@@ -819,12 +827,17 @@ def emit_time_embeddings(bld, cfg, timesteps):
                              M=T, N=td, K=c0, act_out=1), "time_embedding.linear_1")
     bld.add(O.linear_small_m(e1, ws.f32mat("time_embedding.linear_2"), ws.bias("time_embedding.linear_2"), emb,
                              M=T, N=td, K=td), "time_embedding.linear_2")
-    table = {}
-    for name, cout in unet_resnet_names(cfg):
-        t = bld.seq.hold(torch.empty(T, cout, device=dev))
-        bld.add(O.linear_small_m(emb, ws.f32mat(f"{name}.time_emb_proj"), ws.bias(f"{name}.time_emb_proj"), t,
-                                 M=T, N=cout, K=td, act_in=1), f"{name}.time_emb_proj")
-        table[name] = t
+    # every ResNet block's projection in ONE launch: their weights stacked along N (24 launches of ~20 us each otherwise);
+    # a block's row for step s is table[name][s] - a view of the [T][sum of couts] result
+    names = list(unet_resnet_names(cfg))
+    ntot = sum(cout for _, cout in names)
+    wcat, bcat = ws.time_emb_proj_all([name for name, _ in names])
+    tall = bld.seq.hold(torch.empty(T, ntot, device=dev))
+    bld.add(O.linear_small_m(emb, wcat, bcat, tall, M=T, N=ntot, K=td, act_in=1), "resnets.time_emb_proj")
+    table, off = {}, 0
+    for name, cout in names:
+        table[name] = tall[:, off:off + cout]
+        off += cout
     return table
 
 
@@ -837,7 +850,8 @@ def emit_unet_forward(bld, cfg, ctx, rgb_latent, x_latent, eps_out, temb_table, 
     n = len(boc)
 
     def trow(name, cout):
-        return temb_table[name].data_ptr() + step * cout * 4
+        assert temb_table[name].shape[1] == cout
+        return temb_table[name][step].data_ptr()   # cout contiguous fp32 values
 
     c0 = boc[0]
     cin = ws.sd["conv_in.weight"].shape[1]

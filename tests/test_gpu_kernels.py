@@ -62,6 +62,16 @@ CONV_CASES = [
     ("g2_128x128w8", 2, 12, 20, 64, 192, 1, 1, None, 22),
     ("g2_64x64", 1, 9, 7, 64, 64, 1, 1, None, 23),
     ("g2_256x64", 2, 16, 24, 128, 320, 1, 1, None, 35),
+    # the deeper LDS rings (4 / 4 / 3 stages): short K (fewer tiles than stages), ragged M / N, stride 2, up-sampling
+    ("g2_64x64_ring4", 1, 9, 7, 64, 64, 1, 1, None, 24),
+    ("g2_64x64_ring4_kt1_stride2", 2, 16, 16, 64, 192, 2, 1, None, 24),
+    ("g2_64x64_ring4_big_k", 1, 12, 12, 1280, 128, 1, 1, None, 24),
+    ("g2_128x64_ring4", 2, 12, 20, 192, 64, 1, 1, None, 25),
+    ("g2_128x64_ring4_up", 1, 4, 6, 64, 320, 1, 1, (7, 11), 25),
+    ("g2_128x64_ring4_big_k_medge", 1, 13, 12, 1280, 256, 1, 1, None, 25),
+    ("g2_128x128_ring3", 2, 12, 20, 320, 320, 1, 1, None, 26),
+    ("g2_128x128_ring3_stride2_pad0", 1, 16, 24, 128, 128, 2, 0, None, 26),
+    ("g2_128x128_ring3_big_k_medge", 1, 13, 12, 1280, 192, 1, 1, None, 26),
     ("g2_128x64", 2, 12, 20, 192, 64, 1, 1, None, 35),
     ("g2_256x128x2", 1, 24, 24, 64, 128, 1, 1, None, 36),
     ("g2_128x128x3", 2, 12, 20, 320, 320, 1, 1, None, 32),
@@ -528,7 +538,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = torch.randn(N, generator=g) * 0.1
     ref = x @ w.t() + b
-    for variant in (0, 22, 23, 32, 35, 36, 46, 51, 62, 72, 73):
+    for variant in (0, 22, 23, 24, 25, 26, 32, 35, 36, 46, 51, 62, 72, 73):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         _run(ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out, M=M, K=K, N=N,
                         bias=b.to(dev), variant=variant))
@@ -540,7 +550,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     xg = _bf(torch.randn(200, C, generator=g))
     u, gt = (xg @ wg.t() + bg).chunk(2, dim=-1)
     ref = u * F.gelu(gt)
-    for group, variants in ((32, (22, 23, 32, 35, 36, 51, 62, 72, 73, 0)),):
+    for group, variants in ((32, (22, 23, 24, 25, 26, 32, 35, 36, 51, 62, 72, 73, 0)),):
         wp, bp = Wm.pack_geglu(wg, bg, group)
         for variant in variants:
             out = torch.full((200, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
@@ -557,7 +567,7 @@ def test_igemm_linear_geglu_f32_trans_batched(dev):
     qk = torch.full((B * T, 3 * C), float("nan"), device=dev, dtype=torch.bfloat16)
     vt = torch.zeros((B, C, ldt), device=dev, dtype=torch.bfloat16)
     refv = refq[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1)
-    for variant in (0, 23, 32, 35, 62):
+    for variant in (0, 23, 24, 25, 26, 32, 35, 62):
         qk.fill_(float("nan"))
         vt.zero_()
         _run(ops.igemm(xq.to(dev, torch.bfloat16), wqkv.to(dev, torch.bfloat16), qk, B=B, H=T, W=1, Cin=C,
@@ -612,7 +622,7 @@ def test_igemm_layernorm_fold(dev):
     b0 = torch.randn(C, generator=g) * 0.1
     res = _bf(torch.randn(M, C, generator=g))
     ref0 = a @ w0.t() + b0 + res
-    for variant in (0, 46, 51, 35, 62, 72, 73):
+    for variant in (0, 46, 51, 35, 24, 25, 26, 62, 72, 73):
         out = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
         st = torch.full((M * (C // 32 + 1), 2), float("nan"), device=dev)
         for rep_ in range(3):   # the tickets reset themselves: every launch finalizes again
@@ -1150,7 +1160,7 @@ def test_igemm_pingpong_short_k_and_repeatability(dev):
             # same MFMA sequence per accumulator in the ping-pong and the hand-placed 256 x 256 tiles -> identical bits, every launch
             assert torch.equal(out, out62), f"v{v} launch {rep} differs from the first ping-pong launch"
     # split-K named by the op (i[31]; the tuning table's second field): fp32 partials + the fixed-order reduce launch, any tile
-    for v, sp in ((36, 2), (73, 3), (72, 4), (23, 8), (0, 6)):
+    for v, sp in ((36, 2), (73, 3), (72, 4), (23, 8), (0, 6), (24, 12), (25, 5), (26, 16)):
         first = None
         for rep in range(2):
             out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
@@ -1552,6 +1562,16 @@ def test_small_ops(dev):
     o2 = torch.empty(5, 100, device=dev)
     _run(ops.linear_small_m(xi.to(dev), w.to(dev), bb.to(dev), o2, M=5, N=100, K=320, act_in=1, act_out=1))
     _close("linear_small_m", o2, F.silu(F.silu(xi) @ w.t() + bb), tol=1e-5)
+    # more rows than one row block (16), the last block partial; a strided output (a column window of a wider table);
+    # a row's value does not depend on how many rows share the launch
+    xi = torch.randn(37, 320, generator=g)
+    o3 = torch.full((37, 164), float("nan"), device=dev)
+    _run(ops.linear_small_m(xi.to(dev), w.to(dev), bb.to(dev), o3[:, 64:], M=37, N=100, K=320, act_in=1, ldo=164))
+    _close("linear_small_m/row blocks", o3[:, 64:], F.silu(xi) @ w.t() + bb, tol=1e-5)
+    assert torch.isnan(o3[:, :64]).all()
+    o4 = torch.empty(1, 100, device=dev)
+    _run(ops.linear_small_m(xi[20:21].to(dev), w.to(dev), bb.to(dev), o4, M=1, N=100, K=320, act_in=1))
+    assert torch.equal(o4[0], o3[20, 64:])
     lat = torch.randn(2, 4, 6, 5, generator=g)
     w1 = torch.randn(4, 4, generator=g)
     b1 = torch.randn(4, generator=g)

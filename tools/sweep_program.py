@@ -53,7 +53,7 @@ def key_of(op):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ensembles", default="1,2,3,5,10")
-    ap.add_argument("--variants", default="23,25,35,21,32,27,22,20,36,26,46,51,62,72,73")
+    ap.add_argument("--variants", default="23,24,25,26,35,32,22,36,46,51,62,72,73")
     ap.add_argument("--splits", default="1,2,3,4,6,8")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--vae", action="store_true")
