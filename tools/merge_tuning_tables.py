@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """In-program vote between two tuning tables (runs without a GPU; the timings come from the MI355X): _ab/gfx950_A.json (the
 committed table) and _ab/gfx950_B.json (A + a new sweep's entries) were both benched with ``bench.py --dump-ops`` at E = 1, 2, 3, 5
-(scripts/gpu_r5_ab_tables.sh -> gpurun_out/ops_{A,B}{1,2}_e<E>.tsv).  A sweep times a launch in isolation (same launch back to
+(scripts/gpu_ab_tables.sh -> gpurun_out/ops_{A,B}{1,2}_e<E>.tsv).  A sweep times a launch in isolation (same launch back to
 back, warm L2); inside the program some of its winners lose.  An entry that differs between the tables is taken from B only if
 the layers it applies to ran >= 2 % faster in B's programs; everything else stays as in A.  Writes _ab/gfx950_C.json.
 """

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Aggregates the rocprofv3 --pmc passes of tools/microbench.py (gpurun_out/pmc/set*/..., made by
-scripts/gpu_pmc.sh) per kernel into profiles/r1_pmc_mfma_util_microbench.json: MFMA busy fraction of the
+scripts/gpu_pmc_only.sh) per kernel into profiles/r1_pmc_mfma_util_microbench.json: MFMA busy fraction of the
 SIMD time, VALU / LDS / SALU instructions per MFMA, LDS bank-conflict fraction.  Counter units follow
 MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts cycles, SQ_BUSY_CU_CYCLES / SQ_WAVE_CYCLES quad-cycles."""
 import collections
