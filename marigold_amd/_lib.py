@@ -21,6 +21,7 @@ RG_BF16, RG_GEGLU, RG_QKV, RG_XATTN = 0, 1, 2, 3
 OP_SCHED_STEP = 12
 OP_LINEAR_SMALL_M, OP_LATENT_1X1, OP_POST_NCHW, OP_IM2COL_SMALL = 13, 14, 15, 16
 OP_CONV3X3 = 17
+OP_CONV3X3_HEAD = 18
 OP_ENS_DEPTH_STATS, OP_ENS_DEPTH_MEDIAN, OP_ENS_DEPTH_NORM, OP_ENS_NORMALS = 20, 21, 22, 23
 OP_RESIZE = 24
 OP_COLORIZE = 25

@@ -158,5 +158,6 @@ int mg_launch_norm(const mg_op* op, hipStream_t s);
 int mg_launch_attention(const mg_op* op, hipStream_t s);
 int mg_launch_flash512(const mg_op* op, hipStream_t s);
 int mg_launch_misc(const mg_op* op, hipStream_t s);
+int mg_launch_head_conv(const mg_op* op, hipStream_t s);
 int mg_launch_ensemble(const mg_op* op, hipStream_t s);
 int mg_launch_resize(const mg_op* op, hipStream_t s);

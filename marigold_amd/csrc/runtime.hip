@@ -61,6 +61,7 @@ static int dispatch(const mg_op* op, hipStream_t s) {
     case MG_OP_IM2COL_SMALL:
     case MG_OP_MEMSET:
     case MG_OP_COPY: return mg_launch_misc(op, s);
+    case MG_OP_CONV3X3_HEAD: return mg_launch_head_conv(op, s);
     case MG_OP_ENS_DEPTH_STATS:
     case MG_OP_ENS_DEPTH_MEDIAN:
     case MG_OP_ENS_DEPTH_NORM:

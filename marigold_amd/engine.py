@@ -43,6 +43,7 @@ IGEMM73_CONV = _tune("MARIGOLD_IGEMM73_CONV", True)     # plain N = 320 k convol
 IGEMM73_CONV_MIN_TILES = _tune("MARIGOLD_IGEMM73_CONV_MIN_TILES", 120)
 IGEMM72_VAE = _tune("MARIGOLD_IGEMM72_VAE", True)       # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
 GN_STATS_ONE_LAUNCH = _tune("MARIGOLD_GN_STATS_ONE_LAUNCH", True)   # the two sources of a skip concat in one statistics launch
+HEAD_CONV = _tune("MARIGOLD_HEAD_CONV", True)   # conv_norm_out + SiLU + conv_out (<= 4 channels) as one MG_OP_CONV3X3_HEAD launch
 FOLD_SHORTCUT = _tune("MARIGOLD_FOLD_SHORTCUT", True)   # conv_shortcut as extra K of conv2 where conv2 runs on the implicit GEMM
 GN_SLAB = _tune("MARIGOLD_GN_SLAB", True)               # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 GN_SLAB_MIN_WG = _tune("MARIGOLD_GN_SLAB_MIN_WG", 64)   # ... from this many (image, channel window) workgroups,
@@ -549,14 +550,34 @@ class Builder:
         self.free(col)
         return out
 
-    def conv_to_nchw(self, x, key, w4, bias, out, cout, post=L.POST_NONE, scale=1.0, sched=None):
+    def head_conv_ok(self, x, cout):
+        """norm + SiLU + conv3x3 to <= 4 channels as one MG_OP_CONV3X3_HEAD launch?"""
+        return HEAD_CONV and cout <= 4 and x.C % 32 == 0
+
+    def norm_conv_to_nchw(self, x, norm, eps, key, w4, bias, out, cout, **kw):
+        """conv_norm_out -> SiLU -> conv_out -> the pointwise tail (diffusers' output heads of the UNet and the VAE decoder)."""
+        if self.head_conv_ok(x, cout):
+            ss = self.gn_scale_shift([x], norm, eps)
+            self.conv_to_nchw(x, key, w4, bias, out, cout, head_ss=ss, **kw)
+            self.free(ss)
+        else:
+            g = self.group_norm(x, norm, eps, True)
+            self.conv_to_nchw(g, key, w4, bias, out, cout, **kw)
+            self.free(g)
+
+    def conv_to_nchw(self, x, key, w4, bias, out, cout, post=L.POST_NONE, scale=1.0, sched=None, head_ss=None):
         """conv3x3 (pad 1) bf16 NHWC -> <= 4 fp32 NCHW channels on the MFMA path: GEMM into a padded
-        fp32 [M][8] buffer, then the pointwise tail (MG_OP_POST_NCHW)."""
+        fp32 [M][8] buffer, then the pointwise tail (MG_OP_POST_NCHW).  ``head_ss``: x is the RAW tensor and the GroupNorm's
+        scale / shift + SiLU are applied inside the convolution (MG_OP_CONV3X3_HEAD)."""
         w8, b8 = self.ws.small_conv_mfma(key, w4, bias)
         npad = w8.shape[0]
         tmp = self.raw(x.M * npad * 4)
-        self.add(O.igemm(x.t, w8, tmp, B=x.B, H=x.H, W=x.W, Cin=x.C, Ho=x.H, Wo=x.W, N=npad, taps=9, stride=1,
-                         pad=1, bias=b8, epi=L.EPI_F32, ldo=npad, n_alg=cout), f"{key}")
+        if head_ss is not None:
+            self.add(O.conv3x3_head(x.t, head_ss, w8, b8, tmp, B=x.B, H=x.H, W=x.W, C=x.C, Cout=cout, ldo=npad, silu=True),
+                     f"{key[:-len('conv_out')]}conv_norm_out+silu+conv_out" if key.endswith("conv_out") else f"norm+silu+{key}")
+        else:
+            self.add(O.igemm(x.t, w8, tmp, B=x.B, H=x.H, W=x.W, Cin=x.C, Ho=x.H, Wo=x.W, N=npad, taps=9, stride=1,
+                             pad=1, bias=b8, epi=L.EPI_F32, ldo=npad, n_alg=cout), f"{key}")
         if sched is not None:   # (cx, cm, cn, noise): the scheduler update replaces the store of the model output
             cx, cm, cn, nz = sched
             self.add(O.post_nchw(tmp, out, B=x.B, HW=x.HW, Cout=cout, ldi=npad, post=L.POST_SCHED, scale=scale, noise=nz,
@@ -733,6 +754,10 @@ class Builder:
             ff = self.dense(h, wg, None, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu",
                             ln=(self.ln_mean_rstd(st[2], h.M, C), gg, cg))
         self.free(*st)
+        # (round 5, tried and NOT kept: GEGLU -> ff.out in two row chunks through a chunk-sized intermediate, so that ff.out reads
+        # its 236 MB A operand out of the 256 MB memory-side cache - tools/ubench/mall_probe.py: 6.6-7.2 TB/s for working sets that
+        # fit, 5.1-5.4 beyond.  ff.out gained 0.7 ms per map, the two half-size GEGLU launches lost 3.0:
+        # profiles/r5_ff_row_chunks_lost.log)
         self.dense(ff, self.ws.mat(f"{b}.ff.net.2"), self.ws.bias(f"{b}.ff.net.2"), C, residual=h, out=h,
                    label=f"{b}.ff.out")
         self.free(ff)
@@ -897,11 +922,9 @@ def emit_unet_forward(bld, cfg, ctx, rgb_latent, x_latent, eps_out, temb_table, 
             y = bld.conv3x3(x, f"up_blocks.{i}.upsamplers.0.conv", cout, up=up)
             bld.free(x)
             x = y
-    g = bld.group_norm(x, "conv_norm_out", 1e-5, True)
+    bld.norm_conv_to_nchw(x, "conv_norm_out", 1e-5, "conv_out", ws.sd["conv_out.weight"], ws.sd["conv_out.bias"],
+                          x_latent if sched else eps_out, cfg.out_channels, sched=sched)
     bld.free(x)
-    bld.conv_to_nchw(g, "conv_out", ws.sd["conv_out.weight"], ws.sd["conv_out.bias"], x_latent if sched else eps_out,
-                     cfg.out_channels, sched=sched)
-    bld.free(g)
 
 
 # ------------------------------------------------------------------------------------------ VAE
@@ -971,9 +994,7 @@ def emit_vae_decode(bld, cfg: VAEConfig, latent, out, B, h, w, post):
             y = bld.conv3x3(x, f"decoder.up_blocks.{i}.upsamplers.0.conv", c, up=(2 * x.H, 2 * x.W))
             bld.free(x)
             x = y
-    g = bld.group_norm(x, "decoder.conv_norm_out", 1e-6, True)
+    bld.norm_conv_to_nchw(x, "decoder.conv_norm_out", 1e-6, "decoder.conv_out", ws.sd["decoder.conv_out.weight"],
+                          ws.sd["decoder.conv_out.bias"], out, 3, post=post)
     bld.free(x)
-    bld.conv_to_nchw(g, "decoder.conv_out", ws.sd["decoder.conv_out.weight"], ws.sd["decoder.conv_out.bias"],
-                     out, 3, post=post)
-    bld.free(g)
-    return g.H, g.W
+    return x.H, x.W

@@ -163,6 +163,12 @@ def im2col_small(src0, src1, out, *, B, H, W, C0, C1, Kp, bcast0=False):
     return make_op(L.OP_IM2COL_SMALL, i=[B, H, W, C0, C1, Kp, int(bcast0)], p=[src0, src1, out])
 
 
+def conv3x3_head(x, ss, w, bias, out, *, B, H, W, C, Cout, ldo=0, silu=True):
+    """GroupNorm apply (``ss`` = scale / shift [B][2][C], or None) [+ SiLU] + conv3x3 pad 1 to <= 4 fp32 channels, one launch
+    (MG_OP_CONV3X3_HEAD); ``w`` bf16 [>= Cout][9 C] as weights.pack_conv3x3 lays it out."""
+    return make_op(L.OP_CONV3X3_HEAD, i=[B, H, W, C, Cout, ldo, int(silu)], p=[x, ss, w, bias, out])
+
+
 def post_nchw(x, out, *, B, HW, Cout, ldi, post=L.POST_NONE, scale=1.0, noise=None, cx=0.0, cm=0.0, cn=0.0):
     return make_op(L.OP_POST_NCHW, i=[B, HW, Cout, ldi, post], f=[scale, cx, cm, cn], p=[x, out, noise])
 

@@ -13,7 +13,7 @@ CLASS = {
     L.OP_GN_FINALIZE: "groupnorm", L.OP_GN_APPLY: "groupnorm", L.OP_GN_SLAB: "groupnorm",
     L.OP_SOFTMAX_ROWS: "softmax",
     L.OP_SCHED_STEP: "scheduler_step", L.OP_LINEAR_SMALL_M: "time_embedding",
-    L.OP_LATENT_1X1: "boundary_conv", L.OP_POST_NCHW: "boundary_conv", L.OP_IM2COL_SMALL: "boundary_conv", L.OP_ENS_DEPTH_STATS: "ensemble", L.OP_ENS_DEPTH_MEDIAN: "ensemble",
+    L.OP_LATENT_1X1: "boundary_conv", L.OP_POST_NCHW: "boundary_conv", L.OP_CONV3X3_HEAD: "boundary_conv", L.OP_IM2COL_SMALL: "boundary_conv", L.OP_ENS_DEPTH_STATS: "ensemble", L.OP_ENS_DEPTH_MEDIAN: "ensemble",
     L.OP_ENS_DEPTH_NORM: "ensemble", L.OP_ENS_NORMALS: "ensemble", L.OP_RESIZE: "resize", L.OP_COLORIZE: "resize", L.OP_MEMSET: "memops", L.OP_COPY: "memops",
 }
 BOUND = {"igemm_mfma": "mfma", "rowgemm_mfma": "mfma", "conv3x3_patch": "mfma", "flash_attn64": "mfma", "flash_attn512": "mfma"}   # everything else is HBM-bound streaming
@@ -58,6 +58,10 @@ def op_cost(op):
         byts = B * H * W * Cin * 2 + par * (N * T * Cin * 2 + B * H * W * N * 2)
         if op.p[5]:
             byts += B * H * W * N * 2
+    elif k == L.OP_CONV3X3_HEAD:
+        B, H, W, C, co = (i[j] for j in range(5))
+        flops = 2 * B * H * W * co * 9 * C
+        byts = B * H * W * (C * 2 + co * 4)
     elif k == L.OP_FLASH_ATTN64:
         B, heads, T = i[0], i[1], i[2]
         flops = 4 * B * heads * T * T * 64

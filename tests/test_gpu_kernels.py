@@ -1676,6 +1676,63 @@ def test_program_and_graph_replay(dev):
     assert len(ms) == 3 and all(m >= 0 for m in ms)
 
 
+HEAD_CASES = [
+    # B, H, W, C, Cout, normalise, silu
+    (2, 20, 37, 64, 3, True, True),        # ragged 16 x 16 tiles
+    (1, 96, 96, 320, 4, True, True),       # the UNet's conv_norm_out -> conv_out at one member
+    (3, 33, 16, 32, 1, True, False),
+    (1, 64, 80, 128, 2, False, False),     # no normalisation: a plain conv3x3 to 2 channels
+    (4, 256, 256, 64, 3, True, True),      # >= 512 tiles of 16 x 32: two pixels per thread
+    (5, 250, 300, 32, 3, True, True),      # the same, ragged in both directions
+    (2, 256, 512, 128, 4, True, True),
+]
+
+
+@pytest.mark.parametrize("case", HEAD_CASES, ids=[f"B{c[0]}_{c[1]}x{c[2]}_C{c[3]}_to{c[4]}" + ("" if c[5] else "_raw") for c in HEAD_CASES])
+def test_conv3x3_head(dev, case):
+    """MG_OP_CONV3X3_HEAD (conv_norm_out -> SiLU -> conv_out in one launch) vs torch fp32 on the same bf16-rounded operands:
+    the normalised input is rounded to bf16 exactly where the materialising pass (MG_OP_GN_APPLY) rounds it."""
+    from marigold_amd import ops, weights as Wm
+    B, H, W, C, Cout, norm, silu = case
+    g = torch.Generator().manual_seed(B * 1000 + H + C)
+    x = _bf(torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3)
+    w = _bf(torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    scale = 1.0 + 0.3 * torch.randn(B, C, generator=g)
+    shift = 0.3 * torch.randn(B, C, generator=g)
+    h = x
+    if norm:
+        h = x * scale[:, :, None, None] + shift[:, :, None, None]
+        if silu:
+            h = F.silu(h)
+        h = _bf(h)
+    ref = F.conv2d(h, w, bias, padding=1)
+    npad = 8
+    wd = torch.zeros(npad, 9 * C)
+    wd[:Cout] = Wm.pack_conv3x3(w)
+    out = torch.full((B * H * W, npad), float("nan"), device=dev)
+    ss = torch.stack([scale, shift], dim=1).contiguous().to(dev) if norm else None
+    _run(ops.conv3x3_head(_nhwc(x).to(dev, torch.bfloat16), ss, wd.to(dev, torch.bfloat16), bias.to(dev), out,
+                          B=B, H=H, W=W, C=C, Cout=Cout, ldo=npad, silu=silu))
+    got = out[:, :Cout].reshape(B, H, W, Cout).permute(0, 3, 1, 2)
+    # (SiLU through v_exp / v_rcp before the bf16 rounding: a rounding boundary may fall the other way on single elements)
+    _close(f"conv3x3_head {case}", got, ref, tol=4e-3)
+    assert torch.isnan(out[:, Cout:]).all()   # the padding columns are not touched
+
+
+def test_conv3x3_head_rejects_what_it_cannot_run(dev):
+    from marigold_amd import ops, _lib as L
+    x = torch.zeros(1, 8, 8, 48, device=dev, dtype=torch.bfloat16)
+    w = torch.zeros(8, 9 * 48, device=dev, dtype=torch.bfloat16)
+    out = torch.zeros(64, 8, device=dev)
+    with pytest.raises(L.MarigoldHipError):   # C not a multiple of 32
+        _run(ops.conv3x3_head(x, None, w, None, out, B=1, H=8, W=8, C=48, Cout=3, ldo=8))
+    x = torch.zeros(1, 8, 8, 64, device=dev, dtype=torch.bfloat16)
+    w = torch.zeros(8, 9 * 64, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(L.MarigoldHipError):   # more than 4 output channels
+        _run(ops.conv3x3_head(x, None, w, None, out, B=1, H=8, W=8, C=64, Cout=5, ldo=8))
+
+
 def test_small_cout_conv_on_mfma_path(dev):
     """conv3x3 to <= 4 fp32 NCHW channels = GEMM into a padded fp32 [M][8] buffer (tile variant 29)
     + MG_OP_POST_NCHW with the pipeline's pointwise tails (depth mean/clip/shift, normals L2)."""
