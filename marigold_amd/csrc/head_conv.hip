@@ -16,7 +16,6 @@
 namespace {
 
 typedef __bf16 hc_v2bf16 __attribute__((ext_vector_type(2)));
-typedef uint32_t hc_u32x4 __attribute__((ext_vector_type(4)));   // (a plain vector: loadable through the constant address space)
 
 struct HeadArgs {
   const bf16_t* x;
@@ -38,15 +37,11 @@ __device__ __forceinline__ float hc_dot2(uint32_t a, uint32_t b, float c) {
 template <int COUT, int PPT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PPT == 2 ? 2 : 4))) void head_conv_kernel(const HeadArgs a) {
   constexpr int TH = 16 * PPT, PH = TH + 2, PW = HC_TW + 2;
-  constexpr int PATCH = PH * PW * HC_PS;
-  __shared__ __attribute__((aligned(16))) char smem[PATCH + 2 * HC_CK * 4];
+  constexpr int PATCH = PH * PW * HC_PS, WCH = COUT * 9 * HC_CK * 2;
+  __shared__ __attribute__((aligned(16))) char smem[PATCH + WCH + 2 * HC_CK * 4];
   char* const patch = smem;
-  float* const ssl = (float*)(smem + PATCH);   // [2][32] scale, shift of the pass
-  // the weights are the same for every lane: scalar loads (constant address space), SGPR operands of the dot products - as LDS
-  // broadcast reads (first version) they were 144 of a thread's 180 LDS reads per pass and the kernel was LDS-bound (79 us for
-  // the UNet's head at ten members, 0.8 ms for the decoder's)
-  typedef const __attribute__((address_space(4))) hc_u32x4* wconst_t;
-  const wconst_t wc = (wconst_t)(uintptr_t)a.w;
+  char* const wl = smem + PATCH;
+  float* const ssl = (float*)(smem + PATCH + WCH);   // [2][32] scale, shift of the pass
   const int tid = threadIdx.x;
   int t = blockIdx.x;
   const int txi = t % a.tiles_x; t /= a.tiles_x;
@@ -63,9 +58,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PPT == 2 ? 
 
   // The raw operands of a pass travel global -> registers -> (normalise) -> LDS, and the registers of pass c + 1 are requested
   // BEFORE pass c is computed: as a loop of dependent loads (first version) a pass cost ten HBM round trips per thread, 60 us per
-  // tile against 6 us of dot products.
+  // tile against 6 us of dot products.  The weights stay LDS broadcast reads (144 of a thread's 180 LDS reads per pass at four
+  // output channels: the kernel is LDS-bound, 0.80 ms for the decoder's ten maps); as scalar loads with SGPR operands - tried - the
+  // dot products wait on lgkmcnt, which scalar memory returns out of order and shares with LDS: 1.04 ms.
   constexpr int NIT = (PH * PW * 4 + 255) / 256;   // 16-byte patch items per thread and pass
-  uint4 u[NIT];
+  constexpr int NWI = COUT * 9 * 4;                // 16-byte weight items per pass (<= 144: one per thread)
+  uint4 u[NIT], wreg = make_uint4(0, 0, 0, 0);
   float ssreg = 0.f;
   auto request = [&](int c0) {
 #pragma unroll
@@ -77,12 +75,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PPT == 2 ? 
       const bool in = i < PH * PW * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       u[k] = in ? *(const uint4*)(xb + ((long long)gy * a.W + gx) * a.C + c0 + part * 8) : make_uint4(0, 0, 0, 0);
     }
+    if (tid < NWI) {   // [co][tap][32 channels]
+      const int part = tid & 3, ct = tid >> 2, co = ct / 9, tap = ct - co * 9;
+      wreg = *(const uint4*)(a.w + (long long)co * 9 * a.C + (long long)tap * a.C + c0 + part * 8);
+    }
     if (a.ss && tid < 2 * HC_CK) ssreg = a.ss[((long long)b * 2 + (tid >> 5)) * a.C + c0 + (tid & 31)];
   };
   request(0);
   for (int c0 = 0; c0 < a.C; c0 += HC_CK) {
     __syncthreads();   // the previous pass' reads of LDS are done
     if (tid < 2 * HC_CK) ssl[tid] = ssreg;
+    if (tid < NWI) *(uint4*)(wl + tid * 16) = wreg;
     __syncthreads();   // (scale / shift visible)
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PPT == 2 ? 
             if (dy < 0 || dy > 2) continue;
 #pragma unroll
             for (int co = 0; co < COUT; ++co) {
-              const hc_u32x4 wv = wc[((co * 9 + dy * 3 + dx) * a.C + c0) / 8 + part];   // wave-uniform address: s_load_dwordx4
+              const uint4 wv = *(const uint4*)(wl + ((co * 9 + dy * 3 + dx) * 4 + part) * 16);   // wave-uniform: a broadcast read
               float s = acc[p][co];
               s = hc_dot2(xv.x, wv.x, s); s = hc_dot2(xv.y, wv.y, s);
               s = hc_dot2(xv.z, wv.z, s); s = hc_dot2(xv.w, wv.w, s);

@@ -44,6 +44,7 @@ IGEMM73_CONV_MIN_TILES = _tune("MARIGOLD_IGEMM73_CONV_MIN_TILES", 120)
 IGEMM72_VAE = _tune("MARIGOLD_IGEMM72_VAE", True)       # plain 512-channel convolutions on the hand-placed implicit-GEMM tile
 GN_STATS_ONE_LAUNCH = _tune("MARIGOLD_GN_STATS_ONE_LAUNCH", True)   # the two sources of a skip concat in one statistics launch
 HEAD_CONV = _tune("MARIGOLD_HEAD_CONV", True)   # conv_norm_out + SiLU + conv_out (<= 4 channels) as one MG_OP_CONV3X3_HEAD launch
+HEAD_CONV_MIN_PIXELS = _tune("MARIGOLD_HEAD_CONV_MIN_PIXELS", 1 << 18)
 FOLD_SHORTCUT = _tune("MARIGOLD_FOLD_SHORTCUT", True)   # conv_shortcut as extra K of conv2 where conv2 runs on the implicit GEMM
 GN_SLAB = _tune("MARIGOLD_GN_SLAB", True)               # GroupNorm as one launch per norm (MG_OP_GN_SLAB) where it applies
 GN_SLAB_MIN_WG = _tune("MARIGOLD_GN_SLAB_MIN_WG", 64)   # ... from this many (image, channel window) workgroups,
@@ -551,8 +552,11 @@ class Builder:
         return out
 
     def head_conv_ok(self, x, cout):
-        """norm + SiLU + conv3x3 to <= 4 channels as one MG_OP_CONV3X3_HEAD launch?"""
-        return HEAD_CONV and cout <= 4 and x.C % 32 == 0
+        """norm + SiLU + conv3x3 to <= 4 channels as one MG_OP_CONV3X3_HEAD launch?  The VAE decoder's head (768^2 maps: 0.80 ms
+        against 0.58 + 1.22 ms for the normalising pass + the implicit GEMM at ten members); NOT the UNet's - its 96^2 maps are
+        360 workgroups of ten LDS-bound passes (79-102 us at ten members, 64-101 at one) where the pass + GEMM pair takes 54 / 33 us
+        (profiles/r5_ops_hipevents*.tsv of the two final sessions)."""
+        return HEAD_CONV and cout <= 4 and x.C % 32 == 0 and x.B * x.H * x.W >= HEAD_CONV_MIN_PIXELS
 
     def norm_conv_to_nchw(self, x, norm, eps, key, w4, bias, out, cout, **kw):
         """conv_norm_out -> SiLU -> conv_out -> the pointwise tail (diffusers' output heads of the UNet and the VAE decoder)."""
