@@ -331,12 +331,27 @@ def test_full_size_programs_validate_without_gpu():
     # SURVEY: 2137.7 GF with the full cross-attention; the 2-token collapse removes ~51 GF and the sub-pixel form of
     # the three up-sampling convolutions (4/9 of their MACs) another 84.9 GF: 2001.5 GF executed per member and forward
     assert abs(per_fwd - 2001.5) < 3, per_fwd
+    # the launch forms of round 5, as the engine routes them at full size
+    from marigold_amd import _lib as L
+    labelled = list(zip(prog.seq.ops, prog.seq.labels))
+    fwd = labelled[prog.n_prologue_ops:prog.n_prologue_ops + prog.n_fwd_ops]
+    folded = [op for op, lab in fwd if lab.endswith("conv2+conv_shortcut")]   # conv_shortcut as extra K of conv2 (implicit GEMM levels)
+    assert len(folded) == 11 and all(op.kind == L.OP_IGEMM and op.p[12] and op.i[32] % 64 == 0 and op.i[7] == 9 for op in folded)
+    assert sum(bool(op.p[13]) for op in folded) == 9          # the up blocks' [hidden | skip] pairs, never concatenated
+    assert [lab for _, lab in fwd if lab.endswith(".conv_shortcut")] == [f"up_blocks.3.resnets.{j}.conv_shortcut" for j in range(3)]
+    assert any(op.kind == L.OP_GN_STATS and op.p[6] and op.i[9] > 0 for op, _ in fwd)      # a skip concat's statistics: one launch
+    assert not any(lab.endswith((".stats0", ".stats1")) for _, lab in fwd)
+    assert [lab for _, lab in labelled[:prog.n_prologue_ops]].count("resnets.time_emb_proj") == 1
+    # the UNet's 96^2 head stays on the pass + GEMM pair, the decoder's 768^2 head is one MG_OP_CONV3X3_HEAD launch
+    assert [lab for _, lab in fwd if "conv_out" in lab or "conv_norm_out" in lab] == ["conv_norm_out.stats", "conv_norm_out.apply", "conv_out", "conv_out.post+scheduler.step"]
     vae = AutoencoderKLHIP(vsd, vcfg).dry()
     seq, _, _ = vae._program("encode", 1, 768, 768)
     seq.validate()
     assert abs(opstats.program_flops(seq.ops) / 1e9 - 2609.1) < 5
     seq, _, _ = vae._program("decode", 2, 96, 96, 1)
     seq.validate()
+    heads = [op for op in seq.ops if op.kind == L.OP_CONV3X3_HEAD]
+    assert len(heads) == 1 and (heads[0].i[1], heads[0].i[2], heads[0].i[3], heads[0].i[4]) == (768, 768, 128, 3) and heads[0].p[1]
     # 5754.3 GF as published; the three up-sampling convolutions in sub-pixel form execute 869.8 GF less
     assert abs(opstats.program_flops(seq.ops) / 2 / 1e9 - 4884.5) < 5
     # the IID family at full size (appearance: 2 modalities -> 12 in / 8 out latent channels; lighting: 3 -> 16 / 12):
