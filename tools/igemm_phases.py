@@ -5,7 +5,6 @@ addressed, first K tile landed, K loop done, outputs stored, exit (csrc/igemm2_b
 hand-placed tiles, variants 72 / 73 - the compiled tiles were stamped the same way for profiles/r5_igemm_phase_stamps.log).  Prints, per case, the launch's
 wall time by HIP events and the distribution over workgroups of each phase and of the start / end times relative to the first
 workgroup's entry."""
-import ctypes
 import math
 import os
 import sys

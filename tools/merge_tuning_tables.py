@@ -10,7 +10,7 @@ import sys, json, csv, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
 sys.path.insert(0, ROOT)
-import torch, marigold_amd as M
+import marigold_amd as M
 from marigold_amd import _lib as L, tuning
 from marigold_amd.schedulers import DDIMScheduler
 A = json.load(open('_ab/gfx950_A.json')); B = json.load(open('_ab/gfx950_B.json'))
@@ -49,7 +49,7 @@ for E in (1, 2, 3, 5):
 c = dict(a)
 took = kept = unseen = 0
 gain = 0.0
-for k in changed:
+for k in sorted(changed):
     if k not in votes:
         unseen += 1      # a shape of another ensemble size (not in these programs): keep A's choice
         continue
