@@ -184,7 +184,8 @@ enum mg_op_kind {
    *  mg_conv3x3_gn_slots(op), HW = H W or 4 H W): the next GroupNorm's statistics without a pass over the tensor. */
   MG_OP_CONV3X3 = 17,
   /* The output heads: GroupNorm apply [+ SiLU] + conv3x3 (pad 1) to <= 4 channels in one launch (conv_norm_out -> conv_act ->
-   * conv_out of the UNet and of the VAE decoder; csrc/head_conv.hip: the raw input patch of a pixel tile is normalised on its
+   * conv_out of the UNet and of the VAE decoder - the tail of the modules the reference calls at marigold_depth_pipeline.py:461-463
+   * and :498-516; csrc/head_conv.hip: the raw input patch of a pixel tile is normalised on its
    * way into LDS, the taps are packed bf16 dot products - no MFMA work at <= 4 output channels, one HBM read of the input).
    *  p[0] x bf16 [B][H][W][C]  p[1] scale_shift f32 [B][2][C] | NULL  p[2] Wt bf16 [>= Cout][9 C], k = (ky*3+kx)*C + c
    *  p[3] bias f32 | NULL  p[4] out f32 [B H W][ldo] (columns [0, Cout): what MG_OP_POST_NCHW reads)
