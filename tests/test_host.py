@@ -694,6 +694,37 @@ def test_tuning_table_is_well_formed_and_applied():
     assert tuning.key_of(opf) == fkey and (tuning.apply(opf).i[19], opf.i[31]) == (fv, fs)
 
 
+def test_folded_shortcut_and_stacked_time_projection_weights():
+    """Host arithmetic of two weight layouts of round 5 (engine.WeightStore), against torch on the CPU: (a) ``conv3x3_fold`` - rows
+    [9 Cin | Cx] and the summed bias reproduce conv2(h) + conv_shortcut(x) (diffusers ResnetBlock2D's output sum) as ONE GEMM over
+    [im2col(h) | x]; (b) ``time_emb_proj_all`` - the ResNet blocks' projections stacked along N give each block's own Linear."""
+    import torch.nn.functional as F
+    from marigold_amd import engine as E
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cx, Cout = 2, 6, 5, 64, 128, 64
+    sd = {"r.conv2.weight": torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05, "r.conv2.bias": torch.randn(Cout, generator=g),
+          "r.conv_shortcut.weight": torch.randn(Cout, Cx, 1, 1, generator=g) * 0.05, "r.conv_shortcut.bias": torch.randn(Cout, generator=g),
+          "a.time_emb_proj.weight": torch.randn(64, 32, generator=g), "a.time_emb_proj.bias": torch.randn(64, generator=g),
+          "b.time_emb_proj.weight": torch.randn(128, 32, generator=g), "b.time_emb_proj.bias": torch.randn(128, generator=g)}
+    ws = E.WeightStore(sd, torch.device("cpu"))
+    wf, bf = ws.conv3x3_fold("r.conv2", "r.conv_shortcut")
+    assert wf.dtype == torch.bfloat16 and tuple(wf.shape) == (Cout, 9 * Cin + Cx) and bf.dtype == torch.float32
+    h = torch.randn(B, Cin, H, W, generator=g)
+    x = torch.randn(B, Cx, H, W, generator=g)
+    # im2col in the kernel's K order: k = (ky * 3 + kx) * Cin + c, then the shortcut's channels at the centre pixel
+    cols = F.unfold(h, 3, padding=1).reshape(B, Cin, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * Cin)
+    a = torch.cat([cols, x.permute(0, 2, 3, 1).reshape(B * H * W, Cx)], dim=1)
+    got = (a @ wf.float().t() + bf).reshape(B, H, W, Cout).permute(0, 3, 1, 2)
+    wq = lambda k: sd[k].to(torch.bfloat16).float()
+    ref = F.conv2d(h, wq("r.conv2.weight"), sd["r.conv2.bias"], padding=1) + F.conv2d(x, wq("r.conv_shortcut.weight"), sd["r.conv_shortcut.bias"])
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    wall, ball = ws.time_emb_proj_all(["a", "b"])
+    e = torch.randn(3, 32, generator=g)
+    out = F.silu(e) @ wall.t() + ball
+    torch.testing.assert_close(out[:, :64], F.linear(F.silu(e), sd["a.time_emb_proj.weight"], sd["a.time_emb_proj.bias"]))
+    torch.testing.assert_close(out[:, 64:], F.linear(F.silu(e), sd["b.time_emb_proj.weight"], sd["b.time_emb_proj.bias"]))
+
+
 def test_model_image_round_trip_without_gpu(tmp_path):
     """SURVEY section 8(b)'s module-level C entry points: ``export_model_image`` compiles the three native programs of a fixed
     shape (VAE encode, the whole T-step denoising loop, VAE decode) + their kernel-ready weights + a memory plan into one file;
