@@ -725,6 +725,26 @@ def test_folded_shortcut_and_stacked_time_projection_weights():
     torch.testing.assert_close(out[:, 64:], F.linear(F.silu(e), sd["b.time_emb_proj.weight"], sd["b.time_emb_proj.bias"]))
 
 
+def test_opstats_of_the_round5_launch_forms():
+    """The algorithmic FLOPs / bytes bench.py's roofline uses (marigold_amd/opstats.py) for the launch forms added in round 5: a
+    folded launch = the 3x3 convolution + the 1x1 convolution it carries (its input and weights read once, no residual round
+    trip); the output head = one read of the input; a two-source statistics launch = both sources' bytes."""
+    from marigold_amd import _lib as L, ops as O, opstats
+    a = torch.zeros(1)
+    B, HW, Cin, Cx, N = 2, 24, 128, 192, 256
+    kw = dict(B=B, H=HW, W=HW, Cin=Cin, Ho=HW, Wo=HW, N=N, taps=9, stride=1, pad=1, bias=a)
+    M = B * HW * HW
+    c0, f0, b0 = opstats.op_cost(O.igemm(a, a, a, **kw))
+    c1, f1, b1 = opstats.op_cost(O.igemm(a, a, a, fold=(a, a, 128, Cx), **kw))
+    assert c0 == c1 == "igemm_mfma" and f0 == 2 * M * N * 9 * Cin
+    assert f1 - f0 == 2 * M * N * Cx and b1 - b0 == (M + N) * Cx * 2
+    ch, fh, bh = opstats.op_cost(O.conv3x3_head(a, a, a, a, a, B=B, H=HW, W=HW, C=Cin, Cout=3, ldo=8))
+    assert ch == "boundary_conv" and fh == 2 * M * 3 * 9 * Cin and bh == M * (Cin * 2 + 3 * 4)
+    _, _, bs1 = opstats.op_cost(O.gn_stats(a, a, B=B, HW=HW * HW, C=Cin, chunks=4, groups=32))
+    _, _, bs2 = opstats.op_cost(O.gn_stats(a, a, B=B, HW=HW * HW, C=Cin, chunks=4, groups=32, Ctot=Cin + Cx, x1=a, C1=Cx))
+    assert bs1 == M * Cin * 2 and bs2 == M * (Cin + Cx) * 2
+
+
 def test_model_image_round_trip_without_gpu(tmp_path):
     """SURVEY section 8(b)'s module-level C entry points: ``export_model_image`` compiles the three native programs of a fixed
     shape (VAE encode, the whole T-step denoising loop, VAE decode) + their kernel-ready weights + a memory plan into one file;
