@@ -1,24 +1,21 @@
 #!/bin/bash
-# Same-box A/B of one tuning switch (engine._tune / csrc mg_tuning_int names; honoured under MARIGOLD_TUNING=1 only):
-#   gpurun -- 'ENS="10 1 5" KTESTS="fold or igemm_conv3x3" bash scripts/gpu_ab_env.sh MARIGOLD_FOLD_SHORTCUT 0 1'
-# runs the kernel tests selected by KTESTS (optional), then bench.py at every ensemble size of ENS with the switch at each given
-# value, two interleaved rounds; one line per run in gpurun_out/ab_env_$VAR.log (how profiles/r5_conv_shortcut_fold_ab.log and
-# r5_gn_stats_one_launch_ab.log were made).
-export PYTHONUNBUFFERED=1
+# Same-box A/B of engine / library tuning switches: scripts/gpu_ab_env.sh "<name>" "<ENV=.. for A>" "<ENV=.. for B>" [bench args]
+# Interleaved twice; prints ms per map and the per-class kernel times of each run.  MARIGOLD_TUNING=1 is set for both sides.
+export PYTHONUNBUFFERED=1 MARIGOLD_TUNING=1
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-VAR=$1; shift
-: > gpurun_out/ab_env_$VAR.log
-if [ -n "$KTESTS" ]; then
-  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout=300 --timeout-method=thread -k "$KTESTS" 2>&1 | tail -5 >> gpurun_out/ab_env_$VAR.log
-fi
-for e in ${ENS:-10 1}; do for round in 1 2; do for v in "$@"; do
-  env MARIGOLD_TUNING=1 $VAR=$v timeout 400 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --ensemble $e 2>/dev/null | python -c "
+NAME=$1; A=$2; B=$3; shift 3
+LOG=gpurun_out/ab_$NAME.log
+: > $LOG
+for round in 1 2; do
+  for side in A B; do
+    if [ $side == A ]; then E="$A"; else E="$B"; fi
+    env $E timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --dump-ops gpurun_out/ops_${NAME}_$side.tsv "$@" 2>gpurun_out/ab_${NAME}_err_$side.log | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
-        j=json.loads(l); k=j['kernels']
-        print('E=$e $VAR=$v', 'ms', j['ms_per_step'], ' '.join(f\"{n}={x['ms']:.2f}/{x['launches']}\" for n,x in k.items() if x['ms']>1.5), {a: round(b['ms'],1) for a,b in j['stages'].items()})
-" >> gpurun_out/ab_env_$VAR.log
-done; done; done
-cat gpurun_out/ab_env_$VAR.log
+        j=json.loads(l); print('$side [$E] round=$round ms_per_map', j['ms_per_step'], {k: round(v['ms'],2) for k,v in j.get('stages',{}).items()}, 'launches', sum(v['launches'] for v in j['kernels'].values()), {k: (round(v['ms'],2), v['launches']) for k,v in j['kernels'].items() if v['ms'] > 1.0}, 'gemm', (j.get('calibration') or {}).get('gemm4096_bf16_tflops'))
+" >> $LOG
+  done
+done
+cat $LOG; tail -3 gpurun_out/ab_${NAME}_err_B.log
