@@ -109,7 +109,12 @@ enum mg_op_kind {
    *  columns, i[11] = 2 x heads of them live, f[1] softmax scale; p[1] = weights.pack_rowgemm_xattn (scores stage + VO^T
    *  fragments + bias), p[4] required, out[M][K] = P VO^T + bias + x, p[5] its row statistics; out may alias x.  K = 640 /
    *  1280 (the deeper levels): the K-split kernel - 32-row workgroups whose four waves split K and the output channels,
-   *  p[1] = weights.pack_rowgemm_xattn_ksplit.  p[8] (tuning only): per-wave phase cycle stamps | NULL. */
+   *  p[1] = weights.pack_rowgemm_xattn_ksplit.  p[8] (tuning only): per-wave phase cycle stamps | NULL.
+   *  form 1 with p[9] (round 6; K = 320, no column split): the collapsed cross-attention as the PROLOGUE of the GEGLU launch
+   *  (BasicTransformerBlock: x += attn2(norm2(x)); ff(norm3(x))) - p[9] = a weights.pack_rowgemm_xattn image, p[4] = (mean, rstd) of
+   *  the rows AS LOADED (norm2's), i[11] = 2 x heads, f[1] softmax scale; the rows are updated in registers, written once to
+   *  p[10] bf16 [M][ldx] (may alias x: ff.out's residual) and the GEGLU projection's folded LayerNorm (norm3, f[0] eps) takes its
+   *  statistics from the wave's own sums.  Bit-identical to the form-3 launch followed by the plain form-1 launch. */
   MG_OP_ROWGEMM = 10,
   /* Self-attention core, head dim 64, bf16 MFMA flash attention with LDS-staged K / V^T
    * tiles (replaces diffusers Attention / SDPA / xformers, run.py:217-220).

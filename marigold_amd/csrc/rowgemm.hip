@@ -53,6 +53,14 @@ struct RgArgs {
   double inv_n;
   int prio;
   int spl;              // stages per workgroup (N / 64 unless the columns are split over gridDim.y)
+  // XA (round 6): the collapsed cross-attention as the PROLOGUE of the GEGLU form - the rows x = h1 are updated in registers
+  // (h2 = P VO^T + bias + h1, stored once to xout for ff.out's residual) and the folded LayerNorm of the GEGLU projection takes its
+  // (mean, rstd) from the wave's own sums: no cross-attention launch, no second read of the residual stream
+  const char* xwp;      // weights.pack_rowgemm_xattn image (scores stage + VO^T fragments + bias) | NULL
+  bf16_t* xout;         // [M][ldx] the updated rows (may alias x)
+  int sm_cols;
+  float sm_scale;
+  double inv_k;
   unsigned long long* dbg;   // tuning only: per-wave phase cycles [wave-tiles][4] (wait+barrier, issue, MFMA, epilogue) | NULL
 };
 
@@ -104,9 +112,10 @@ __device__ __forceinline__ void rg_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int K, int NW, int EPI, bool LN, bool GN, bool RES, bool LNO>
+template <int K, int NW, int EPI, bool LN, bool GN, bool RES, bool LNO, bool XA = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void rowgemm_kernel(const RgArgs a) {
+  static_assert(!XA || (K == 320 && EPI == RG_GEGLU && LN && !GN && !RES && !LNO), "the cross-attention prologue rides on the K = 320 GEGLU form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // a stage = 2 tiles x KS fragments of 1 KB + one 1 KB trailer: fp32 [64] per-channel constants, [64] folded-LayerNorm g
   // K = 640: a SLOT of the ring holds ONE 32-channel tile (40 fragments) and a 64-channel stage is two consecutive slots
@@ -146,7 +155,7 @@ void rowgemm_kernel(const RgArgs a) {
   };
   const int h0 = j0 * SPS, hend = nst * SPS;   // this workgroup's slots
   issue(h0, 0);
-  if (h0 + 1 < hend) issue(h0 + 1, 1);
+  if constexpr (!XA) { if (h0 + 1 < hend) issue(h0 + 1, 1); }
 
   // the wave's 32 rows of x: K step s -> x[m][16 s + 8 half .. + 8] (the MFMA's own K order)
   bf16x8 xf[KS];
@@ -175,6 +184,119 @@ void rowgemm_kernel(const RgArgs a) {
     const float2 st = a.ln_in[m];
     l_sc = st.y;
     l_mr = -st.y * st.x;
+  }
+  if constexpr (XA) {
+    // ---- the collapsed cross-attention on the rows in registers (rowgemm_xattn_kernel's arithmetic, operation for operation:
+    // the results are bit-identical to the separate launch).  Its two weight images sit behind ring slot 0, which already
+    // receives the first GEGLU stage; slots 1 and 2 are primed once every wave has left the images.
+    constexpr int NSUB = K / 64, P0 = 2 * KS + 1, P1 = NSUB * 8 + 2, S0 = P0 * 1024, XOFF = STAGE;
+    auto issue_img = [&](auto pieces_tag, int src_off, int dst_off) {
+      constexpr int P = decltype(pieces_tag)::value;
+      const char* src = a.xwp + src_off + lane * 16;
+      char* dst = smem + XOFF + dst_off;
+#pragma unroll
+      for (int i = 0; i < P / NW; ++i) glds16(src + (wave + i * NW) * 1024, dst + (wave + i * NW) * 1024);
+      if (wave < P % NW) glds16(src + (wave + (P / NW) * NW) * 1024, dst + (wave + (P / NW) * NW) * 1024);
+    };
+    issue_img(std::integral_constant<int, P0>{}, 0, 0);
+    issue_img(std::integral_constant<int, P1>{}, S0, S0);
+    rg_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (active) {
+      const char* const sb = smem + XOFF + lane * 16;
+      const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem + (uint32_t)XOFF;
+      bf16x8 pf[4];
+      {
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const bf16x8 w0 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + s * 1024));
+          const bf16x8 w1 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + (KS + s) * 1024));
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int c = t * 32 + q * 16 + 8 * half;   // this lane's 8 score columns: 4 (key 0, key 1) pairs
+            const uint32_t cbp = lds0 + (uint32_t)(2 * KS * 1024 + c * 4);
+            f32x4 c0 = rg_lds16<0>(cbp), c1 = rg_lds16<16>(cbp), g0 = rg_lds16<256>(cbp), g1 = rg_lds16<272>(cbp);
+            rg_lgk0(c0, c1, g0, g1);
+            const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            uint32_t w4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float a0 = t == 0 ? acc0[8 * q + 2 * k] : acc1[8 * q + 2 * k], a1 = t == 0 ? acc0[8 * q + 2 * k + 1] : acc1[8 * q + 2 * k + 1];
+              const float s0 = __builtin_fmaf(a0, l_sc, __builtin_fmaf(l_mr, gg[2 * k], cc[2 * k])) * a.sm_scale;
+              const float s1 = __builtin_fmaf(a1, l_sc, __builtin_fmaf(l_mr, gg[2 * k + 1], cc[2 * k + 1])) * a.sm_scale;
+              const float mx = fmaxf(s0, s1);
+              const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx);
+              const float inv = 1.0f / (e0 + e1);
+              w4[k] = (c + 2 * k < a.sm_cols) ? pack2bf(e0 * inv, e1 * inv) : 0u;
+            }
+            pf[t * 2 + q] = __builtin_bit_cast(bf16x8, make_uint4(w4[0], w4[1], w4[2], w4[3]));
+          }
+      }
+      bf16_t* const px2 = a.xout + (long long)m * a.ldx + 8 * half;
+      double sd2 = 0.0, qd2 = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < NSUB; ++jj) {
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 w0 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + S0 + ((jj * 2 + 0) * 4 + s) * 1024));
+          const bf16x8 w1 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + S0 + ((jj * 2 + 1) * 4 + s) * 1024));
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, pf[s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pf[s], acc1, 0, 0, 0);
+        }
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int c = jj * 64 + t * 32 + q * 16;
+            const uint32_t bp = lds0 + (uint32_t)(S0 + NSUB * 8 * 1024 + (c + 8 * half) * 4);
+            f32x4 b0 = rg_lds16<0>(bp), b1 = rg_lds16<16>(bp);
+            rg_lgk0(b0, b1);
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const uint4 r4 = __builtin_bit_cast(uint4, xf[jj * 4 + t * 2 + q]);   // the row's own channels c + 8 half .. + 8
+            const float rr[8] = {bflo(r4.x), bfhi(r4.x), bflo(r4.y), bfhi(r4.y), bflo(r4.z), bfhi(r4.z), bflo(r4.w), bfhi(r4.w)};
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              v[i] = (t == 0 ? acc0[8 * q + i] : acc1[8 * q + i]) + bb[i] + rr[i];
+              ps += v[i];
+              pq = __builtin_fmaf(v[i], v[i], pq);
+            }
+            uint4 pk;
+            pk.x = cvt_pk_bf16_f32(v[0], v[1]); pk.y = cvt_pk_bf16_f32(v[2], v[3]);
+            pk.z = cvt_pk_bf16_f32(v[4], v[5]); pk.w = cvt_pk_bf16_f32(v[6], v[7]);
+            *(uint4*)(px2 + c) = pk;
+            xf[jj * 4 + t * 2 + q] = __builtin_bit_cast(bf16x8, pk);   // ... and K steps 4 jj + 2 t + q of the GEGLU projection
+          }
+        asm volatile("" : "+v"(ps), "+v"(pq));
+        sd2 += (double)ps;
+        qd2 += (double)pq;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // (mean, rstd) of the new rows exactly as the separate launch stores and the GEGLU form reloads them
+      sd2 += __shfl_xor(sd2, 32);
+      qd2 += __shfl_xor(qd2, 32);
+      const double mean = sd2 * a.inv_k;
+      const float var = fmaxf((float)__builtin_fma(qd2, a.inv_k, -mean * mean), 0.f);
+      const float mean_f = (float)mean, rstd = __builtin_amdgcn_rsqf(var + a.ln_eps);
+      l_sc = rstd;
+      l_mr = -rstd * mean_f;
+    }
+    __builtin_amdgcn_s_barrier();   // every wave has left the images: ring slots 1 and 2 are free
+    if (h0 + 1 < hend) issue(h0 + 1, 1);
   }
   bf16_t* const po = a.out + (long long)m * a.ldo + 8 * half;
   const bf16_t* const pr = RES ? a.res + (long long)m * a.ldr + 8 * half : nullptr;
@@ -691,11 +813,14 @@ int rg_launch_xattn_ksplit(const RgXkArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int K, int NW, int EPI, bool LN, bool GN, bool RES, bool LNO>
+template <int K, int NW, int EPI, bool LN, bool GN, bool RES, bool LNO, bool XA = false>
 int rg_launch(const RgArgs& a, hipStream_t s) {
-  constexpr int LDS = 3 * ((K <= 320 ? 2 : 1) * (K / 16) + 1) * 1024;
+  constexpr int RING = 3 * ((K <= 320 ? 2 : 1) * (K / 16) + 1) * 1024;
+  // XA: the cross-attention images (scores stage + VO^T fragments + bias) sit behind ring slot 0
+  constexpr int LDS = XA ? (RING / 3 + (2 * (K / 16) + 1 + (K / 64) * 8 + 2) * 1024 > RING ? RING / 3 + (2 * (K / 16) + 1 + (K / 64) * 8 + 2) * 1024 : RING) : RING;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = rowgemm_kernel<K, NW, EPI, LN, GN, RES, LNO>;
+  auto kern = rowgemm_kernel<K, NW, EPI, LN, GN, RES, LNO, XA>;
   if (!attr_set && !g_dry_run) {
     MG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -710,6 +835,12 @@ int rg_dispatch(const RgArgs& a, int epi, hipStream_t s) {
   const bool ln = a.ln_in != nullptr, gn = a.gn_ss != nullptr, res = a.res != nullptr, lno = a.ln_out != nullptr;
   if (epi == RG_GEGLU) {
     MG_REQUIRE(!gn && !res && !lno, "rowgemm: the GEGLU form takes no GroupNorm input / residual / row statistics");
+    if (a.xwp) {
+      if constexpr (K == 320) {
+        MG_REQUIRE(ln, "rowgemm: the cross-attention prologue needs the (mean, rstd) table of its input rows");
+        return rg_launch<K, NW, RG_GEGLU, true, false, false, false, true>(a, s);
+      } else MG_REQUIRE(false, "rowgemm: the cross-attention prologue is instantiated for K = 320");
+    }
     return ln ? rg_launch<K, NW, RG_GEGLU, true, false, false, false>(a, s) : rg_launch<K, NW, RG_GEGLU, false, false, false, false>(a, s);
   }
   if (epi == RG_QKV) {
@@ -751,6 +882,11 @@ int mg_launch_rowgemm(const mg_op* op, hipStream_t s) {
   a.vt = (bf16_t*)op->p[6];
   a.gn_ss = (const float*)op->p[7];
   a.dbg = (unsigned long long*)op->p[8];
+  a.xwp = epi == RG_GEGLU ? (const char*)op->p[9] : nullptr;
+  a.xout = (bf16_t*)op->p[10];
+  a.sm_cols = op->i[11];
+  a.sm_scale = op->f[1];
+  a.inv_k = 1.0 / (double)K;
   a.inv_n = 1.0 / (double)(a.N > 0 ? a.N : 1);
   a.trans_stage = epi == RG_QKV ? trans_from / 64 : (1 << 30);
   a.prio = 1;
@@ -761,6 +897,12 @@ int mg_launch_rowgemm(const mg_op* op, hipStream_t s) {
     MG_REQUIRE(nsplit == 1 || !a.ln_out, "rowgemm: row statistics need whole rows in one workgroup (no column split)");
   }
   MG_REQUIRE(epi >= RG_BF16 && epi <= RG_XATTN, "rowgemm: unknown form %d", epi);
+  if (a.xwp) {
+    MG_REQUIRE(K == 320 && a.xout && a.ln_in && (op->i[12] <= 1) && a.sm_cols > 0 && a.sm_cols % 2 == 0 && a.sm_cols <= 64 &&
+               (uintptr_t)a.xwp % 16 == 0 && (uintptr_t)a.xout % 16 == 0,
+               "rowgemm: the cross-attention prologue (p[9]) rides on the unsplit K = 320 GEGLU form; p[10] = the updated rows, p[4] = the (mean, rstd) "
+               "table of the rows as loaded, i[11] = 2 x heads score columns");
+  }
   if (epi == RG_XATTN && (K == 640 || K == 1280)) {
     RgXkArgs x;
     x.x = a.x; x.wp = a.wp; x.out = a.out; x.ln_in = a.ln_in; x.ln_out = a.ln_out;

@@ -52,6 +52,7 @@ GN_SLAB_SMALL_KB = _tune("MARIGOLD_GN_SLAB_SMALL_KB", 48)   # or fewer when a wo
 ROWGEMM = _tune("MARIGOLD_ROWGEMM", True)               # row-resident GEMM (MG_OP_ROWGEMM) for the K = 320 token-local layers
 XATTN_KSPLIT = _tune("MARIGOLD_XATTN_KSPLIT", True)     # deep-level collapsed cross-attention as the K-split kernel
 ROWGEMM_WIDE = _tune("MARIGOLD_ROWGEMM_WIDE", True)     # ... and its K = 640 form for the 640-channel level's QKV / GEGLU
+XATTN_IN_GEGLU = _tune("MARIGOLD_XATTN_IN_GEGLU", True)   # the collapsed cross-attention as the prologue of the row-resident GEGLU launch
 ROWGEMM_MIN_M = _tune("MARIGOLD_ROWGEMM_MIN_M", 9216)   # below: the tile GEMM (one 96 x 96 member is 72 128-row workgroups)
 
 
@@ -748,11 +749,20 @@ class Builder:
             self.free(g)
         b = f"{name}.transformer_blocks.0"
         self.self_attention(h, st[0], f"{b}.attn1", f"{b}.norm1", heads, st[1])
-        self.cross_attention2(h, st[1], f"{b}.attn2", f"{b}.norm2", heads, ctx, st[2])
-        if rg or self.rowgemm_wide_ok(h):
+        # (round 6) at the 320-channel level the collapsed cross-attention is the PROLOGUE of the GEGLU launch: that launch holds the
+        # rows in registers anyway - it updates them (and stores them once, for ff.out's residual), takes the next LayerNorm's
+        # statistics from its own sums and goes on; no cross-attention launch, one read of the residual stream less
+        gcfg = self.rowgemm_cfg(h.M, 8 * C, K=C) if (rg or self.rowgemm_wide_ok(h)) else None
+        fuse_x = rg and XATTN_IN_GEGLU and 2 * heads <= 64 and gcfg.get("nsplit", 1) <= 1
+        if not fuse_x:
+            self.cross_attention2(h, st[1], f"{b}.attn2", f"{b}.norm2", heads, ctx, st[2])
+        if gcfg is not None:
             ff = self.new(h.B, h.H, h.W, 4 * C)
+            xkw = dict(xattn=self.ws.rg_cross_ln(f"{b}.attn2", ctx, heads, f"{b}.norm2"), xout=h.t, sm_cols=2 * heads,
+                       sm_scale=1.0 / math.sqrt(C // heads)) if fuse_x else {}
             self.add(O.rowgemm(h.t, self.ws.rg_geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3"), ff.t, M=h.M, K=C, N=8 * C,
-                               form=L.RG_GEGLU, ln_in=self.ln_mean_rstd(st[2], h.M, C), **self.rowgemm_cfg(h.M, 8 * C, K=C)), f"{b}.ff.geglu")
+                               form=L.RG_GEGLU, ln_in=self.ln_mean_rstd(st[1] if fuse_x else st[2], h.M, C), **gcfg, **xkw),
+                     f"{b}.attn2+ff.geglu" if fuse_x else f"{b}.ff.geglu")
         else:
             wg, gg, cg = self.ws.geglu_ln(f"{b}.ff.net.0.proj", f"{b}.norm3")
             ff = self.dense(h, wg, None, 8 * C, epi=L.EPI_GEGLU, label=f"{b}.ff.geglu",

@@ -78,10 +78,13 @@ def conv3x3_gn_slots(op):
 
 
 def rowgemm(x, wp, out, *, M, K, N, form=L.RG_BF16, ldx=0, ldo=0, ldr=0, residual=None, ln_in=None, ln_out=None, vt=None,
-            gn_ss=None, tokens=0, ldt=0, trans_from=0, waves=0, ln_eps=1e-5, sm_cols=0, sm_scale=0.0, dbg=None, nsplit=0):
-    """Row-resident GEMM (MG_OP_ROWGEMM): ``wp`` from weights.pack_rowgemm (form RG_XATTN: pack_rowgemm_xattn)."""
+            gn_ss=None, tokens=0, ldt=0, trans_from=0, waves=0, ln_eps=1e-5, sm_cols=0, sm_scale=0.0, dbg=None, nsplit=0,
+            xattn=None, xout=None):
+    """Row-resident GEMM (MG_OP_ROWGEMM): ``wp`` from weights.pack_rowgemm (form RG_XATTN: pack_rowgemm_xattn).  ``xattn`` (GEGLU
+    form, K = 320, no column split): a pack_rowgemm_xattn image - the collapsed cross-attention runs on the rows in registers before
+    the projection (``ln_in`` = the statistics of the rows as loaded, ``xout`` = where the updated rows go, ``sm_cols`` / ``sm_scale``)."""
     return make_op(L.OP_ROWGEMM, i=[M, K, N, ldx, ldo, ldr, form, tokens, ldt, trans_from, waves, sm_cols, nsplit], f=[ln_eps, sm_scale],
-                   p=[x, wp, out, residual, ln_in, ln_out, vt, gn_ss, dbg])
+                   p=[x, wp, out, residual, ln_in, ln_out, vt, gn_ss, dbg, xattn, xout if xattn is not None else None])
 
 
 def linear(x, w, out, *, M, K, N, **kw):

@@ -51,6 +51,9 @@ def op_cost(op):
         if form == L.RG_XATTN:   # + P [M][64] x VO^T [K][64]; x read once, out [M][K] written once
             flops += 2 * M * K * N
             byts = 2 * M * K * 2 + 2 * N * K * 2
+        if form == L.RG_GEGLU and op.p[9]:   # the cross-attention prologue: scores + blend GEMMs, the updated rows written once
+            flops += 2 * 2 * M * K * 64
+            byts += M * K * 2 + 2 * 64 * K * 2
     elif k == L.OP_CONV3X3:
         B, H, W, C0, C1, N, subpix = (i[j] for j in range(7))
         Cin, par, T = C0 + C1, (4 if subpix else 1), (4 if subpix else 9)

@@ -806,6 +806,68 @@ def test_rowgemm_fused_cross_attention(dev, C, heads, waves):
     _close(f"rowgemm/xattn/stats/C{C}/{waves}w", so, torch.stack([ref.mean(-1), 1.0 / torch.sqrt(ref.var(-1, unbiased=False) + 1e-5)], -1), tol=2e-3)
 
 
+@pytest.mark.parametrize("waves", [12, 8, 4])
+def test_rowgemm_cross_attention_as_geglu_prologue(dev, waves):
+    """(round 6) MG_OP_ROWGEMM form RG_GEGLU with p[9]: the collapsed cross-attention runs on the rows in registers BEFORE the GEGLU
+    projection - against the two launches it replaces (form RG_XATTN in place, then form RG_GEGLU on its rows and statistics) bit
+    for bit (updated rows and hidden activations), against the unfused fp32 chain, and bit-stable over repeat launches.  M is not
+    a multiple of the workgroup's rows: surplus waves keep the barriers and move weights only."""
+    from marigold_amd import _lib as L, ops, weights as Wm
+    C, heads = 320, 5
+    g = torch.Generator().manual_seed(53 + waves)
+    M = 2112
+    x = _bf(torch.randn(M, C, generator=g) * 0.9 + 0.3 * torch.randn(M, 1, generator=g))
+    g2, b2 = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    g3, b3 = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    ctx = torch.randn(2, 1024, generator=g)
+    wq, wo = torch.randn(C, C, generator=g) / math.sqrt(C), torch.randn(C, C, generator=g) / math.sqrt(C)
+    wk, wv = torch.randn(C, 1024, generator=g) / 32, torch.randn(C, 1024, generator=g) / 32
+    bo = 0.1 * torch.randn(C, generator=g)
+    wg, bg = torch.randn(8 * C, C, generator=g) / math.sqrt(C), 0.1 * torch.randn(8 * C, generator=g)
+    # fp32 reference: x2 = x + attn2(LN2(x)); hidden = GEGLU(LN3(x2))
+    y = F.layer_norm(x, (C,), g2, b2, 1e-5)
+    q = (y @ wq.t()).view(M, heads, C // heads)
+    k = (ctx @ wk.t()).view(2, heads, C // heads)
+    v = (ctx @ wv.t()).view(2, heads, C // heads)
+    p = torch.softmax(torch.einsum("mhd,jhd->mhj", q, k) / math.sqrt(C // heads), dim=-1)
+    x2 = torch.einsum("mhj,jhd->mhd", p, v).reshape(M, C) @ wo.t() + bo + x
+    u, gt = (F.layer_norm(x2, (C,), g3, b3, 1e-5) @ wg.t() + bg).chunk(2, dim=-1)
+    ref_hid = u * F.gelu(gt)
+    wqk, vot, npad = Wm.cross_attention_tables(wq, wk, wv, wo, ctx, heads)
+    wpx, lgx, lcx = Wm.fold_layernorm(wqk, None, g2, b2)
+    pkx = Wm.pack_rowgemm_xattn(wpx.float(), lcx, lgx, vot, bo).to(dev)
+    order = Wm.rowgemm_geglu_order(8 * C)
+    wpg, lgg, lcg = Wm.fold_layernorm(wg[order], bg[order], g3, b3)
+    pkg = Wm.pack_rowgemm(wpg.float(), lcg, lgg).to(dev)
+    stx = torch.stack([x.mean(-1), 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5)], dim=-1).to(dev).contiguous()
+    nan_bf = lambda *sh: torch.full(sh, float("nan"), device=dev, dtype=torch.bfloat16)
+    kw = dict(sm_cols=2 * heads, sm_scale=1.0 / math.sqrt(C // heads))
+    # the two launches
+    h_a, so = x.to(dev, torch.bfloat16).clone(), torch.full((M, 2), float("nan"), device=dev)
+    _run(ops.rowgemm(h_a, pkx, h_a, M=M, K=C, N=64, form=L.RG_XATTN, ln_in=stx, ln_out=so, waves=12 if waves == 12 else 8, **kw))
+    hid_a = nan_bf(M, 4 * C)
+    _run(ops.rowgemm(h_a, pkg, hid_a, M=M, K=C, N=8 * C, form=L.RG_GEGLU, ln_in=so, waves=waves))
+    # the one launch, in place on the rows
+    outs = []
+    for rep in range(3):
+        h_b, hid_b = x.to(dev, torch.bfloat16).clone(), nan_bf(M, 4 * C)
+        _run(ops.rowgemm(h_b, pkg, hid_b, M=M, K=C, N=8 * C, form=L.RG_GEGLU, ln_in=stx, waves=waves, xattn=pkx, xout=h_b, **kw))
+        outs.append((h_b, hid_b))
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:]), "repeat launches differ"
+    h_b, hid_b = outs[0]
+    assert torch.equal(h_a, h_b), "updated rows differ from the separate cross-attention launch"
+    assert torch.equal(hid_a, hid_b), "hidden activations differ from the two-launch chain"
+    _close(f"rowgemm/xattn+geglu/rows/{waves}w", h_b, x2)
+    _close(f"rowgemm/xattn+geglu/hidden/{waves}w", hid_b, ref_hid, tol=2e-2)
+    # out of place: the rows stay, the updated ones go to another buffer
+    h_c, hid_c, x_in = nan_bf(M, C), nan_bf(M, 4 * C), x.to(dev, torch.bfloat16).clone()
+    _run(ops.rowgemm(x_in, pkg, hid_c, M=M, K=C, N=8 * C, form=L.RG_GEGLU, ln_in=stx, waves=waves, xattn=pkx, xout=h_c, **kw))
+    assert torch.equal(h_c, h_b) and torch.equal(hid_c, hid_b) and torch.equal(x_in, x.to(dev, torch.bfloat16))
+    # a column split would let one workgroup overwrite rows another still reads: refused
+    with pytest.raises(Exception):
+        _run(ops.rowgemm(h_b, pkg, hid_b, M=M, K=C, N=8 * C, form=L.RG_GEGLU, ln_in=stx, waves=4, nsplit=3, xattn=pkx, xout=h_b, **kw))
+
+
 def test_rowgemm_rejects_shapes_outside_its_contract(dev):
     from marigold_amd import _lib as L, ops, weights as Wm
     x = torch.zeros(64, 320, device=dev, dtype=torch.bfloat16)
