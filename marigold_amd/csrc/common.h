@@ -114,6 +114,24 @@ inline mg_fastdiv mg_make_fastdiv(long long d) {
 }
 __device__ __forceinline__ int fdiv(int x, const mg_fastdiv f) { return (int)(__umulhi((uint32_t)x << 1, f.m) >> f.l); }
 
+// Cross-workgroup hand-offs inside one launch (the row-statistics tickets of igemm2_body.h, GroupNorm's last-block finalize in
+// norm.hip, the key pieces of flash4w.hip).  The product form is the write-through one of cdna_hip_programming.md Guideline 16 /
+// MI355X_MICROARCH.md "valid forms": 16-byte / 8-byte sc1 stores of the payload -> every storing wave drains vmcnt ->
+// __syncthreads -> ONE relaxed agent-scope ticket; the last arriver reads the payload with sc1 loads ("sc1 loads may replace the
+// acquire only when the producer stored sc1").  MG_HANDOFF_FENCES (Makefile: HANDOFF_FENCES=1) adds the C++-memory-model form on
+// top - an agent-scope release fence in front of the ticket, an acquire fence in the last arriver - for same-box A/B runs of what
+// that costs (profiles/r6_ab_handoff_fences.log).
+constexpr bool MG_HANDOFF_FENCES = MG_HANDOFF_FENCES_BUILD != 0;
+__device__ __forceinline__ void mg_handoff_release() {   // lane 0, behind the workgroup barrier that follows the drained stores
+  if constexpr (MG_HANDOFF_FENCES) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (ROCm 7.2 may drop the wait behind buffer_wbl2: restated where it cannot)
+  }
+}
+__device__ __forceinline__ void mg_handoff_acquire() {   // the last arriver's lane 0, in front of the barrier that releases its readers
+  if constexpr (MG_HANDOFF_FENCES) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 #define MG_ZERO_BYTES (128 * 1024)
 extern void* g_zero_page;  // MG_ZERO_BYTES zero bytes in device memory (mg_init): padding source
 // Dry run (mg_program_validate): every launcher checks its op's shape / alignment contract and

@@ -210,8 +210,9 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
     // ---- a piece: leave the partial result, draw a ticket; the block's last piece adds the others to its registers ----
     // Hand-off (cdna_hip_programming.md, the split-K slab recipe in its write-through form): 16-byte sc1 stores -> every wave
     // drains vmcnt -> __syncthreads -> ONE relaxed agent-scope ticket; the last piece reads the slabs with sc1 loads (they
-    // bypass its L1; the stores went through L2).  No release / acquire fence: an agent-scope release writes back the XCD's
-    // whole L2 - with __threadfence() here the split launch ran 1.7 x SLOWER than the unsplit one.
+    // bypass its L1; the stores went through L2) - a valid form per MI355X_MICROARCH.md; mg_handoff_release / _acquire add the
+    // fences in the A/B build (common.h).  With __threadfence() in EVERY wave here the split launch ran 1.7 x SLOWER than the
+    // unsplit one (round 4).
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc((char*)a.ws + F4_CTR_BYTES, 0, 0x7fffffff, 0x00020000);
     const unsigned mine = (unsigned)(((long long)rem * F4_PIECES + part) * F4_PART_BYTES + wave * (16384 + 1024));
@@ -234,9 +235,13 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
     int* flag = (int*)(smem + F4_PRE);
     if (tid == 0) {
       unsigned* ctr = (unsigned*)a.ws + rem;
+      mg_handoff_release();
       const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool lastp = ticket == (unsigned)(npieces - 1);
-      if (lastp) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream-ordered)
+      if (lastp) {
+        mg_handoff_acquire();
+        __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream-ordered)
+      }
       *flag = lastp ? 1 : 0;
     }
     __syncthreads();

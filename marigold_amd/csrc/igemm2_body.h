@@ -853,9 +853,13 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
     __syncthreads();                                     // (also: every wave is past the K loop - the ring is free)
     int* const flag = (int*)smem;
     if (tid == 0) {
+      mg_handoff_release();
       const unsigned ticket = __hip_atomic_fetch_add(&a.ln_ctr[tile_m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == (unsigned)(a.tiles_n - 1);
-      if (last) __hip_atomic_store(&a.ln_ctr[tile_m], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (last) {
+        mg_handoff_acquire();
+        __hip_atomic_store(&a.ln_ctr[tile_m], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       *flag = last ? 1 : 0;
     }
     __syncthreads();

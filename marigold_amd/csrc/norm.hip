@@ -180,10 +180,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
+    mg_handoff_release();
     const unsigned ticket = __hip_atomic_fetch_add(&counters[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = ticket == (unsigned)(slots - 1);
     lds[0] = last ? 1.f : 0.f;
-    if (last) __hip_atomic_store(&counters[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last) {
+      mg_handoff_acquire();
+      __hip_atomic_store(&counters[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   __syncthreads();
   if (lds[0] == 0.f) return;
