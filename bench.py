@@ -29,6 +29,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+SURVEY_TFLOP_PER_MAP = 273.92   # E = 10, T = 10, 768 x 768, reference-faithful FLOP count
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,10 +70,11 @@ def pmc_traffic(kernel_class):
     path = files[-1]
     try:
         with open(path) as f:
-            t = json.load(f).get(kernel_class)
+            j = json.load(f)
+        t = j.get(kernel_class)
         rel = os.path.relpath(path, ROOT)
         return None if t is None else {"bytes_per_launch": t["bytes_per_launch"], "launches": t["launches"],
-                                       "source": f"{rel} (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE)"}
+                                       "source": f"{rel} (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE)", "build": j.get("_build") or {}}
     except (OSError, ValueError, KeyError):
         return None
 
@@ -465,6 +469,14 @@ def main():
                         roof["traffic_launches_profiled"] = t["launches"]
                         roof["traffic_source"] = t["source"]
                         roof["algorithmic_bytes_per_launch"] = round(kernels[dom]["bytes"] / kernels[dom]["launches"])
+                        # the counters are collected offline (separate rocprofv3 --pmc passes): say which build they belong to and
+                        # whether that is the build running now (content hash of the kernel sources + program builder + tuning table)
+                        from marigold_amd.util.host import build_fingerprint
+                        now = build_fingerprint()
+                        roof["traffic_build"] = t["build"].get("fingerprint")
+                        roof["traffic_git_head"] = t["build"].get("git_head")
+                        roof["build_fingerprint"] = now
+                        roof["traffic_stale"] = t["build"].get("fingerprint") != now
                 except Exception as e:  # noqa: BLE001 - a reporting nicety must never cost the benchmark line
                     log(f"[bench] traffic annotation skipped: {e}")
                 for d in kernels.values():
@@ -538,6 +550,9 @@ def main():
 
     if rank == 0:
         value = args.steps / dt
+        headline_cfg = (args.kind, args.ensemble, args.denoise, args.res, args.scheduler, args.tiny) == ("depth", 10, 10, 768, "ddim", False)
+        if roof is not None and roof.get("bound") == "mfma" and headline_cfg and world == 1:
+            roof["frac_survey"] = round(SURVEY_TFLOP_PER_MAP * value / opstats.MFMA_PEAK_TFLOPS, 4)   # whole map, SURVEY 8(d)'s FLOP count
         line = {
             "metric": f"{args.kind} maps/sec @{args.res}x{args.res}, ens={args.ensemble}, {args.denoise} {args.scheduler.upper()} steps",
             "value": round(value, 4), "unit": f"{args.kind} maps/s", "n_gpus": world, "steps": args.steps,
@@ -559,6 +574,10 @@ def main():
             "algorithmic_tflop_per_map": round(flops_per_map / 1e12, 2) if world == 1 else None,
             "pipeline_tflops": round(flops_per_map * value / 1e12, 1) if world == 1 else None,
             "pipeline_mfma_frac": round(flops_per_map * value / 1e12 / opstats.MFMA_PEAK_TFLOPS, 4) if world == 1 else None,
+            # the same against SURVEY.md section 8(d)'s reference-faithful count (273.92 TFLOP per map at the headline configuration):
+            # comparable across rounds however much work the engine folds away (sub-pixel up-sampling, collapsed cross-attention)
+            "pipeline_mfma_frac_survey": (round(SURVEY_TFLOP_PER_MAP * value / opstats.MFMA_PEAK_TFLOPS, 4)
+                                          if world == 1 and headline_cfg else None),
             "stages": stages,
             "kernels": kernels,
         }

@@ -40,3 +40,24 @@ def cpu_model() -> str:
     except OSError:
         pass
     return "unknown"
+
+
+def build_fingerprint():
+    """sha256 over everything that decides which kernels a map launches and what they do: the library's sources (csrc/*.hip, *.h,
+    *.inc, Makefile), the program builder (engine.py, ops.py, weights.py) and the tuning table.  bench.py prints it and compares it
+    with the one recorded beside the PMC traffic figures (profiles/r*_pmc_hbm_traffic.json: ``traffic_stale``) - the GPU box has
+    no .git, a content hash travels."""
+    import glob
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "csrc", "*.hip")) + glob.glob(os.path.join(root, "csrc", "*.h")) +
+                   glob.glob(os.path.join(root, "csrc", "*.inc")) + [os.path.join(root, "csrc", "Makefile")] +
+                   [os.path.join(root, n) for n in ("engine.py", "ops.py", "weights.py")] +
+                   glob.glob(os.path.join(root, "tuning", "*.json")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, root).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

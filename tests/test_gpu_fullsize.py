@@ -237,6 +237,33 @@ def test_metric_config_b10_members_vs_oracle(full, gold768):
     assert m1["rmse"] < 1e-2
 
 
+def test_c3_batch_e8_members_vs_oracle(full, gold768):
+    """C3's per-node total (E = 8 members, 10 steps, 768x768) as ONE batch on one GPU - the program a single-GPU run of C3 executes,
+    with its own tile / split-K choices (the tuning table keys on the row count): the four members the oracle holds against the
+    oracle, the ensembled map of the eight finite and in range, and member 0 against the B = 10 program's member 0."""
+    from marigold_amd import synthetic as syn
+    from oracle import metrics as omet
+    img = syn.synthetic_image(768, 768, seed=0)
+    lat = torch.cat([syn.synthetic_latents(4, 96, 96, seed=7), syn.synthetic_latents(6, 96, 96, seed=8)])
+    pipe = _pipe(full)
+    rgb = (img.float() / 255.0 * 2.0 - 1.0)
+    d8 = pipe.single_infer(rgb.expand(8, -1, -1, -1), 10, None, False, init_latents=lat[:8])
+    prog = full["unet"].denoise_program(8, 96, 96, pipe.scheduler, 10, rgb_broadcast=True)
+    for e in range(4):
+        r = _rel(prog.x[e:e + 1], gold768["ddim10_final"][e:e + 1])
+        print(f"[parity] C3 member {e} of the B=8 batch: final latent rmse/rms {r:.3e}")
+        assert r < LAT_REL_BOUND
+    m = omet.affine_invariant_depth_errors(gold768["ddim10_depth_m0"].astype(np.float32), d8[0, 0].cpu().numpy())
+    print(f"[parity] C3 member 0 depth vs fp32 CPU oracle: {m}")
+    assert m["rmse"] < DEPTH_RMSE_BOUND and m["delta1"] > DEPTH_D1_BOUND, m
+    out = pipe(img, denoising_steps=10, ensemble_size=8, processing_res=0, show_progress_bar=False, init_latents=lat[:8], color_map=None)
+    dn = np.asarray(out.depth_np)
+    assert dn.shape == (768, 768) and np.isfinite(dn).all() and dn.min() >= 0.0 and dn.max() <= 1.0
+    m2 = omet.affine_invariant_depth_errors(gold768["ddim10_depth_m0"].astype(np.float32), dn)
+    print(f"[property] C3 ensembled map (E=8) vs the oracle's member 0, affine-invariant: {m2}")
+    assert m2["delta1"] > 0.9
+
+
 def test_c2_heavy_tailed_weights_vs_oracle(full, golden_dir):
     """C2 on weights with SD-like activation statistics planted (marigold_amd/synthetic.py::plant_heavy_tails: 2 % outlier
     channels at 30x in every layer that writes the transformer residual stream, norm gains at 8x, GEGLU gate rows at 4x) -

@@ -442,14 +442,15 @@ def test_ensemble_depth_metric_config_vs_reference(golden_dir):
     # evaluations, 5.1 ms per call - the same gap to the reference's noise-limited stopping point as on the small
     # realistic golden (d_real_e10: mean 6.3e-3), i.e. it does not grow with the resolution
     assert m["rmse"] < 8e-3 and m["delta1"] > 0.99 and m["abs_rel"] < 2e-2
-    assert diff.mean() < 1e-2 and diff.max() < 5e-2
+    assert diff.mean() < 8e-3 and diff.max() < 3.5e-2   # (round 6: <= 1.5 x measured - mean 5.6e-3, max 2.2e-2)
     assert du.max() < 5e-2
     # The yardstick (round 5): the reference does not reproduce ITSELF more closely than this.  Its optimiser stops where the
     # fp32 summation noise of its cost swamps the finite differences, and that noise changes with the CPU thread count:
     # oracle/ref_ensemble_spread.py ran the reference on these members with 4, 8 and 16 threads (8 = the golden above, bit for
     # bit) - the three outputs differ from one another by max 1.2-1.6e-2, mean 4.3-4.9e-3, delta1 0.9959-0.9976
     # (profiles/r5_reference_ensemble_thread_spread.log).  The engine's deterministic output must sit inside that band:
-    # its mean deviation from EVERY reference run at most 1.5 x the largest mean deviation between two reference runs.
+    # its mean deviation from EVERY reference run at most 1.25 x the largest mean deviation between two reference runs, its
+    # largest at most 1.75 x theirs (round 6; measured 1.15 x / 1.62 x).
     thr = np.load(os.path.join(golden_dir, "ensemble_ref_768_threads.npz"))
     refs = {8: ref, 4: thr["d_real_e10_768_out_t4"].astype(np.float32), 16: thr["d_real_e10_768_out_t16"].astype(np.float32)}
     keys = sorted(refs)
@@ -459,8 +460,8 @@ def test_ensemble_depth_metric_config_vs_reference(golden_dir):
     print(f"[parity] ensemble_depth vs the reference run with 4 / 8 / 16 threads: mean |diff| " +
           " / ".join(f"{ours[k].mean():.2e}" for k in keys) + ", max " + " / ".join(f"{ours[k].max():.2e}" for k in keys) +
           f"; the reference runs among themselves: mean up to {spread_mean:.2e}, max up to {spread_max:.2e}")
-    assert max(float(v.mean()) for v in ours.values()) <= 1.5 * spread_mean
-    assert max(float(v.max()) for v in ours.values()) <= 2.0 * spread_max
+    assert max(float(v.mean()) for v in ours.values()) <= 1.25 * spread_mean
+    assert max(float(v.max()) for v in ours.values()) <= 1.75 * spread_max
 
 
 def _mp_worker(rank, world, port, q, hw=(64, 128)):

@@ -2,7 +2,7 @@
 """Turns the two rocprofv3 --pmc passes of bench.py (gpurun_out/pmc_fetch, gpurun_out/pmc_write; made by
 `scripts/gpu_round.sh pmc`) into profiles/<round>_pmc_hbm_traffic.{csv,json}: HBM bytes per launch per kernel,
 FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads - MI355X_MICROARCH.md, HBM).
-Usage: python tools/pmc_traffic.py [round tag, default r5]"""
+Usage: python tools/pmc_traffic.py [round tag, default r6]"""
 import collections
 import csv
 import json
@@ -27,7 +27,7 @@ def load(path, name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
     base = os.path.join(ROOT, "gpurun_out")
     import glob
 
@@ -53,6 +53,17 @@ def main():
         if n:
             out[cls] = {"launches": n, "bytes_per_launch": (2 * fs + ws) * 1024 / n,
                         "fetch_kb_sum": fs, "write_kb_sum": ws}
+    # which build the counters belong to: the content hash bench.py compares against (the GPU box has no .git) and, for the reader,
+    # the commit this tree sits on.  Run this tool on the tree that was sent to the GPU box, before editing it further.
+    sys.path.insert(0, ROOT)
+    from marigold_amd.util.host import build_fingerprint
+    import subprocess
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "marigold_amd"], capture_output=True, text=True).stdout.strip())
+    except OSError:
+        head, dirty = "", False
+    out["_build"] = {"fingerprint": build_fingerprint(), "git_head": head, "git_dirty": dirty}
     with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json"), "w") as j:
         json.dump(out, j, indent=1)
     print(json.dumps(out, indent=1))
