@@ -205,7 +205,7 @@ enum mg_op_kind {
    *   p[3] mad f32 [HW]|NULL  p[4] out f32 [2+2E] = min, max of the prediction and the raw member
    *   values d[.][argmin px], d[.][argmax px] (exact sub-gradient of the regulariser on the
    *   host)  p[5] scratch (>= 12288 B) ; i: E, reduction(0 median,1 mean), has_shift ; l[0] HW
-   * (DEPTH_STATS scratch: >= 128*E*(E+3) doubles.  Any E >= 1: <= 32 members are selected in registers, <= 128 in LDS,
+   * (DEPTH_STATS scratch: >= nblk*E*(E+3) doubles, nblk = min(ceil(HW / 256), E > 256 ? 32 : 128) - 128*E*(E+3) always suffices.  Any E >= 1: <= 32 members are selected in registers, <= 128 in LDS,
    * larger ensembles by a bitwise selection over the members in memory - the reference has no limit, ensemble.py:39-49)
    * DEPTH_NORM  : out = (med - lo)/range ; unc /= range.  p[0] med p[1] mad|NULL p[2] minmax
    *   ; i[0] shift_invariant ; l[0] HW

@@ -179,6 +179,8 @@ int mg_launch_head_conv(const mg_op* op, hipStream_t s) {
   a.silu = op->i[6];
   a.tiles_x = a.tiles_y = 0;
   MG_REQUIRE(a.x && a.w && a.out && a.B > 0 && a.H > 0 && a.W > 0, "conv3x3_head: bad arguments");
+  // the activation is applied where the norm is (the staging pass): a SiLU without scale / shift is not a form this kernel has
+  MG_REQUIRE(a.ss || !a.silu, "conv3x3_head: i[6] (SiLU) needs the GroupNorm scale / shift in p[1] (pass scale 1, shift 0 for a bare activation)");
   MG_REQUIRE(a.C > 0 && a.C % HC_CK == 0 && cout >= 1 && cout <= 4 && a.ldo >= cout,
              "conv3x3_head: C %d must be a multiple of %d, 1 <= Cout %d <= 4 <= ldo %d", a.C, HC_CK, cout, a.ldo);
   MG_REQUIRE((uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && (uintptr_t)a.out % 4 == 0, "conv3x3_head: misaligned operands");

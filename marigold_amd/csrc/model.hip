@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -72,6 +73,7 @@ struct mg_model {
   char* arena = nullptr;       // one device allocation holding every buffer (host-only: a fake base address, never touched)
   uint64_t arena_bytes = 0;
   std::vector<char*> bufs;
+  std::vector<uint64_t> buf_bytes;   // the buffer table's sizes: every relocation / slot is checked against them
   Prog enc, den, dec;
 };
 
@@ -91,6 +93,8 @@ int load_program(FILE* f, const ImgProgram& ip, mg_model* m, Prog* out) {
              "mg_model_load: short read (relocations of %s)", out->name.c_str());
   for (const ImgReloc& r : rel) {
     MG_REQUIRE(r.op < ip.n_ops && r.buf < m->bufs.size(), "mg_model_load: relocation out of range (%s)", out->name.c_str());
+    MG_REQUIRE(r.off < m->buf_bytes[r.buf], "mg_model_load: corrupt image - a relocation of %s points %llu bytes into buffer %u of %llu bytes",
+               out->name.c_str(), (unsigned long long)r.off, r.buf, (unsigned long long)m->buf_bytes[r.buf]);
     char* p = m->bufs[r.buf] + r.off;
     if (r.slot < 16) {
       ops[r.op].p[r.slot] = p;
@@ -106,6 +110,9 @@ int load_program(FILE* f, const ImgProgram& ip, mg_model* m, Prog* out) {
   for (uint32_t k = 0; k < ip.n_slots; ++k) {
     const ImgSlot& s = ip.slots[k];
     MG_REQUIRE(s.buf < m->bufs.size(), "mg_model_load: slot out of range (%s)", out->name.c_str());
+    MG_REQUIRE(s.off <= m->buf_bytes[s.buf] && s.nbytes <= m->buf_bytes[s.buf] - s.off,
+               "mg_model_load: corrupt image - slot %u of %s spans [%llu, +%llu) of a %llu-byte buffer", k, out->name.c_str(),
+               (unsigned long long)s.off, (unsigned long long)s.nbytes, (unsigned long long)m->buf_bytes[s.buf]);
     out->slots.push_back(Slot{std::string(s.name, strnlen(s.name, sizeof(s.name))), m->bufs[s.buf] + s.off, s.nbytes});
   }
   return 0;
@@ -120,9 +127,21 @@ int load_into(mg_model* m, FILE* f, int device) {
   MG_REQUIRE(h.n_programs == 3 && h.n_buffers > 0 && h.n_buffers < (1u << 24), "mg_model_load: corrupt header");
   std::vector<ImgBuffer> bt(h.n_buffers);
   MG_REQUIRE(read_at(f, sizeof(ImgHeader), bt.data(), sizeof(ImgBuffer) * h.n_buffers), "mg_model_load: short read (buffer table)");
+  // the file's own size bounds every stored buffer (a truncated / corrupt table must not size a staging buffer or a copy)
+  MG_REQUIRE(fseek(f, 0, SEEK_END) == 0, "mg_model_load: cannot seek");
+  const long fsz = ftell(f);
+  MG_REQUIRE(fsz > 0, "mg_model_load: cannot size the image");
+  const uint64_t file_bytes = (uint64_t)fsz;
   std::vector<uint64_t> off(h.n_buffers);
   uint64_t total = 0;
+  m->buf_bytes.resize(h.n_buffers);
   for (uint32_t i = 0; i < h.n_buffers; ++i) {
+    MG_REQUIRE(bt[i].nbytes > 0 && bt[i].nbytes < (1ull << 40), "mg_model_load: corrupt image - buffer %u has %llu bytes", i, (unsigned long long)bt[i].nbytes);
+    if (bt[i].kind == 2)
+      MG_REQUIRE(bt[i].file_off <= file_bytes && bt[i].nbytes <= file_bytes - bt[i].file_off,
+                 "mg_model_load: corrupt image - buffer %u lies at [%llu, +%llu) of a %llu-byte file", i, (unsigned long long)bt[i].file_off,
+                 (unsigned long long)bt[i].nbytes, (unsigned long long)file_bytes);
+    m->buf_bytes[i] = bt[i].nbytes;
     off[i] = total;
     total += (bt[i].nbytes + 255) / 256 * 256;
   }
@@ -181,7 +200,13 @@ mg_model* mg_model_load(const char* path, int device) {
     return nullptr;
   }
   mg_model* m = new mg_model();
-  const int rc = load_into(m, f, device);
+  int rc;
+  try {   // (std::vector / std::string allocations: nothing may unwind across the C boundary)
+    rc = load_into(m, f, device);
+  } catch (const std::exception& e) {
+    mg_set_error("mg_model_load: %s while reading %s (corrupt image?)", e.what(), path);
+    rc = 2;
+  }
   fclose(f);
   if (rc) {
     mg_model_destroy(m);

@@ -91,7 +91,10 @@ class HipStatsBackend:
     def stats(self):
         E = self.E
         dev = self.d.device
-        sscratch = torch.empty(128 * E * (E + 3), dtype=torch.float64, device=dev)
+        # partial table: one (E x (E + 3)) block of doubles per pixel block the launcher uses (csrc/ensemble.hip: 128, 32 beyond 256
+        # members, never more than the map has 256-pixel blocks) - at E = 1000 that is 257 MB where the fixed 128 asked for 1 GB
+        nblk = min(-(-self.HW // 256), 32 if E > 256 else 128)
+        sscratch = torch.empty(nblk * E * (E + 3), dtype=torch.float64, device=dev)
         stats = torch.empty(3 * E + E * E, dtype=torch.float64, device=dev)
         O.launch(O.ens_depth_stats(self.d, sscratch, stats, E=E, HW=self.HW))
         st = stats.cpu().numpy()

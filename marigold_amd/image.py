@@ -115,15 +115,32 @@ def export_model_image(pipe, path, *, ensemble_size, height, width, denoising_st
              ("denoise", den.seq, dict({"rgb_latent": den.rgb_latent, "x": den.x}, **{f"noise{k}": nz for k, nz in enumerate(den.noises)})),
              ("vae.decode", dec_seq, {"latent": dec_in, "pred": dec_out})]
     for _, seq, io in progs:
-        persist_ptrs = set()
         for t in seq.keep:
-            # zero-initialised state the kernels rely on (V^T pad columns, tickets, flash workspace) is uint8 torch.zeros from
-            # Builder.zeros_persistent; everything else held by the program is a constant or an input / output slot
-            zero_state = t.dtype == torch.uint8
-            bufs.add(t, KIND_ZERO if zero_state else KIND_DATA)
-            if zero_state:
-                persist_ptrs.add(t.data_ptr())
+            # zero-initialised state the kernels rely on (V^T pad columns, tickets, flash workspace): tagged by the builder
+            # (Builder.zeros_persistent -> OpSeq.zero_state); everything else held by the program is a constant or an input /
+            # output slot
+            bufs.add(t, KIND_ZERO if t.data_ptr() in seq.zero_state else KIND_DATA)
     bufs.finalize()
+    # the workspace pools also hold buffers of programs built earlier in this process for OTHER shapes: only what these three
+    # programs point into travels
+    used = set()
+    for _, seq, io in progs:
+        for op in seq.ops:
+            for s_ in range(16):
+                if op.p[s_]:
+                    hit = bufs.find(op.p[s_])
+                    if hit is not None:
+                        used.add(hit[0])
+            if op.kind == L.OP_IGEMM and (op.i[29] or op.i[30]):
+                hit = bufs.find((op.i[29] & 0xffffffff) | ((op.i[30] & 0xffffffff) << 32))
+                if hit is not None:
+                    used.add(hit[0])
+        for t in io.values():
+            hit = bufs.find(t.data_ptr())
+            if hit is not None:
+                used.add(hit[0])
+    bufs.items = [it for k, it in enumerate(bufs.items) if it[2] != KIND_SCRATCH or k in used]
+    bufs.starts = [it[0] for it in bufs.items]
 
     sz_op = ctypes.sizeof(L.MgOp)
     with open(path, "wb") as f:

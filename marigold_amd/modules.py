@@ -140,6 +140,7 @@ class UNet2DConditionModelHIP(_EngineModule):
             E.emit_unet_forward(bld, self.config, self._ctx, rgb_latent, x, eps, table, i, B, h, w, sched=sched)
             n_fwd = len(seq) - n0
         seq.keep.extend(bld.persist.values())
+        seq.zero_state = {t.data_ptr() for t in bld.persist.values()}   # Builder.zeros_persistent: state the kernels expect zeroed
         prog = DenoiseProgram(seq, rgb_latent, x, eps, noises, n_fwd, n_pro)
         self._programs[key] = prog
         return prog
@@ -192,6 +193,7 @@ class AutoencoderKLHIP(_EngineModule):
             E.emit_vae_decode(bld, self.config, inp, out, B, H, W, post)
         seq.hold(inp, out)
         seq.keep.extend(bld.persist.values())
+        seq.zero_state = {t.data_ptr() for t in bld.persist.values()}   # Builder.zeros_persistent: state the kernels expect zeroed
         self._programs[key] = (seq, inp, out)
         return self._programs[key]
 

@@ -228,6 +228,7 @@ class OpSeq:
         self.ops = []
         self.labels = []
         self.keep = []
+        self.zero_state = set()   # data_ptr()s of the held tensors that are zero-initialised kernel state (tickets, workspaces, pad columns)
         self._prog = None
         self._captured = False
 
@@ -245,6 +246,7 @@ class OpSeq:
         self.ops.extend(other.ops)
         self.labels.extend(other.labels)
         self.keep.extend(other.keep)
+        self.zero_state |= other.zero_state
         self._prog = None
 
     def __len__(self):

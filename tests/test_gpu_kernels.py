@@ -193,6 +193,12 @@ FOLD_CASES = [
     ("fold_v36_split_in_fold", 1, 12, 12, 64, 128, 512, 256, 36, 4),   # most of K is the folded part
     ("fold_v72_split2", 1, 12, 12, 1280, 256, 1280, 1280, 72, 2),
     ("fold_auto_split", 1, 12, 12, 1280, 1280, 1280, 1280, 0, 0),
+    # the tile / split pairs the tuning table names for folded launches of small ensembles (marigold_amd/tuning/gfx950.json)
+    ("fold_v22_split8", 1, 12, 12, 1280, 1280, 1280, 1280, 22, 8),
+    ("fold_v22_split6", 2, 12, 12, 1280, 1280, 1280, 0, 22, 6),
+    ("fold_v24_split8", 1, 12, 12, 1280, 1280, 1280, 1280, 24, 8),
+    ("fold_v32_split8", 1, 24, 24, 1280, 1280, 640, 640, 32, 8),
+    ("fold_v73_split16", 1, 24, 24, 1280, 640, 1280, 640, 73, 16),
 ]
 
 
