@@ -781,7 +781,7 @@ def test_model_image_round_trip_without_gpu(tmp_path):
         image.ModelImage(bad, device=-1)
     raw = open(path, "rb").read()
     open(bad, "wb").write(raw[:len(raw) // 2])
-    with pytest.raises(L.MarigoldHipError, match="short read"):
+    with pytest.raises(L.MarigoldHipError, match="short read|corrupt image"):   # (round 6: the buffer table is checked against the file size first)
         image.ModelImage(bad, device=-1)
     hdr = bytearray(raw[:88])
     struct.pack_into("<I", hdr, 12, 3)   # the ABI field
