@@ -35,7 +35,10 @@ SURVEY_TFLOP_PER_MAP = 273.92   # E = 10, T = 10, 768 x 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="maps on the GPU at a time (pipeline.map_images: independent maps on concurrent HIP streams); "
+                         "0 = the pipeline's default (2) on one GPU, 1 with several ranks")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ensemble", type=int, default=10)
     ap.add_argument("--denoise", type=int, default=10)
@@ -386,13 +389,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # maps in flight: K steps = K maps handed to pipe.map_images, which keeps up to `in_flight` of them on the GPU (each on its own
+    # engine replica and HIP stream; every map is the same computation as a lone pipe(img) call, bit for bit)
+    in_flight = args.in_flight if args.in_flight > 0 else (1 if dist_on else pipe.default_maps_in_flight)
+    if dist_on:
+        in_flight = 1   # member-parallel maps are collectives: one at a time, the same order on every rank
+
+    def run_maps(k):
+        last = None
+        for last in pipe.map_images([img] * k, in_flight=in_flight, **kw):
+            pass
+        return last
+
     out = None
     for i in range(args.warmup):
         t1 = time.perf_counter()
-        out = pipe(img, **kw)
+        out = run_maps(in_flight)   # one map per lane: every replica's programs built, its kernels loaded
         torch.cuda.synchronize()
         if rank == 0:
-            log(f"[bench] warmup {i}: {time.perf_counter() - t1:.3f}s")
+            log(f"[bench] warmup {i}: {time.perf_counter() - t1:.3f}s ({in_flight} map(s))")
     if args.graph:
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
@@ -402,10 +417,17 @@ def main():
         out = pipe(img, **kw)
     barrier()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        out = pipe(img, **kw)
+    out = run_maps(args.steps)
     barrier()
     dt = time.perf_counter() - t1
+    latency_ms = None
+    if in_flight > 1:   # the same maps one at a time: what a single request waits (not the headline)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(2):
+            pipe(img, **kw)
+        torch.cuda.synchronize()
+        latency_ms = (time.perf_counter() - t2) / 2 * 1e3
     tt = torch.tensor([dt], device="cpu" if (dist_on and dist.get_backend() == "gloo") else dev, dtype=torch.float64)
     if dist_on:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -564,7 +586,10 @@ def main():
                                     + ", seeded synthetic weights"
                                     + (" [TINY ARCH - plumbing only]" if args.tiny else "")),
                        "members_per_gpu": -(-args.ensemble // world), "parallelism": f"member-parallel x{world}",
-                       "hipgraph": bool(args.graph)},
+                       "hipgraph": bool(args.graph), "maps_in_flight": in_flight},
+            # one map at a time on one stream (None when that is what the headline ran); the per-kernel tables below
+            # ("stages", "kernels", "roofline") are timed that way too - launch by launch with HIP events, one map in flight
+            "latency_ms_per_map": None if latency_ms is None else round(latency_ms, 2),
             "roofline": roof,
             "collective": ({"backend": dist.get_backend(), "world_size": world, "forced_single_rank": bool(force_dist and world == 1),
                             "gathers_per_map": 1} if dist_on else None),

@@ -66,6 +66,8 @@ enum mg_op_kind {
    *  pad 1 only; Cx, Cx0 multiples of 64; the bias is the two layers' sum
    *  i[31] split-K: 0 = automatic (few output tiles x long K: fp32 partials + a fixed-order reduce launch), n >= 1 = exactly n
    *  K ranges per tile (1 = none) - bf16 epilogue without row statistics / folded LayerNorm / batching only
+   *  p[14] split-K workspace of the caller (64 MiB, 16-byte aligned) | NULL = the library's own, which programs on ONE stream may
+   *  share (stream-ordered reuse); programs that run concurrently on several streams each bring their own
    *  l[0..3] z-strides (elements) of A, Wt, out, residual      f[0] scale on the accumulator */
   MG_OP_IGEMM = 1,
   /* GroupNorm, 3 launches (stats partials -> per-(b,c) scale/shift -> apply [+SiLU]).

@@ -51,6 +51,9 @@ def build_parser(kind: str) -> argparse.ArgumentParser:
     p.add_argument("--seed", type=int, default=None, help="Reproducibility seed; None = randomised inference.")
     p.add_argument("--batch_size", type=int, default=0, help="Inference batch size; 0 = automatic.")
     p.add_argument("--apple_silicon", action="store_true", help="(reference flag; not available on this engine)")
+    p.add_argument("--maps_in_flight", type=int, default=0,
+                   help="Images on the GPU at a time (independent maps on concurrent HIP streams; results do not depend on it); "
+                        "0 = the engine's default (2).")
     return p
 
 
@@ -157,18 +160,27 @@ def main(kind: str, argv=None, pipeline=None) -> int:
                  f"processing resolution = {args.processing_res or pipeline.default_processing_resolution}, "
                  f"seed = {args.seed}" + (f"; color_map = {args.color_map}." if kind == "depth" else ""))
     device = getattr(pipeline, "device", "cpu")
-    for rgb_path in files:
-        image = Image.open(rgb_path)
-        generator = None
-        if args.seed is not None:
-            generator = torch.Generator(device=device)
-            generator.manual_seed(args.seed)
-        kw = dict(denoising_steps=args.denoise_steps, ensemble_size=args.ensemble_size,
-                  processing_res=args.processing_res, match_input_res=match_input_res,
-                  batch_size=args.batch_size, show_progress_bar=True, resample_method=args.resample_method,
-                  generator=generator)
-        if kind == "depth":
-            kw["color_map"] = args.color_map
-        out = pipeline(image, **kw)
-        save_prediction(kind, dirs, rgb_path, out)
+    kw = dict(denoising_steps=args.denoise_steps, ensemble_size=args.ensemble_size,
+              processing_res=args.processing_res, match_input_res=match_input_res,
+              batch_size=args.batch_size, show_progress_bar=True, resample_method=args.resample_method)
+    if kind == "depth":
+        kw["color_map"] = args.color_map
+
+    def generator_of(_path):   # a fresh generator per image, like the reference's loop (script/depth/run.py:240-244)
+        if args.seed is None:
+            return None
+        g = torch.Generator(device=device)
+        g.manual_seed(args.seed)
+        return g
+
+    if hasattr(pipeline, "map_images"):
+        # the engine's multi-image form: up to --maps_in_flight images on the GPU at a time, outputs in input order
+        outs = pipeline.map_images((Image.open(f) for f in files), in_flight=args.maps_in_flight or None,
+                                   generators=(generator_of(f) for f in files), **kw)
+        for rgb_path, out in zip(files, outs):
+            save_prediction(kind, dirs, rgb_path, out)
+    else:   # an object with the reference pipeline's call surface only
+        for rgb_path in files:
+            out = pipeline(Image.open(rgb_path), generator=generator_of(rgb_path), **kw)
+            save_prediction(kind, dirs, rgb_path, out)
     return 0

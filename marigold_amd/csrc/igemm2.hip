@@ -113,7 +113,7 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
   const long long tiles = (long long)b.tiles_m * b.tiles_n;
   // a.splits: -1 = never (forced tile / epilogues the reduce launch cannot finish), 0 = the automatic rule, n >= 1 = exactly n
   // (op i[31]: the tuning sweeps and the per-batch rules of mg_igemm_auto_split)
-  const bool sk_ok = !TRANS && a.splits >= 0 && batch_z == 1 && a.epi == MG_EPI_BF16 && a.n_begin == 0 && a.n_end == a.N && g_splitk_ws;
+  const bool sk_ok = !TRANS && a.splits >= 0 && batch_z == 1 && a.epi == MG_EPI_BF16 && a.n_begin == 0 && a.n_end == a.N && (a.ws || g_splitk_ws);
   if (sk_ok && (a.splits > 1 || (a.splits == 0 && tiles < 160 && b.KT >= 32))) {   // (a wider window, < 256 tiles, measured no gain at E = 10)
     int sp;
     if (a.splits > 1) {
@@ -132,7 +132,7 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
     if (sp > 1) {
       b.kps = (b.KT + sp - 1) / sp;
       b.splits = (b.KT + b.kps - 1) / b.kps;
-      b.ws = (float*)g_splitk_ws;
+      b.ws = a.ws ? a.ws : (float*)g_splitk_ws;   // op p[14]: the program's own workspace (programs on concurrent streams)
     }
   }
   const long long grid = tiles * b.splits * batch_z;
@@ -289,7 +289,7 @@ int mg_launch_igemm2(const mg_op* op, hipStream_t s, int variant) {
     a.splits = -1;
   }
   a.kps = 0;
-  a.ws = nullptr;
+  a.ws = (float*)op->p[14];   // the caller's split-K workspace (MG_SPLITK_WS_BYTES) | NULL = the library's (one stream only)
   a.ctr = 0;
   a.fd_rpi = mg_make_fastdiv(a.rows_per_img > 0 ? a.rows_per_img : 1);
   a.fd_wo = mg_make_fastdiv(a.Wo > 0 ? a.Wo : 1);

@@ -10,6 +10,7 @@ program order, so the working set of a forward stays small and cache-friendly.
 """
 import math
 import os
+import threading
 from collections import defaultdict
 
 import torch
@@ -101,11 +102,13 @@ class WeightStore:
         self.sd = sd
         self.device = device
         self.cache = {}
+        self._lock = threading.RLock()   # engine replicas (modules._EngineModule.replica) build their programs from one store
 
     def _memo(self, key, fn):
-        if key not in self.cache:
-            self.cache[key] = fn()
-        return self.cache[key]
+        with self._lock:
+            if key not in self.cache:
+                self.cache[key] = fn()
+            return self.cache[key]
 
     def has(self, name):
         return f"{name}.weight" in self.sd
@@ -295,6 +298,10 @@ class Builder:
         return self.persist[key]
 
     def add(self, op, label):
+        if op.kind == L.OP_IGEMM and not op.p[14]:
+            # the program's own split-K workspace (MG_OP_IGEMM p[14]): programs on concurrent streams - two maps in flight -
+            # must not share the library's
+            op.p[14] = self.zeros_persistent("splitk_ws", O.SPLITK_WS_BYTES).data_ptr()
         self.seq.add(tuning.apply(op), label)   # (MG_OP_IGEMM: the measured tile / split-K choice where the table has one)
 
     # ---- primitive layers ----------------------------------------------------------------

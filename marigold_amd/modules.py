@@ -60,6 +60,19 @@ class _EngineModule:
         self._programs = {}
         return self
 
+    def replica(self):
+        """A second engine over the SAME device-resident weights: its own workspace pool, programs and every piece of
+        launch-private state a program carries (tickets, split-K and key-split workspaces) - what a map needs to run on another
+        HIP stream while this engine's map is in flight (pipeline.map_images)."""
+        self._require_device()
+        if self.device.type != "cuda":
+            raise RuntimeError("replica(): the engine is not on a GPU")
+        r = object.__new__(type(self))
+        r.__dict__.update(self.__dict__)
+        r.pool = E.Pool(self.device)
+        r._programs = {}
+        return r
+
     def _require_device(self):
         if self.ws is None:
             raise RuntimeError(f"{type(self).__name__}: call .to('cuda') first")

@@ -113,6 +113,7 @@ def gn_slab(x0, out, ss, *, B, HW, C, groups, gamma, beta, eps, silu=False, x1=N
     return make_op(L.OP_GN_SLAB, i=[B, HW, C, C0, groups, int(silu)], f=[eps], p=[x0, x1, out, gamma, beta, ss])
 
 
+SPLITK_WS_BYTES = 64 << 20   # MG_SPLITK_WS_BYTES (csrc/common.h): what MG_OP_IGEMM p[14] must hold
 FLASH_WS_BYTES = 4096 + 255 * 4 * 4 * (16384 + 1024)   # tickets + four partial results for up to 255 split blocks of queries (tests: split = 1)
 # What the engine allocates per program: the automatic rule (split = 0) only splits a left-over of at most CUs / 8 blocks (32 on
 # MI355X; 40 leaves room for a larger part) - 11 MB instead of 71 MB zeroed per Builder.  A smaller workspace than a launch could

@@ -100,6 +100,7 @@ class _MarigoldPipelineBase:
     def to(self, device):
         self.unet.to(device)
         self.vae.to(device)
+        self._lanes = None   # engine replicas of map_images belong to the device they were made on
         return self
 
     @classmethod
@@ -124,6 +125,137 @@ class _MarigoldPipelineBase:
 
     def _sharded(self):
         return self._member_parallel and (mdist.world_size(self._member_group) > 1 or getattr(self, "_member_force", False))
+
+    # ---- maps in flight ----------------------------------------------------------------------
+    # The reference's scripts call the pipeline image by image (script/depth/run.py:231-262, script/depth/infer.py): every map waits
+    # for the one before it.  One map alone leaves the MI355X partly idle wherever a launch is a single lockstep round of workgroups
+    # whose HBM-bound epilogues follow their K loops, has a part-filled last round, or is a host-driven chain (the alignment
+    # optimiser's ~80 evaluations per map): a SECOND, independent map on another HIP stream fills those holes (DESIGN.md section 6b;
+    # tools/inflight_bench.py: +9 % maps/s at E = 10, every map bit-identical to the one-at-a-time result).  288 GB of HBM hold the
+    # second set of workspaces (23 GB at 768 x 768, E = 10) many times over; the weights are shared.
+    default_maps_in_flight = 2
+
+    def replicate(self):
+        """Another pipeline over the same device-resident weights: engine replicas (own workspaces, programs, launch-private
+        state) and its own scheduler object - what ``map_images`` runs a second map on."""
+        import copy
+        r = copy.copy(self)
+        r.unet, r.vae = self.unet.replica(), self.vae.replica()
+        r.scheduler = copy.deepcopy(self.scheduler)
+        r._lanes = None
+        return r
+
+    def _lane_pipelines(self, n):
+        lanes = getattr(self, "_lanes", None)
+        if lanes is None:
+            lanes = self._lanes = [(self, torch.cuda.Stream(device=self.device))]
+        while len(lanes) < n:
+            lanes.append((self.replicate(), torch.cuda.Stream(device=self.device)))
+        return lanes[:n]
+
+    def map_images(self, images, in_flight: Optional[int] = None, generators=None, **call_kwargs):
+        """``(pipe(image, **call_kwargs) for image in images)`` with up to ``in_flight`` maps on the GPU at a time (default
+        ``default_maps_in_flight``; 1 = one after the other on the caller's stream).  A generator: outputs come in input order
+        as they complete, and ``images`` (any iterable) is consumed as lanes become free.  ``generators``: one
+        ``torch.Generator`` (or None) per image - with several maps in flight a single shared generator would be consumed in
+        completion order, so ``generator=`` is refused; every map is then bit-identical to what ``pipe(image, generator=g)``
+        returns on its own.  Member-parallel pipelines (several ranks) run one map at a time: their gathers are collectives
+        that every rank must issue in the same order."""
+        n = self.default_maps_in_flight if in_flight is None else int(in_flight)
+        if n < 1:
+            raise ValueError(f"in_flight must be >= 1 (got {in_flight})")
+        if generators is not None and hasattr(images, "__len__") and hasattr(generators, "__len__") and len(images) != len(generators):
+            raise ValueError(f"{len(generators)} generators for {len(images)} images")
+        if hasattr(images, "__len__"):
+            n = min(n, max(1, len(images)))
+        if self._sharded() or self.device.type != "cuda":
+            n = 1
+        if n > 1 and call_kwargs.get("generator") is not None:
+            raise ValueError("map_images: pass `generators` (one per image) instead of a shared `generator` when in_flight > 1")
+        return self._map_images(iter(images), None if generators is None else iter(generators), n, call_kwargs)
+
+    def _map_images(self, images, generators, n, call_kwargs):
+        import threading
+        lock = threading.Lock()
+        count = [0]
+
+        def take():
+            """-> (index, image, generator) | None; under the lock: the two iterables advance together"""
+            with lock:
+                try:
+                    image = next(images)
+                except StopIteration:
+                    return None
+                g = None
+                if generators is not None:
+                    try:
+                        g = next(generators)
+                    except StopIteration:
+                        raise ValueError("map_images: fewer generators than images") from None
+                k = count[0]
+                count[0] += 1
+                return k, image, g
+
+        def one(pipe, image, g):
+            kw = dict(call_kwargs)
+            if generators is not None:
+                kw["generator"] = g
+            return pipe(image, **kw)
+
+        if n == 1:
+            while (item := take()) is not None:
+                yield one(self, item[1], item[2])
+            return
+        lanes = self._lane_pipelines(n)
+        caller = torch.cuda.current_stream(self.device)
+        done = {}
+        cv = threading.Condition()
+        stop = threading.Event()
+        live = [len(lanes)]
+
+        def work(pipe, stream):
+            try:
+                torch.cuda.set_device(self.device)
+                stream.wait_stream(caller)   # inputs the caller produced on its stream
+                with torch.cuda.stream(stream):
+                    while not stop.is_set():
+                        item = take()
+                        if item is None:
+                            break
+                        out = one(pipe, item[1], item[2])
+                        with cv:
+                            done[item[0]] = out
+                            cv.notify_all()
+            except BaseException as e:  # noqa: BLE001 - handed to the caller's thread
+                with cv:
+                    done.setdefault("error", e)
+                    cv.notify_all()
+            finally:
+                with cv:
+                    live[0] -= 1
+                    cv.notify_all()
+
+        threads = [threading.Thread(target=work, args=lane, daemon=True) for lane in lanes]
+        for t in threads:
+            t.start()
+        try:
+            k = 0
+            while True:
+                with cv:
+                    cv.wait_for(lambda: k in done or "error" in done or live[0] == 0)
+                    if "error" in done:
+                        raise done["error"]
+                    if k not in done:
+                        break   # every lane has finished and map k was never started: the input is exhausted
+                    out = done.pop(k)
+                yield out
+                k += 1
+        finally:
+            stop.set()
+            for t in threads:
+                t.join()
+            for _, stream in lanes:
+                caller.wait_stream(stream)
 
     # ---- reference methods -------------------------------------------------------------------
     def _check_inference_step(self, n_step: int) -> None:

@@ -10,11 +10,11 @@ LOG=gpurun_out/ab_$NAME.log
 for round in 1 2; do
   for side in A B; do
     if [ $side == A ]; then E="$A"; else E="$B"; fi
-    env $E timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --dump-ops gpurun_out/ops_${NAME}_$side.tsv "$@" 2>gpurun_out/ab_${NAME}_err_$side.log | python -c "
+    env $E timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --dump-ops gpurun_out/ops_${NAME}_$side.tsv "$@" 2>gpurun_out/ab_${NAME}_err_$side.log | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
-        j=json.loads(l); print('$side [$E] round=$round ms_per_map', j['ms_per_step'], {k: round(v['ms'],2) for k,v in j.get('stages',{}).items()}, 'launches', sum(v['launches'] for v in j['kernels'].values()), {k: (round(v['ms'],2), v['launches']) for k,v in j['kernels'].items() if v['ms'] > 1.0}, 'gemm', (j.get('calibration') or {}).get('gemm4096_bf16_tflops'))
+        j=json.loads(l); print('$side [$E] round=$round ms_per_map', j['ms_per_step'], 'alone', j.get('latency_ms_per_map'), {k: round(v['ms'],2) for k,v in j.get('stages',{}).items()}, 'launches', sum(v['launches'] for v in j['kernels'].values()), {k: (round(v['ms'],2), v['launches']) for k,v in j['kernels'].items() if v['ms'] > 1.0}, 'gemm', (j.get('calibration') or {}).get('gemm4096_bf16_tflops'))
 " >> $LOG
   done
 done

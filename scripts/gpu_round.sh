@@ -40,12 +40,12 @@ for l in sys.stdin:
 done
 echo "configs done" >> gpurun_out/status.log
 rm -rf gpurun_out/prof
-(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r5 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $R/gpurun_out/rocprof_bench.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r5 -- python $R/bench.py --steps 1 --warmup 1 --in-flight 1 --no-cpu-baseline --no-profile > $R/gpurun_out/rocprof_bench.log 2>&1)
 echo "rocprof rc=$?" >> gpurun_out/status.log
 if [ "$1" == "pmc" ]; then
-  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o r5 -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $R/gpurun_out/pmc_fetch.log 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o r5 -- python $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-profile > $R/gpurun_out/pmc_fetch.log 2>&1)
   echo "pmc fetch rc=$?" >> gpurun_out/status.log
-  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o r5 -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $R/gpurun_out/pmc_write.log 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o r5 -- python $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-profile > $R/gpurun_out/pmc_write.log 2>&1)
   echo "pmc write rc=$?" >> gpurun_out/status.log
 fi
 find gpurun_out -name "*kernel_trace*" -size +30M -delete 2>/dev/null

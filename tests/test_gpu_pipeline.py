@@ -214,6 +214,49 @@ def test_pipeline_call_depth_ensemble(tiny):
     assert out2.depth_np.shape == (64, 128)
 
 
+def test_map_images_maps_in_flight_bit_identical(tiny):
+    """pipeline.map_images: several maps on the GPU at a time (engine replicas over the same weights, one HIP stream and host
+    thread each) - every map is bit-identical to the lone ``pipe(image, generator=g)`` call (reference loop
+    script/depth/run.py:231-262), in input order, for 2 and 3 lanes, depth (host-driven ensembling) and normals; misuse raises."""
+    from marigold_amd import schedulers as S
+    from marigold_amd import synthetic as syn
+    imgs = [syn.synthetic_image(64, 128, seed=k) for k in range(5)]
+
+    def gens():
+        out = []
+        for k in range(len(imgs)):
+            g = torch.Generator(device="cuda:0")
+            g.manual_seed(1000 + k)
+            out.append(g)
+        return out
+    for kind, key in (("depth", "depth_np"), ("normals", "normals_np")):
+        pipe = _engine_pipe(tiny, kind, S.DDIMScheduler())
+        kw = dict(denoising_steps=2, ensemble_size=3, processing_res=0, show_progress_bar=False)
+        if kind == "depth":
+            kw["color_map"] = None
+        alone = [getattr(pipe(im, generator=g, **kw), key) for im, g in zip(imgs, gens())]
+        for n in (1, 2, 3):
+            got = [getattr(o, key) for o in pipe.map_images(imgs, in_flight=n, generators=gens(), **kw)]
+            assert len(got) == len(imgs)
+            for k, (a, b) in enumerate(zip(alone, got)):
+                assert np.array_equal(a, b), f"{kind}: map {k} differs with {n} in flight"
+        # a second round on the cached lanes (tickets / workspaces left clean by the first)
+        got = [getattr(o, key) for o in pipe.map_images(imgs[:4], in_flight=2, generators=gens()[:4], **kw)]
+        assert all(np.array_equal(a, b) for a, b in zip(alone, got))
+        assert len(pipe._lanes) == 3 and pipe._lanes[1][0].unet.ws is pipe.unet.ws and pipe._lanes[1][0].unet.pool is not pipe.unet.pool
+    with pytest.raises(ValueError):
+        list(pipe.map_images(imgs, in_flight=2, generator=gens()[0], **kw))
+    with pytest.raises(ValueError):
+        list(pipe.map_images(imgs, in_flight=2, generators=gens()[:2], **kw))
+    with pytest.raises(ValueError):
+        list(pipe.map_images(imgs, in_flight=0, **kw))
+
+    # an exception inside a lane reaches the caller
+    bad = [imgs[0], "not an image", imgs[1]]
+    with pytest.raises(TypeError):
+        list(pipe.map_images(bad, in_flight=2, **kw))
+
+
 def test_pipeline_image_size_not_a_multiple_of_8(tiny):
     """KITTI (script/depth/eval/21_infer_kitti.sh): 1242 x 375 -> processing_res 768 -> 768 x 231, which the VAE's three
     stride-2 convolutions take to a 96 x 28 latent and the decoder back to 768 x 224 - smaller than the image.  Here at

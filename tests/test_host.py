@@ -515,6 +515,44 @@ def test_depth_alignment_gradient_and_fd_survival(golden_dir):
     assert k[0] == 0 and k[1] == 0 and abs(k[2] - 1) < 1e-6 and abs(k[3] - 1) < 0.07 and abs(k[5] - 1) < 1e-6
 
 
+def test_map_images_host_logic():
+    """pipeline.map_images without a GPU: one map at a time on the caller's thread, inputs consumed lazily and zipped with their
+    generators, argument checks made at the call (the several-lanes form is a GPU test:
+    tests/test_gpu_pipeline.py::test_map_images_maps_in_flight_bit_identical)."""
+    from marigold_amd.pipeline import _MarigoldPipelineBase
+
+    class P(_MarigoldPipelineBase):
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self._member_parallel = False
+            self.seen = []
+
+        def __call__(self, image, **kw):
+            self.seen.append((image, kw.get("generator"), kw.get("ensemble_size")))
+            return image * 2
+
+    p = P()
+    pulled = []
+
+    def src():
+        for k in range(4):
+            pulled.append(k)
+            yield k
+    it = p.map_images(src(), in_flight=3, generators=iter("abcd"), ensemble_size=5)
+    assert pulled == [] and p.seen == []          # nothing runs before the first output is asked for
+    assert next(it) == 0 and pulled == [0]        # ... and no further than the map that is asked for
+    assert list(it) == [2, 4, 6]
+    assert p.seen == [(0, "a", 5), (1, "b", 5), (2, "c", 5), (3, "d", 5)]
+    assert list(p.map_images([1, 2], in_flight=1, generator="g")) == [2, 4]     # a shared generator is fine one map at a time
+    with pytest.raises(ValueError):
+        p.map_images([1, 2, 3], generators=["a"])
+    with pytest.raises(ValueError):
+        p.map_images([1], in_flight=0)
+    with pytest.raises(ValueError):
+        list(p.map_images(iter([1, 2, 3]), generators=iter(["a"])))
+
+
 def test_cli_flags_and_output_formats(tmp_path):
     """script/{depth,normals}/run.py: the reference's flags, folders, file names and encodings
     (script/depth/run.py:54-135, 165-171, 270-292), driven with a stand-in pipeline object."""
