@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--in-flight", type=int, default=0,
                     help="maps on the GPU at a time (pipeline.map_images: independent maps on concurrent HIP streams); "
-                         "0 = the pipeline's default (2) on one GPU, 1 with several ranks")
+                         "0 = the pipeline's default (2)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ensemble", type=int, default=10)
     ap.add_argument("--denoise", type=int, default=10)
@@ -391,9 +391,8 @@ def main():
 
     # maps in flight: K steps = K maps handed to pipe.map_images, which keeps up to `in_flight` of them on the GPU (each on its own
     # engine replica and HIP stream; every map is the same computation as a lone pipe(img) call, bit for bit)
-    in_flight = args.in_flight if args.in_flight > 0 else (1 if dist_on else pipe.default_maps_in_flight)
-    if dist_on:
-        in_flight = 1   # member-parallel maps are collectives: one at a time, the same order on every rank
+    # (with several ranks every rank runs the same lanes; the gathers are issued in map order on all of them - pipeline._Turnstile)
+    in_flight = args.in_flight if args.in_flight > 0 else pipe.default_maps_in_flight
 
     def run_maps(k):
         last = None

@@ -127,6 +127,10 @@ int launch2(const Igemm2Args& a, int batch_z, hipStream_t s) {
     // launch: correct, but 25 ms per map SLOWER (igemm 110.5 -> 135.5 ms, profiles/r4_ab_splitk_fused.log) - ONE workgroup then
     // reads splits x 256 KB of slabs per tile at the 60-100 GB/s a single workgroup gets, on the launch's critical path, where
     // the reduce launch spreads the same bytes over the whole chip in 13 us.
+    {   // tuning only (A/B under maps in flight): MARIGOLD_SPLITK_MAX = 1: no split-K, n > 1: at most n K ranges per tile
+      static const int skmax = mg_tuning_int("MARIGOLD_SPLITK_MAX", 0);
+      if (skmax > 0) sp = min(sp, skmax);
+    }
     const long long per_split = (long long)a.M * a.N * 4;
     while (sp > 1 && (long long)sp * per_split > MG_SPLITK_WS_BYTES) --sp;
     if (sp > 1) {

@@ -58,6 +58,9 @@ def infer_parser(kind):
     p.add_argument("--resample_method", choices=["bilinear", "bicubic", "nearest"], default="bilinear")
     p.add_argument("--seed", type=int, default=None, help="Reproducibility seed; None = time-seeded.")
     p.add_argument("--yes", action="store_true", help="Do not ask before writing into an existing output dir.")
+    p.add_argument("--maps_in_flight", type=int, default=0,
+                   help="Images on the GPU at a time (independent maps on concurrent HIP streams; results do not depend on it); "
+                        "0 = the engine's default (2).")
     return p
 
 
@@ -134,24 +137,35 @@ def infer_main(kind, argv=None, pipeline=None) -> int:
     device = getattr(pipeline, "device", "cpu")
     n = len(dataset)
     t0 = time.perf_counter()
+    kw = dict(denoising_steps=args.denoise_steps, ensemble_size=args.ensemble_size,
+              processing_res=args.processing_res, match_input_res=match_input_res, batch_size=0,
+              show_progress_bar=False, resample_method=args.resample_method)
+    if kind == "depth":
+        kw["color_map"] = None
+
+    def generator_of():   # a fresh generator per image, seeded alike (script/depth/infer.py:186-190)
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        return g
     with ThreadPoolExecutor(max_workers=1) as reader, ThreadPoolExecutor(max_workers=2) as writer:
-        pending = reader.submit(dataset.__getitem__, 0) if n else None
+        samples = []   # in input order; the engine asks for the next image when a lane is free, results come back in order
+
+        def images():
+            pending = reader.submit(dataset.__getitem__, 0) if n else None
+            for i in range(n):
+                sample = pending.result()
+                pending = reader.submit(dataset.__getitem__, i + 1) if i + 1 < n else None
+                samples.append(sample)
+                yield Image.fromarray(np.moveaxis(_pipeline_input(kind, sample), 0, -1))
+        if hasattr(pipeline, "map_images"):   # the engine: up to --maps_in_flight images on the GPU at a time
+            outs = pipeline.map_images(images(), in_flight=args.maps_in_flight or None, generators=(generator_of() for _ in range(n)), **kw)
+        else:                                 # an object with the reference pipeline's call surface only
+            outs = (pipeline(im, generator=generator_of(), **kw) for im in images())
         writes = []
-        for i in range(n):
-            sample = pending.result()
-            pending = reader.submit(dataset.__getitem__, i + 1) if i + 1 < n else None
-            rgb = _pipeline_input(kind, sample)
-            image = Image.fromarray(np.moveaxis(rgb, 0, -1))
-            generator = torch.Generator(device=device)
-            generator.manual_seed(seed)
-            kw = dict(denoising_steps=args.denoise_steps, ensemble_size=args.ensemble_size,
-                      processing_res=args.processing_res, match_input_res=match_input_res, batch_size=0,
-                      show_progress_bar=False, resample_method=args.resample_method, generator=generator)
-            if kind == "depth":
-                kw["color_map"] = None
-            out = pipeline(image, **kw)
-            for rel, arr in _prediction_files(kind, dataset, pipeline, sample["rgb_relative_path"], out):
+        for i, out in enumerate(outs):
+            for rel, arr in _prediction_files(kind, dataset, pipeline, samples[i]["rgb_relative_path"], out):
                 writes.append(writer.submit(_save_npy, os.path.join(args.output_dir, rel), arr))
+            samples[i] = None
         for w in writes:
             w.result()
     dt = time.perf_counter() - t0

@@ -47,6 +47,33 @@ class MarigoldNormalsOutput:
     uncertainty: Union[None, np.ndarray]
 
 
+class _Turnstile:
+    """Calls pass in index order, one at a time: ``wait(k)`` returns once 0 ... k - 1 are ``done``."""
+
+    def __init__(self):
+        import threading
+        self._cv = threading.Condition()
+        self._next = 0
+        self._error = None
+
+    def wait(self, k):
+        with self._cv:
+            self._cv.wait_for(lambda: self._next == k or self._error is not None)
+            if self._error is not None:
+                raise RuntimeError("map_images: another lane failed before its gather") from self._error
+
+    def done(self, k):
+        with self._cv:
+            if self._next == k:
+                self._next = k + 1
+            self._cv.notify_all()
+
+    def abort(self, error):
+        with self._cv:
+            self._error = error
+            self._cv.notify_all()
+
+
 class _MarigoldPipelineBase:
     latent_scale_factor = 0.18215
     _kind = "depth"
@@ -159,8 +186,9 @@ class _MarigoldPipelineBase:
         as they complete, and ``images`` (any iterable) is consumed as lanes become free.  ``generators``: one
         ``torch.Generator`` (or None) per image - with several maps in flight a single shared generator would be consumed in
         completion order, so ``generator=`` is refused; every map is then bit-identical to what ``pipe(image, generator=g)``
-        returns on its own.  Member-parallel pipelines (several ranks) run one map at a time: their gathers are collectives
-        that every rank must issue in the same order."""
+        returns on its own.  Member-parallel pipelines (several ranks): every rank must call this with the same images and
+        ``in_flight``; the lanes then issue their gathers strictly in map order, one at a time (``_Turnstile``), so the collective
+        sequence is the same on every rank whichever lane finishes first."""
         n = self.default_maps_in_flight if in_flight is None else int(in_flight)
         if n < 1:
             raise ValueError(f"in_flight must be >= 1 (got {in_flight})")
@@ -168,7 +196,7 @@ class _MarigoldPipelineBase:
             raise ValueError(f"{len(generators)} generators for {len(images)} images")
         if hasattr(images, "__len__"):
             n = min(n, max(1, len(images)))
-        if self._sharded() or self.device.type != "cuda":
+        if self.device.type != "cuda":
             n = 1
         if n > 1 and call_kwargs.get("generator") is not None:
             raise ValueError("map_images: pass `generators` (one per image) instead of a shared `generator` when in_flight > 1")
@@ -196,11 +224,17 @@ class _MarigoldPipelineBase:
                 count[0] += 1
                 return k, image, g
 
-        def one(pipe, image, g):
+        turnstile = _Turnstile() if (n > 1 and self._sharded()) else None
+
+        def one(pipe, image, g, k=0):
             kw = dict(call_kwargs)
             if generators is not None:
                 kw["generator"] = g
-            return pipe(image, **kw)
+            pipe._gather_turn = None if turnstile is None else (turnstile, k)
+            try:
+                return pipe(image, **kw)
+            finally:
+                pipe._gather_turn = None
 
         if n == 1:
             while (item := take()) is not None:
@@ -222,11 +256,13 @@ class _MarigoldPipelineBase:
                         item = take()
                         if item is None:
                             break
-                        out = one(pipe, item[1], item[2])
+                        out = one(pipe, item[1], item[2], item[0])
                         with cv:
                             done[item[0]] = out
                             cv.notify_all()
             except BaseException as e:  # noqa: BLE001 - handed to the caller's thread
+                if turnstile is not None:
+                    turnstile.abort(e)   # lanes waiting for their turn must not wait for a gather that will never be issued
                 with cv:
                     done.setdefault("error", e)
                     cv.notify_all()
@@ -367,8 +403,17 @@ class _MarigoldPipelineBase:
             # need the shape too, so it is computed, not taken from `local`
             f = 2 ** (len(self.vae.config.block_out_channels) - 1)
             hh, ww = (f * d for d in self._latent_hw(rgb_norm.shape[-2:]))
-            return mdist.gather_members(local, E, (C, hh, ww), self.device, self._member_group,
-                                        getattr(self, "_member_root", None), force=getattr(self, "_member_force", False))
+            # maps in flight: the gather is a collective on ONE process group - every rank issues the gathers of maps 0, 1, 2 ...
+            # in that order, one at a time, whichever lane (thread, stream) predicted them (map_images hands each call its turn)
+            turn = getattr(self, "_gather_turn", None)
+            if turn is not None:
+                turn[0].wait(turn[1])
+            try:
+                return mdist.gather_members(local, E, (C, hh, ww), self.device, self._member_group,
+                                            getattr(self, "_member_root", None), force=getattr(self, "_member_force", False))
+            finally:
+                if turn is not None:
+                    turn[0].done(turn[1])
         return local
 
     def _latent_hw(self, hw):

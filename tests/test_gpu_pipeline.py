@@ -524,10 +524,15 @@ def _mp_worker(rank, world, port, q, hw=(64, 128)):
     g = torch.Generator(device="cuda:0").manual_seed(5)
     out = pipe(img, denoising_steps=2, ensemble_size=3, processing_res=0, color_map=None, show_progress_bar=False,
                generator=g)
+    # maps in flight with several ranks: two lanes per rank, the gathers issued in map order on both ranks (pipeline._Turnstile)
+    imgs = [syn.synthetic_image(hw[0], hw[1], seed=k) for k in range(5)]
+    gens = [torch.Generator(device="cuda:0").manual_seed(50 + k) for k in range(5)]
+    many = [o.depth_np for o in pipe.map_images(imgs, in_flight=2, generators=gens, denoising_steps=2, ensemble_size=3,
+                                                processing_res=0, color_map=None, show_progress_bar=False)]
     if rank == 0:
-        q.put(out.depth_np)
+        q.put((out.depth_np, many))
     else:
-        assert out.depth_np is None
+        assert out.depth_np is None and all(m is None for m in many) and len(many) == 5
     dist.barrier()
     dist.destroy_process_group()
 
@@ -553,11 +558,15 @@ def test_member_parallel_two_ranks_share_one_gpu(hw):
     procs = [ctx.Process(target=_mp_worker, args=(r, 2, port, q, hw)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=180)
+    got, many = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     pipe = M.build_synthetic_pipeline("depth", TINY_UNET, TINY_VAE, default_processing_resolution=0).to("cuda:0")
+    for k, m_ in enumerate(many):   # five maps, two in flight per rank, each equal to the single-process map of its image / seed
+        r_ = pipe(syn.synthetic_image(hw[0], hw[1], seed=k), denoising_steps=2, ensemble_size=3, processing_res=0, color_map=None,
+                  show_progress_bar=False, generator=torch.Generator(device="cuda:0").manual_seed(50 + k)).depth_np
+        assert m_.shape == tuple(hw) and np.abs(r_ - m_).max() < 2e-2, (k, float(np.abs(r_ - m_).max()))
     g = torch.Generator(device="cuda:0").manual_seed(5)
     ref = pipe(syn.synthetic_image(hw[0], hw[1], seed=0), denoising_steps=2, ensemble_size=3, processing_res=0,
                color_map=None, show_progress_bar=False, generator=g).depth_np
@@ -585,6 +594,11 @@ def _nccl_single_rank_worker(port, q):
         pipe.enable_member_parallel(root=0, force_collective=True)
         assert pipe._sharded()
         got = pipe(img, generator=torch.Generator(device="cuda:0").manual_seed(5), **kw).depth_np
+        # two maps in flight through the forced collective: two host threads / streams on ONE nccl communicator, their gathers
+        # serialised in map order
+        many = [o.depth_np for o in pipe.map_images([img] * 4, in_flight=2, generators=[torch.Generator(device="cuda:0").manual_seed(5)
+                                                                                      for _ in range(4)], **kw)]
+        assert all(np.array_equal(m_, ref) for m_ in many), "maps in flight through the nccl gather differ from the plain map"
         # the collective itself: rooted gather and all_gather of a member stack on the RCCL backend
         x = torch.rand(3, 1, 16, 24, device="cuda:0")
         a = md.gather_members(x, 3, (1, 16, 24), torch.device("cuda:0"), None, 0, force=True)
