@@ -460,10 +460,20 @@ class Builder:
         MFMAs do not hide: it pays when one workgroup covers all output channels (N <= 320) or when the separate
         pass would be HBM-bound on a tensor that no cache holds (profiles/r2_sweep3_patch_conv.log)."""
         mode = FUSE_GN
-        if mode != "auto":
+        if mode not in ("auto", "auto5"):
             return mode == "all"
         tiles_n = 1 if N in (128, 256, 320) else -(-N // (256 if N % 256 == 0 else 128))
-        return tiles_n == 1 or B * H * W * Cin * 2 >= (192 << 20)
+        if mode == "auto5":   # the rule of rounds 2-5 (A/B)
+            return tiles_n == 1 or B * H * W * Cin * 2 >= (192 << 20)
+        # Round 6, measured layer by layer with the norm fused everywhere / nowhere (profiles/r6_ab_fuse_gn_per_layer.log): the
+        # fix-up is VALU beside the MFMAs, the separate pass is HBM traffic - and with two maps in flight (section 6b) an HBM-bound
+        # pass runs under the other map's matrix work.  Fused wins on the VAE's 128 / 256-channel levels (tensors of 0.75-1.5 GB:
+        # +0.45 ... +0.97 ms per block unfused); it LOSES where the plain convolution gets a hand-placed four-wave kernel that the
+        # fused one does not - the UNet's 320-channel level from five members (-0.1 ... -0.66 ms per block) - and on the VAE's
+        # 512-channel 192 x 192 level (two output-channel tiles repeat the fix-up: -0.17 ... -0.24 ms per block).
+        if N == 320:
+            return B * -(-H // 12) * -(-W // 16) < 200
+        return tiles_n == 1
 
     def conv3x3p(self, srcs, name, cout, *, ss=None, silu=False, rowvec=None, residual=None, out=None, subpix=False):
         x = srcs[0]

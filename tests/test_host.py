@@ -336,9 +336,11 @@ def test_full_size_programs_validate_without_gpu():
     labelled = list(zip(prog.seq.ops, prog.seq.labels))
     fwd = labelled[prog.n_prologue_ops:prog.n_prologue_ops + prog.n_fwd_ops]
     folded = [op for op, lab in fwd if lab.endswith("conv2+conv_shortcut")]   # conv_shortcut as extra K of conv2 (implicit GEMM levels)
-    assert len(folded) == 11 and all(op.kind == L.OP_IGEMM and op.p[12] and op.i[32] % 64 == 0 and op.i[7] == 9 for op in folded)
-    assert sum(bool(op.p[13]) for op in folded) == 9          # the up blocks' [hidden | skip] pairs, never concatenated
-    assert [lab for _, lab in fwd if lab.endswith(".conv_shortcut")] == [f"up_blocks.3.resnets.{j}.conv_shortcut" for j in range(3)]
+    # (round 6: at ten members the 96 x 96 level's norms are separate passes and its plain convolutions run on the hand-placed GEMM
+    # tile - engine.fuse_norm_into_conv - so up_blocks.3's three shortcuts fold as well: 14 folded launches, no shortcut launch left)
+    assert len(folded) == 14 and all(op.kind == L.OP_IGEMM and op.p[12] and op.i[32] % 64 == 0 and op.i[7] == 9 for op in folded)
+    assert sum(bool(op.p[13]) for op in folded) == 12         # the up blocks' [hidden | skip] pairs, never concatenated
+    assert [lab for _, lab in fwd if lab.endswith(".conv_shortcut")] == []
     assert any(op.kind == L.OP_GN_STATS and op.p[6] and op.i[9] > 0 for op, _ in fwd)      # a skip concat's statistics: one launch
     assert not any(lab.endswith((".stats0", ".stats1")) for _, lab in fwd)
     assert [lab for _, lab in labelled[:prog.n_prologue_ops]].count("resnets.time_emb_proj") == 1
