@@ -47,6 +47,9 @@ def parse():
                     help="iid = the appearance model (albedo + material: UNet 12 -> 8 latent channels)")
     ap.add_argument("--scheduler", default="ddim", choices=["ddim", "lcm"], help="ddim = v1-1 (trailing, zero-SNR); lcm = depth-lcm-v1-0")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit operand type of the engine (fp32 accumulation): bf16 = the headline build; fp16 = libmarigold_hip_f16.so, "
+                         "the reference's --fp16 arithmetic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the denoising loop as a hipGraph")
@@ -364,7 +367,8 @@ def main():
     if args.kind == "iid":
         extra["target_properties"] = {"target_names": ["albedo", "material"], "albedo": {"prediction_space": "srgb"},
                                       "material": {"prediction_space": "stack"}}
-    pipe = cls(unet=UNet2DConditionModelHIP(usd, ucfg), vae=AutoencoderKLHIP(vsd, vcfg),
+    cdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    pipe = cls(unet=UNet2DConditionModelHIP(usd, ucfg, compute_dtype=cdt), vae=AutoencoderKLHIP(vsd, vcfg, compute_dtype=cdt),
                scheduler=DDIMScheduler() if args.scheduler == "ddim" else LCMScheduler(), empty_text_embed=ctx,
                default_denoising_steps=args.denoise,
                default_processing_resolution=0, **extra).to(dev)
@@ -481,8 +485,8 @@ def main():
                             "launches_per_map": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
                 # the PMC passes were collected for the headline workload only
                 try:
-                    headline = (args.kind, args.ensemble, args.denoise, args.res, args.scheduler, args.tiny) == \
-                        ("depth", 10, 10, 768, "ddim", False)
+                    headline = (args.kind, args.ensemble, args.denoise, args.res, args.scheduler, args.tiny, args.dtype) == \
+                        ("depth", 10, 10, 768, "ddim", False, "bf16")
                     t = pmc_traffic(dom) if headline else None
                     if t is not None:
                         roof["traffic"] = round(t["bytes_per_launch"])      # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)
@@ -578,7 +582,7 @@ def main():
             "metric": f"{args.kind} maps/sec @{args.res}x{args.res}, ens={args.ensemble}, {args.denoise} {args.scheduler.upper()} steps",
             "value": round(value, 4), "unit": f"{args.kind} maps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"marigold-{args.kind}-v1-1 architecture (SD-v2 UNet 865.9M + AutoencoderKL), "
                                     f"{args.res}x{args.res}, ensemble_size={args.ensemble}, {args.denoise} "
                                     + ("DDIM steps (trailing, zero-SNR, v-prediction)" if args.scheduler == "ddim" else "LCM steps")

@@ -256,6 +256,9 @@ typedef struct mg_program mg_program;
 
 /* Library / device */
 int mg_abi_version(void);
+/* The 16-bit operand type every "bf16" buffer of this build holds: 0 = bf16 (libmarigold_hip.so), 1 = IEEE fp16 (libmarigold_hip_f16.so,
+ * the same sources built with OPERAND_F16=1 - the reference's `--fp16` arithmetic, script/depth/run.py:203-211).  Same ABI, same ops. */
+int mg_operand_bits(void);
 const char* mg_last_error(void);
 int mg_init(int device);                 /* idempotent; allocates the zero page */
 /* GEGLU weight-row interleave the host must pack ff.net.0.proj with (32: 16 u rows, then their 16 gate rows). */

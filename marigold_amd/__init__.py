@@ -6,7 +6,7 @@ from .pipeline import (IIDEntry, MarigoldDepthOutput, MarigoldDepthPipeline,  # 
 MarigoldPipeline = MarigoldDepthPipeline  # for backward compatibility
 
 
-def build_synthetic_pipeline(kind="depth", unet_cfg=None, vae_cfg=None, scheduler=None, seed=1234, **kw):
+def build_synthetic_pipeline(kind="depth", unet_cfg=None, vae_cfg=None, scheduler=None, seed=1234, compute_dtype=None, **kw):
     """A pipeline on seeded synthetic weights in the real architecture (no checkpoints exist in
     this environment - BASELINE.md §4)."""
     from . import synthetic as syn
@@ -21,8 +21,10 @@ def build_synthetic_pipeline(kind="depth", unet_cfg=None, vae_cfg=None, schedule
         unet_cfg = unet_cfg or UNetConfig(in_channels=4 + 4 * n, out_channels=4 * n)
     unet_cfg = unet_cfg or UNetConfig()
     vae_cfg = vae_cfg or VAEConfig()
-    unet = UNet2DConditionModelHIP(syn.synthetic_unet_state_dict(unet_cfg, seed), unet_cfg)
-    vae = AutoencoderKLHIP(syn.synthetic_vae_state_dict(vae_cfg, seed), vae_cfg)
+    import torch
+    compute_dtype = compute_dtype or torch.bfloat16   # torch.float16: the fp16-operand build of the engine
+    unet = UNet2DConditionModelHIP(syn.synthetic_unet_state_dict(unet_cfg, seed), unet_cfg, compute_dtype=compute_dtype)
+    vae = AutoencoderKLHIP(syn.synthetic_vae_state_dict(vae_cfg, seed), vae_cfg, compute_dtype=compute_dtype)
     emb = syn.synthetic_text_embedding(unet_cfg.cross_attention_dim)
     scheduler = scheduler or DDIMScheduler()
     cls = {"depth": MarigoldDepthPipeline, "normals": MarigoldNormalsPipeline, "iid": MarigoldIIDPipeline}[kind]

@@ -32,7 +32,7 @@ POST_NONE, POST_DEPTH, POST_NORMALS, POST_UNIT, POST_SCHED = 0, 1, 2, 3, 4
 OP_NAMES = {v: k[3:].lower() for k, v in list(globals().items()) if k.startswith("OP_")}
 
 EXPORTS = [
-    "mg_abi_version", "mg_last_error", "mg_init", "mg_geglu_interleave", "mg_device_info", "mg_launch",
+    "mg_abi_version", "mg_operand_bits", "mg_last_error", "mg_init", "mg_geglu_interleave", "mg_device_info", "mg_launch",
     "mg_program_create", "mg_program_num_ops", "mg_program_run", "mg_program_validate", "mg_program_run_range",
     "mg_program_capture", "mg_program_profile", "mg_program_destroy", "mg_conv2d_igemm", "mg_conv3x3", "mg_conv3x3_gn_slots", "mg_flash4w_plan_test",
     "mg_sched_step", "mg_ensemble_normals", "mg_ens_align_cost_grad", "mg_bfgs_minimize", "mg_ens_align_minimize", "mg_event_create", "mg_event_record",
@@ -51,22 +51,27 @@ class MarigoldHipError(RuntimeError):
     pass
 
 
-_lib = None
+# The fp16-operand twin (csrc/Makefile: OPERAND_F16=1, same sources, same ABI): what the engine modules load for
+# torch_dtype=torch.float16 (the reference's --fp16, script/depth/run.py:203-211).  Its own globals, its own mg_init.
+LIB_PATH_F16 = os.environ.get("MARIGOLD_HIP_LIB_F16") or os.path.join(_HERE, "libmarigold_hip_f16.so")
+
+_libs = {}
 
 
-def load():
-    """Load the shared library (no GPU needed) and check that every ABI symbol is exported."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(f16=False):
+    """Load the shared library (no GPU needed) and check that every ABI symbol is exported.  ``f16``: the fp16-operand build."""
+    key = bool(f16)
+    if key in _libs:
+        return _libs[key]
+    path = LIB_PATH_F16 if key else LIB_PATH
+    if not os.path.exists(path):
         raise MarigoldHipError(
-            f"{LIB_PATH} not found: the HIP engine is not built. Run __graft_entry__.build() "
+            f"{path} not found: the HIP engine is not built. Run __graft_entry__.build() "
             f"(make -C marigold_amd/csrc). There is no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     missing = [s for s in EXPORTS if not hasattr(lib, s)]
     if missing:
-        raise MarigoldHipError(f"{LIB_PATH} lacks ABI symbols: {missing}")
+        raise MarigoldHipError(f"{path} lacks ABI symbols: {missing}")
     lib.mg_last_error.restype = ctypes.c_char_p
     lib.mg_launch.argtypes = [ctypes.POINTER(MgOp), ctypes.c_void_p]
     lib.mg_geglu_interleave.restype = ctypes.c_int
@@ -115,24 +120,29 @@ def load():
     lib.mg_event_elapsed_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
     lib.mg_event_destroy.argtypes = [ctypes.c_void_p]
     lib.mg_event_destroy.restype = None
+    lib.mg_operand_bits.restype = ctypes.c_int
     if lib.mg_abi_version() != ABI_VERSION:
         raise MarigoldHipError(f"ABI version mismatch: library {lib.mg_abi_version()}, binding {ABI_VERSION}")
-    _lib = lib
+    if bool(lib.mg_operand_bits() & 1) != key:
+        raise MarigoldHipError(f"{path} is the {'fp16' if lib.mg_operand_bits() & 1 else 'bf16'}-operand build")
+    lib._mg_f16 = key
+    _libs[key] = lib
     return lib
 
 
-def check(rc, what="libmarigold_hip"):
+def check(rc, what="libmarigold_hip", lib=None):
     if rc != 0:
-        raise MarigoldHipError(f"{what}: {load().mg_last_error().decode(errors='replace')}")
+        msgs = [(lib or l_).mg_last_error().decode(errors="replace") for l_ in ([lib] if lib is not None else list(_libs.values()) or [load()])]
+        raise MarigoldHipError(f"{what}: {' | '.join(m for m in msgs if m) or 'error'}")
 
 
 _inited = set()
 
 
-def init(device_index=0):
+def init(device_index=0, f16=False):
     """Bind the library to a GPU (one process drives one GPU)."""
-    lib = load()
-    if device_index not in _inited:
-        check(lib.mg_init(int(device_index)), "mg_init")
-        _inited.add(device_index)
+    lib = load(f16)
+    if (device_index, bool(f16)) not in _inited:
+        check(lib.mg_init(int(device_index)), "mg_init", lib)
+        _inited.add((device_index, bool(f16)))
     return lib

@@ -90,12 +90,16 @@ def load_pipeline(cls, path, variant=None, torch_dtype=None, **kw):
     vae_cfg = CC.vae_config_from_json(_json(os.path.join(path, "vae", "config.json")))
     if torch_dtype is not None and torch_dtype not in (torch.float32, torch.float16, torch.bfloat16):
         raise ValueError(f"torch_dtype={torch_dtype}: expected torch.float32, torch.float16 or torch.bfloat16")
-    if torch_dtype is not None and torch_dtype is not torch.bfloat16:
+    # torch_dtype=torch.float16 (the reference's --fp16, script/depth/run.py:203-211) runs the engine's fp16-operand build: the same
+    # kernels on fp16 operands with fp32 accumulation; torch.bfloat16 the product (bf16) build.  The reference's DEFAULT (fp32, or no
+    # torch_dtype) has no engine counterpart - the matrix cores take 16-bit operands - and runs the bf16 build, said once, loudly.
+    compute = torch.float16 if torch_dtype is torch.float16 else torch.bfloat16
+    if torch_dtype in (None, torch.float32):
         import logging
-        logging.warning(f"torch_dtype={torch_dtype}: the HIP engine computes in bf16 with fp32 accumulation whatever the checkpoint's "
-                        f"dtype and keeps latents / predictions in fp32; torch_dtype only selects the dtype of the noise draws")
-    unet = UNet2DConditionModelHIP(_weights(os.path.join(path, "unet"), variant), unet_cfg)
-    vae = AutoencoderKLHIP(_rename_legacy_vae_keys(_weights(os.path.join(path, "vae"), variant)), vae_cfg)
+        logging.warning("torch_dtype=float32 (or none): the HIP engine has no fp32-operand mode; it computes on bf16 operands with fp32 "
+                        "accumulation and keeps latents / predictions in fp32 (torch_dtype=torch.float16 selects fp16 operands)")
+    unet = UNet2DConditionModelHIP(_weights(os.path.join(path, "unet"), variant), unet_cfg, compute_dtype=compute)
+    vae = AutoencoderKLHIP(_rename_legacy_vae_keys(_weights(os.path.join(path, "vae"), variant)), vae_cfg, compute_dtype=compute)
     scfg = _json(os.path.join(path, "scheduler", "scheduler_config.json"))
     sname = scfg.get("_class_name", "DDIMScheduler")
     if sname not in _SCHEDULERS:

@@ -12,8 +12,8 @@ the same minus ``--color_map``):
             the folder flavour is picked from the checkpoint name like the reference does)
 
 Differences: the engine only runs on an MI355X (there is no CPU / MPS path: ``--apple_silicon`` is
-accepted and refused), and ``--half_precision`` selects the ``fp16`` weight variant of the checkpoint
-like the reference while the arithmetic is the engine's bf16/fp32-accumulate either way.
+accepted and refused); ``--half_precision`` / ``--fp16`` selects the ``fp16`` weight variant of the checkpoint AND the
+fp16-operand build of the engine (fp32 accumulation), like the reference; without it the engine computes on bf16 operands.
 """
 import argparse
 import logging

@@ -112,7 +112,7 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       a.sQ = op->l[0]; a.sK = op->l[1]; a.sVt = op->l[2]; a.sO = op->l[3];
       a.scale_log2 = op->f[0] * 1.4426950408889634f;
       a.dbg = (unsigned long long*)op->p[4];
-      a.redo_thr = op->f[1] > 0.f ? op->f[1] : 1.2676506e30f;   // 2^100 (tests force the fallback with a tiny value)
+      a.redo_thr = op->f[1] > 0.f ? op->f[1] : (MG_F16 ? 32768.0f : 1.2676506e30f);   // 2^100 (tests force the fallback with a tiny value)
       a.ws = op->p[5];                                            // variant 26: workspace of the key-split blocks (i[8] KB)
       a.ws_bytes = (long long)op->i[8] * 1024;
       a.split = op->i[9];

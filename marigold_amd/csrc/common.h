@@ -6,26 +6,76 @@
 #include <type_traits>
 #include "../../include/marigold_hip.h"
 
-typedef uint16_t bf16_t;  // raw bf16 bits
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// The 16-bit operand type of the build: bf16 (the product library, libmarigold_hip.so) or IEEE fp16 (libmarigold_hip_f16.so, built
+// from the same sources with -DMG_OPERAND_F16_BUILD=1: what the reference computes with `--fp16` / torch_dtype=torch.float16,
+// script/depth/run.py:203-211).  Same MFMA rate (v_mfma_f32_32x32x16_f16), three more mantissa bits, five fewer exponent bits:
+// every conversion, unpack and matrix instruction of the kernels goes through the helpers below, so the kernels are written once.
+// The names keep "bf16" (the product type); in the fp16 build they hold fp16 bits.
+constexpr bool MG_F16 = MG_OPERAND_F16_BUILD != 0;
+typedef uint16_t bf16_t;  // raw operand bits
+typedef std::conditional_t<MG_F16, _Float16, __bf16> mg_op16_t;
+typedef __attribute__((ext_vector_type(8))) mg_op16_t bf16x8;
+typedef __attribute__((ext_vector_type(2))) mg_op16_t mg_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float mg_f32x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// mnemonics for the hand-placed instruction streams (csrc/gen_*.py emit them as adjacent string literals)
+#if MG_OPERAND_F16_BUILD
+#define MG_MFMA32_ASM "v_mfma_f32_32x32x16_f16"
+#define MG_CVT_PK_ASM "v_cvt_pk_f16_f32"
+#else
+#define MG_MFMA32_ASM "v_mfma_f32_32x32x16_bf16"
+#define MG_CVT_PK_ASM "v_cvt_pk_bf16_f32"
+#endif
+constexpr float MG_OP16_MAX = MG_F16 ? 65504.0f : 3.3895314e38f;   // largest finite operand value
+
+typedef __attribute__((ext_vector_type(8))) _Float16 mg_f16x8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 mg_bf16x8_t;
+__device__ __forceinline__ f32x16 mg_mfma32(bf16x8 a, bf16x8 b, f32x16 c) {   // D = A (32 x 16) B (16 x 32) + C
+  if constexpr (MG_F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mg_f16x8_t, a), __builtin_bit_cast(mg_f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mg_bf16x8_t, a), __builtin_bit_cast(mg_bf16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  if constexpr (MG_F16) return (float)__builtin_bit_cast(_Float16, v);
+  else return __uint_as_float(((uint32_t)v) << 16);
+}
+// two fp32 -> packed operands (round to nearest even) in one instruction: v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32; the fp16 form
+// saturates at +-65504 first (a bf16 value of 1e5 is a number, an fp16 inf poisons every sum it enters)
+__device__ __forceinline__ uint32_t cvt_pk_bf16_f32(float lo, float hi) {
+  if constexpr (MG_F16) {
+    lo = __builtin_amdgcn_fmed3f(lo, -MG_OP16_MAX, MG_OP16_MAX);
+    hi = __builtin_amdgcn_fmed3f(hi, -MG_OP16_MAX, MG_OP16_MAX);
+  }
+  mg_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mg_bf16x2_t));
+}
 __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  if constexpr (MG_F16) return (bf16_t)(cvt_pk_bf16_f32(f, 0.f) & 0xffffu);
   uint32_t u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  if constexpr (MG_F16) return cvt_pk_bf16_f32(lo, hi);
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
-__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float bflo(uint32_t w) {
+  if constexpr (MG_F16) return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+  else return __uint_as_float(w << 16);
+}
+__device__ __forceinline__ float bfhi(uint32_t w) {
+  if constexpr (MG_F16) return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+  else return __uint_as_float(w & 0xffff0000u);
+}
+constexpr uint32_t MG_OP16_ONE_X2 = MG_F16 ? 0x3c003c00u : 0x3f803f80u;   // (1.0, 1.0) as packed operands
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // GELU (diffusers GEGLU: F.gelu, exact-erf form) with the Gaussian CDF as an odd polynomial, Phi(x) = 1/2 + x P(x^2) on |x| <= 4 (degree 6 in x^2,
 // |error| <= 1.1e-4 on Phi, <= 4e-4 on x Phi(x) inside the interval - an eighth of a bf16 rounding step of the result -
@@ -54,13 +104,6 @@ __device__ __forceinline__ void half_swap(float g0, float g1, float& first, floa
   second = __uint_as_float(r[1]);
 }
 
-// v_cvt_pk_bf16_f32: two fp32 -> packed bf16 (round to nearest even) in one instruction
-typedef __attribute__((ext_vector_type(2))) __bf16 mg_bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) float mg_f32x2_t;
-__device__ __forceinline__ uint32_t cvt_pk_bf16_f32(float lo, float hi) {
-  mg_f32x2_t v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mg_bf16x2_t));
-}
 __device__ __forceinline__ float silu_fast_f(float x) {  // x * sigmoid(x): one v_exp, one v_rcp
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }

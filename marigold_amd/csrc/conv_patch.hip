@@ -301,7 +301,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_patch_kernel(const ConvPAr
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = mg_mfma32(fb[ni], fa[mi], acc[ni][mi]);
     }
     if (++t == T) { t = 0; ++c; }
     if constexpr (ISSUE) { if (++ti == T) { ti = 0; ++ci; } }
@@ -478,7 +478,7 @@ int mg_conv3x3_auto_variant(int N, int subpix, int B, int H, int W, int has_ss, 
     static const int cp4 = mg_tuning_int("MARIGOLD_CP4W", 1);
     const long long par = subpix ? 4 : 1;
     if (cp4 && allow4w && N % 320 == 0 && !subpix && (long long)B * ((H + 11) / 12) * ((W + 15) / 16) * (N / 320) >= 200 &&
-        (!has_ss || (Cin >= 640 && Cin <= 1024)))
+        (!has_ss || (!MG_F16 && Cin >= 640 && Cin <= 1024)))   // (the in-stream fix-up unpacks bf16: plain convolutions only in the fp16 build)
       return 11;
     if (cp4 && allow4w && N % 256 == 0 && !has_ss && (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * (N / 256) * par >= 512 && (!subpix || N >= 512))
       return 10;

@@ -109,6 +109,7 @@ int launch4w(const ConvPArgs& a0, void (*plain)(const ConvPArgs), void (*fixed)(
   MG_REQUIRE(LDS <= 160 * 1024, "conv3x3: %d input channels exceed the four-wave tile's LDS budget with the fused norm", a.Cin);
   MG_REQUIRE(a.N % BN == 0, "conv3x3: the four-wave tile needs N %% %d == 0", BN);
   MG_REQUIRE(!a.ss || a.silu, "conv3x3: the four-wave tile's fused norm includes the SiLU");
+  MG_REQUIRE(!a.ss || !MG_F16, "conv3x3: the four-wave tile's in-stream fix-up unpacks bf16 (the fp16 build runs the fused norm on the 12-wave tiles)");
   MG_REQUIRE(!a.gn_part, "conv3x3: the four-wave tiles do not produce output statistics (p[8]: mg_conv3x3_gn_slots() returns 0 for them)");
   MG_REQUIRE((long long)a.B * a.H * a.W * (a.lda0 > a.lda1 ? a.lda0 : a.lda1) < (1ll << 30) && (long long)a.N * a.ldw < (1ll << 30),
              "conv3x3: the four-wave tile addresses its operands with 31-bit byte offsets");

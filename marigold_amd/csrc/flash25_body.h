@@ -72,7 +72,7 @@ __device__ __forceinline__ void fa25_body(const FaArgs& a, char* smem, const int
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; osum[r] = 0.f; }
   fa_f32x2 l2 = {0.f, 0.f};
-  const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(MG_OP16_ONE_X2, MG_OP16_ONE_X2, MG_OP16_ONE_X2, MG_OP16_ONE_X2));
 
   const int nkt = (a.Ntok + FA_KB - 1) / FA_KB;
   const bool ragged_end = (a.Ntok & (FA_KB - 1)) != 0;
@@ -100,7 +100,7 @@ __device__ __forceinline__ void fa25_body(const FaArgs& a, char* smem, const int
       for (int ks = 0; ks < 4; ++ks) {
         const int q = ks * 2 + half;
         const bf16x8 kf = __builtin_bit_cast(bf16x8, *(const uint4*)(sK + row * 128 + ((q ^ ((row >> 1) & 7)) << 4)));
-        s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? negm : s[t2], 0, 0, 0);
+        s[t2] = mg_mfma32(kf, qf[ks], ks == 0 ? negm : s[t2]);
       }
     }
     const int kbase = kt * FA_KB;
@@ -170,9 +170,9 @@ __device__ __forceinline__ void fa25_body(const FaArgs& a, char* smem, const int
           const int row = dt * 32 + l31;
           const int c0 = 4 * t2 + 2 * sh + half;
           const uint4 vw = *(const uint4*)(sV + row * 128 + ((c0 ^ ((row >> 1) & 7)) << 4));
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
+          o[dt] = mg_mfma32(__builtin_bit_cast(bf16x8, vw), pf, o[dt]);
         }
-        if constexpr (SUMM == 1) osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, osum, 0, 0, 0);
+        if constexpr (SUMM == 1) osum = mg_mfma32(ones, pf, osum);
       }
     }
   };

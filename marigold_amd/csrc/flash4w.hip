@@ -35,6 +35,11 @@
 #include "flash25_body.h"
 #include "flash4w.inc"
 
+// fp16 build: probabilities are fp16 (max 65504) where bf16 reaches 2^127 - the reference sits 2^6 above the first keys' maximum
+// (p = 2^(s - max32 - 6): scores may top the first 32 keys' maximum by 2^21 before the row sums reach the 2^15 that sends the
+// workgroup to the running-maximum loop; fp16 subnormals keep 2^-24), every piece of a split block still computes the same reference
+constexpr float F4_REF_BIAS = MG_F16 ? 6.0f : 0.0f;
+
 // the score set Y of the stream (v[160:191]): physical registers, scratch to the compiler
 #define F4_CLOBBER_Y "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", \
                      "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191"
@@ -48,7 +53,7 @@ constexpr int F4_PART_BYTES = 4 * (16384 + 1024);               // one piece's p
 constexpr int F4_CTR_BYTES = 4096;                             // tickets (zero between launches) in front of the partial results
 
 __device__ __forceinline__ void f4_mfma(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  asm volatile(MG_MFMA32_ASM " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void f4_dma(unsigned voff, i32x4 srd, unsigned soff, unsigned m0v) {
   asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(srd), "s"(soff), "s"(m0v) : "memory");
@@ -161,7 +166,7 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
     for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[q][r], s[q][r + 1]));
     float x0, x1;
     half_swap(mx, mx, x0, x1);
-    ref[q] = fmaxf(x0, x1);
+    ref[q] = fmaxf(x0, x1) + F4_REF_BIAS;
   }
   if (t0 != 0) first_scores(F4_PRE + 4096);   // (wave-uniform)
 #pragma unroll
@@ -277,33 +282,23 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
   }
   if (!finish) return;   // (workgroup-uniform)
   // ---- finalize: O[q][d] = o^T / l; lane^32 exchange -> 8 consecutive d per lane, 16-byte stores ----
+  // A block whose reference was too low (row sums >= redo_thr - 2^100, 2^15 in the fp16 build - or not finite) redoes its 256 queries
+  // with the running-maximum form (two blocks of 128) INSTEAD of storing: decided for the whole workgroup before anything is stored
+  // (round 6: the fixed-reference result used to be stored first and overwritten - two stores of one address from different waves
+  // with only a barrier between them; in the fp16 build, where an overflowed probability is inf, the stale store showed).
   bool bad = false;
+  float inv[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     float la, lb;
     half_swap(ll[q], ll[q], la, lb);
     const float l_tot = la + lb;
-    bad = bad || !(l_tot < a.redo_thr);   // 2^100 (or not finite): a score topped the reference by about that much
-    const float inv = 1.0f / l_tot;
-    const int q_row = qb * 256 + wave * 64 + q * 32 + l31;
-    bf16_t* orow = a.O + (long long)b * a.sO + (long long)q_row * a.ldo + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) half_swap(o[q][dt][8 * gp + j] * inv, o[q][dt][8 * gp + 4 + j] * inv, v[j], v[4 + j]);
-        uint4 pk;
-        pk.x = cvt_pk_bf16_f32(v[0], v[1]); pk.y = cvt_pk_bf16_f32(v[2], v[3]);
-        pk.z = cvt_pk_bf16_f32(v[4], v[5]); pk.w = cvt_pk_bf16_f32(v[6], v[7]);
-        *(uint4*)(orow + dt * 32 + 16 * gp + 8 * half) = pk;
-      }
+    bad = bad || !(l_tot < a.redo_thr);
+    inv[q] = 1.0f / l_tot;
   }
-  if (dbgw && lane == 0) dbgw[7] = __builtin_amdgcn_s_memrealtime();
-  // a block whose reference was too low redoes its 256 queries with the running-maximum form (two blocks of 128)
   __syncthreads();   // (no __syncthreads_or: its static LDS word would move the ring off LDS address 0)
-  if (lane == 0) ((int*)smem)[wave] = __any(bad) ? 1 : 0;
+  const int wave_bad = __any(bad) ? 1 : 0;   // over ALL lanes (inside `if (lane == 0)` the vote would see lane 0 alone - the form of rounds 4-5)
+  if (lane == 0) ((int*)smem)[wave] = wave_bad;
   __syncthreads();
   const int4 flags = *(const int4*)smem;
   __syncthreads();
@@ -312,7 +307,26 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
     __syncthreads();
     fa25_body<4, true, 2>(a, smem, 2 * qb + 1, bh);
     __syncthreads();
+    return;
   }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int q_row = qb * 256 + wave * 64 + q * 32 + l31;
+    bf16_t* orow = a.O + (long long)b * a.sO + (long long)q_row * a.ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) half_swap(o[q][dt][8 * gp + j] * inv[q], o[q][dt][8 * gp + 4 + j] * inv[q], v[j], v[4 + j]);
+        uint4 pk;
+        pk.x = cvt_pk_bf16_f32(v[0], v[1]); pk.y = cvt_pk_bf16_f32(v[2], v[3]);
+        pk.z = cvt_pk_bf16_f32(v[4], v[5]); pk.w = cvt_pk_bf16_f32(v[6], v[7]);
+        *(uint4*)(orow + dt * 32 + 16 * gp + 8 * half) = pk;
+      }
+  }
+  if (dbgw && lane == 0) dbgw[7] = __builtin_amdgcn_s_memrealtime();
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn64_4w_kernel(const FaArgs a) {

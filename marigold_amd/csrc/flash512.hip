@@ -32,7 +32,7 @@ struct Fa5Args {
 
 constexpr int FA5_D = 512, FA5_KB = 32, FA5_QB = 128;
 constexpr int FA5_KTILE = FA5_KB * FA5_D * 2, FA5_STAGE = 2 * FA5_KTILE;   // K tile + V^T tile: 64 KB
-constexpr float FA5_THR = 60.0f;
+constexpr float FA5_THR = MG_F16 ? 15.0f : 60.0f;   // log2 units over the reference before a retry (fp16 probabilities must stay below 65504)
 
 __device__ __forceinline__ uint32_t fa5_cvt_pk(float lo, float hi) { return cvt_pk_bf16_f32(lo, hi); }
 
@@ -41,10 +41,10 @@ __device__ __forceinline__ uint32_t fa5_cvt_pk(float lo, float hi) { return cvt_
 // accumulators), o + s + s1 + negm = 304 "accumulator" registers did not fit the 256 AGPRs and it spilled Q: one scratch
 // reload per MFMA.  hipcc does not see an asm MFMA's latency: the consumers below are fenced with s_nop by hand.
 __device__ __forceinline__ void fa5_mfma_v(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  asm volatile(MG_MFMA32_ASM " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void fa5_mfma_a(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  asm volatile(MG_MFMA32_ASM " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void fa5_mfma_drain() {   // an 8-pass MFMA's result: 11 wait states before a VALU may read it
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");

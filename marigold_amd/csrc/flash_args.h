@@ -25,7 +25,7 @@ constexpr int FA_STAGE = 2 * FA_KB * 128;  // K tile + V^T tile, bytes
 constexpr int FA2_NSTAGE = 3;
 constexpr float FA3_THR = 3.0f;         // log2 units: the running max is raised when a row max exceeds it by > 2^3
 typedef __attribute__((ext_vector_type(2))) float fa_f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 fa_bf16x2_t;
+typedef mg_bf16x2_t fa_bf16x2_t;   // (common.h: bf16, or fp16 in the fp16 build; probabilities need no saturation)
 typedef __attribute__((ext_vector_type(2))) float fa_f32x2_t;
 __device__ __forceinline__ uint32_t fa_cvt_pk(float lo, float hi) {
   fa_f32x2_t v = {lo, hi};

@@ -202,6 +202,16 @@ def block(kind, queue):
     return st.out, st.queue
 
 
+
+def c_literal(ln):
+    """One instruction as a C string literal; the operand-type mnemonics come from common.h (MG_MFMA32_ASM, MG_CVT_PK_ASM: bf16 in the
+    product build, fp16 in the fp16 build) as adjacent literals."""
+    for mnem, macro in (("v_mfma_f32_32x32x16_bf16", "MG_MFMA32_ASM"), ("v_cvt_pk_bf16_f32", "MG_CVT_PK_ASM")):
+        if ln.startswith(mnem + " "):
+            return macro + ' "' + ln[len(mnem):]
+    return '"' + ln
+
+
 def main():
     lines = ["s_waitcnt lgkmcnt(0)"]
     lines += vgroup(X[0], "%[l00]", "%[l01]")
@@ -230,7 +240,7 @@ def main():
                 % (n_mfma, n_valu, n_lds, len(full)))
         f.write("#define FA4W_ASM \\\n")
         for x in lines:
-            f.write('  "%s\\n\\t" \\\n' % x)
+            f.write('  %s\\n\\t" \\\n' % c_literal(x))
         f.write('  ""\n')
 
 

@@ -118,10 +118,20 @@ def prologue():
     return reads(0) + reads(1) + toggles(0) + toggles(1)
 
 
+
+def c_literal(ln):
+    """One instruction as a C string literal; the operand-type mnemonics come from common.h (MG_MFMA32_ASM, MG_CVT_PK_ASM: bf16 in the
+    product build, fp16 in the fp16 build) as adjacent literals."""
+    for mnem, macro in (("v_mfma_f32_32x32x16_bf16", "MG_MFMA32_ASM"), ("v_cvt_pk_bf16_f32", "MG_CVT_PK_ASM")):
+        if ln.startswith(mnem + " "):
+            return macro + ' "' + ln[len(mnem):]
+    return '"' + ln
+
+
 def emit(name, lines):
     out = [f"#define {name} \\"]
     for ln in lines:
-        out.append(f'  "{ln}\\n" \\')
+        out.append(f'  {c_literal(ln)}\\n" \\')
     out.append('  ""')
     return "\n".join(out)
 

@@ -30,8 +30,10 @@ constexpr int HC_CK = 32;          // channels per LDS pass
 constexpr int HC_PS = 80;          // bytes per patch pixel in LDS: 64 of data + 16 (a 16-lane read group then hits every bank once)
 constexpr int HC_TW = 16;
 
-__device__ __forceinline__ float hc_dot2(uint32_t a, uint32_t b, float c) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hc_v2bf16, a), __builtin_bit_cast(hc_v2bf16, b), c, false);
+typedef _Float16 hc_v2f16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float hc_dot2(uint32_t a, uint32_t b, float c) {   // v_dot2c_f32_bf16 / v_dot2c_f32_f16
+  if constexpr (MG_F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(hc_v2f16, a), __builtin_bit_cast(hc_v2f16, b), c, false);
+  else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hc_v2bf16, a), __builtin_bit_cast(hc_v2bf16, b), c, false);
 }
 
 template <int COUT, int PPT>

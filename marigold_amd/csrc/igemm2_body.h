@@ -61,12 +61,7 @@ struct Igemm2Args {
   double inv_c2;
 };
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {  // v_cvt_pk_bf16_f32 (RNE)
-  f32x2_t v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return cvt_pk_bf16_f32(lo, hi); }   // (common.h: RNE; the fp16 build saturates)
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -359,9 +354,9 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         if constexpr (!TRANS)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = mg_mfma32(fb[ni], fa[mi], acc[ni][mi]);
         else
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = mg_mfma32(fa[mi], fb[ni], acc[ni][mi]);
       }
   };
 
@@ -645,9 +640,9 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           if constexpr (!TRANS)
-            acc[ni][pair * 2 + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni][ks], fa[m][ks], acc[ni][pair * 2 + m], 0, 0, 0);
+            acc[ni][pair * 2 + m] = mg_mfma32(fb[ni][ks], fa[m][ks], acc[ni][pair * 2 + m]);
           else
-            acc[ni][pair * 2 + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][ks], fb[ni][ks], acc[ni][pair * 2 + m], 0, 0, 0);
+            acc[ni][pair * 2 + m] = mg_mfma32(fa[m][ks], fb[ni][ks], acc[ni][pair * 2 + m]);
         }
       }
       if constexpr (!(PPOPT & 1)) __builtin_amdgcn_s_setprio(0);
@@ -974,7 +969,7 @@ __device__ __forceinline__ void igemm2_body(const Igemm2Args& a) {
           for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb)
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u][kb]), pf[kb], acc2, 0, 0, 0);
+            acc2 = mg_mfma32(__builtin_bit_cast(bf16x8, wf[u][kb]), pf[kb], acc2);
           float ps = 0.f, pq = 0.f;
 #pragma unroll
           for (int gp = 0; gp < 2; ++gp) {

@@ -214,8 +214,8 @@ void rowgemm_kernel(const RgArgs a) {
         for (int s = 0; s < KS; ++s) {
           const bf16x8 w0 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + s * 1024));
           const bf16x8 w1 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + (KS + s) * 1024));
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s], acc1, 0, 0, 0);
+          acc0 = mg_mfma32(w0, xf[s], acc0);
+          acc1 = mg_mfma32(w1, xf[s], acc1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -253,8 +253,8 @@ void rowgemm_kernel(const RgArgs a) {
         for (int s = 0; s < 4; ++s) {
           const bf16x8 w0 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + S0 + ((jj * 2 + 0) * 4 + s) * 1024));
           const bf16x8 w1 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + S0 + ((jj * 2 + 1) * 4 + s) * 1024));
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, pf[s], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pf[s], acc1, 0, 0, 0);
+          acc0 = mg_mfma32(w0, pf[s], acc0);
+          acc1 = mg_mfma32(w1, pf[s], acc1);
         }
         float ps = 0.f, pq = 0.f;
 #pragma unroll
@@ -357,11 +357,11 @@ void rowgemm_kernel(const RgArgs a) {
       if constexpr (TS == 2) rg_lgk<2 * ahead>(w0[s % PR], w1[s % PR]);
       else rg_lgk<ahead>(w0[s % PR], w0[s % PR == 0 ? 1 : 0]);
       if constexpr (!vsec) {
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[s % PR], xf[s], accA, 0, 0, 0);
-        if constexpr (TS == 2) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[s % PR], xf[s], accB, 0, 0, 0);
+        accA = mg_mfma32(w0[s % PR], xf[s], accA);
+        if constexpr (TS == 2) accB = mg_mfma32(w1[s % PR], xf[s], accB);
       } else {
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w0[s % PR], accA, 0, 0, 0);
-        if constexpr (TS == 2) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], w1[s % PR], accB, 0, 0, 0);
+        accA = mg_mfma32(xf[s], w0[s % PR], accA);
+        if constexpr (TS == 2) accB = mg_mfma32(xf[s], w1[s % PR], accB);
       }
     });
   };
@@ -572,8 +572,8 @@ void rowgemm_xattn_kernel(const RgXArgs a) {
     for (int s = 0; s < KS; ++s) {
       const bf16x8 w0 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + s * 1024));
       const bf16x8 w1 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + (KS + s) * 1024));
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s], acc1, 0, 0, 0);
+      acc0 = mg_mfma32(w0, xf[s], acc0);
+      acc1 = mg_mfma32(w1, xf[s], acc1);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -614,8 +614,8 @@ void rowgemm_xattn_kernel(const RgXArgs a) {
     for (int s = 0; s < 4; ++s) {
       const bf16x8 w0 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + S0 + ((jj * 2 + 0) * 4 + s) * 1024));
       const bf16x8 w1 = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + S0 + ((jj * 2 + 1) * 4 + s) * 1024));
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, pf[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pf[s], acc1, 0, 0, 0);
+      acc0 = mg_mfma32(w0, pf[s], acc0);
+      acc1 = mg_mfma32(w1, pf[s], acc1);
     }
     float ps = 0.f, pq = 0.f;
 #pragma unroll
@@ -715,8 +715,8 @@ __global__ __launch_bounds__(256) void rowgemm_xattn_ksplit_kernel(const RgXkArg
     for (int s = 0; s < KSQ; ++s) {
       const bf16x8 w0 = *(const bf16x8*)(wq + s * 1024);
       const bf16x8 w1 = *(const bf16x8*)(wq + (KSQ + s) * 1024);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s], acc1, 0, 0, 0);
+      acc0 = mg_mfma32(w0, xf[s], acc0);
+      acc1 = mg_mfma32(w1, xf[s], acc1);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { part[wave][r][lane] = acc0[r]; part[wave][16 + r][lane] = acc1[r]; }
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256) void rowgemm_xattn_ksplit_kernel(const RgXkArg
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const bf16x8 w = *(const bf16x8*)(wv + (tt * 4 + s) * 1024);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, pf[s], acc, 0, 0, 0);
+      acc = mg_mfma32(w, pf[s], acc);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {

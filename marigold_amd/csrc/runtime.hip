@@ -75,6 +75,7 @@ static int dispatch(const mg_op* op, hipStream_t s) {
 extern "C" {
 
 int mg_abi_version(void) { return MG_ABI_VERSION; }
+int mg_operand_bits(void) { return MG_F16 ? 1 : 0; }
 
 int mg_geglu_interleave(void) { return 32; }
 const char* mg_last_error(void) { return g_err; }
@@ -260,8 +261,8 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* ou
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {   // two independent accumulator chains: the pipe issues one MFMA per 32 cycles
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
+      asm volatile(MG_MFMA32_ASM " %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
+      asm volatile(MG_MFMA32_ASM " %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
     }
   }
   const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();

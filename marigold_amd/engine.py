@@ -98,9 +98,10 @@ class Pool:
 class WeightStore:
     """Device-resident, kernel-ready weights derived from a diffusers-layout state dict."""
 
-    def __init__(self, sd, device):
+    def __init__(self, sd, device, dtype=torch.bfloat16):
         self.sd = sd
         self.device = device
+        self.dtype = dtype   # the 16-bit operand type of the library build these weights feed (bf16, or fp16: libmarigold_hip_f16.so)
         self.cache = {}
         self._lock = threading.RLock()   # engine replicas (modules._EngineModule.replica) build their programs from one store
 
@@ -114,7 +115,7 @@ class WeightStore:
         return f"{name}.weight" in self.sd
 
     def conv3x3(self, name):
-        return self._memo(("c3", name), lambda: Wm.bf16(Wm.pack_conv3x3(self.sd[f"{name}.weight"].float()), self.device))
+        return self._memo(("c3", name), lambda: Wm.bf16(Wm.pack_conv3x3(self.sd[f"{name}.weight"].float()), self.device, self.dtype))
 
     def conv3x3_fold(self, name, shortcut):
         """conv3x3 ``name`` with the 1x1 convolution ``shortcut`` of another tensor folded in as extra K (MG_OP_IGEMM p[12]):
@@ -123,16 +124,16 @@ class WeightStore:
             ws_ = self.sd[f"{shortcut}.weight"].float()
             w = torch.cat([Wm.pack_conv3x3(self.sd[f"{name}.weight"].float()), ws_.reshape(ws_.shape[0], -1)], dim=1)
             b = self.sd[f"{name}.bias"].float() + self.sd[f"{shortcut}.bias"].float()
-            return Wm.bf16(w, self.device), Wm.f32(b, self.device)
+            return Wm.bf16(w, self.device, self.dtype), Wm.f32(b, self.device)
         return self._memo(("c3f", name), f)
 
     def conv3x3_subpix(self, name):
-        return self._memo(("c3s", name), lambda: Wm.bf16(Wm.pack_conv3x3_subpix(self.sd[f"{name}.weight"].float()), self.device))
+        return self._memo(("c3s", name), lambda: Wm.bf16(Wm.pack_conv3x3_subpix(self.sd[f"{name}.weight"].float()), self.device, self.dtype))
 
     def mat(self, name):  # Linear or 1x1 conv -> [N][K]
         def f():
             w = self.sd[f"{name}.weight"].float()
-            return Wm.bf16(w.reshape(w.shape[0], -1), self.device)
+            return Wm.bf16(w.reshape(w.shape[0], -1), self.device, self.dtype)
         return self._memo(("m", name), f)
 
     def vec(self, key):
@@ -162,7 +163,7 @@ class WeightStore:
             w[:co] = Wm.pack_conv3x3(w4.float())
             b = torch.zeros(npad)
             b[:co] = bias.float()
-            return Wm.bf16(w, self.device), Wm.f32(b, self.device)
+            return Wm.bf16(w, self.device, self.dtype), Wm.f32(b, self.device)
         return self._memo(("scm", key), f)
 
     def conv_in_mfma(self, name):
@@ -174,7 +175,7 @@ class WeightStore:
             kp = (k + 63) // 64 * 64
             wp = torch.zeros(w.shape[0], kp)
             wp[:, :k] = Wm.pack_conv3x3(w)
-            return Wm.bf16(wp, self.device), kp
+            return Wm.bf16(wp, self.device, self.dtype), kp
         return self._memo(("cim", name), f)
 
     def qkv(self, prefix, with_bias):
@@ -183,7 +184,7 @@ class WeightStore:
             b = None
             if with_bias:
                 b = Wm.f32(torch.cat([self.sd[f"{prefix}.{q}.bias"].float() for q in ("to_q", "to_k", "to_v")]), self.device)
-            return Wm.bf16(w, self.device), b
+            return Wm.bf16(w, self.device, self.dtype), b
         return self._memo(("qkv", prefix), f)
 
     # ---- Linear layers with the preceding LayerNorm folded in (weights.fold_layernorm) ----
@@ -193,14 +194,14 @@ class WeightStore:
     def qkv_ln(self, prefix, norm):
         def f():
             w = Wm.pack_qkv(*(self.sd[f"{prefix}.{q}.weight"].float() for q in ("to_q", "to_k", "to_v")))
-            wp, g, c = Wm.fold_layernorm(w, None, *self._ln(norm))
+            wp, g, c = Wm.fold_layernorm(w, None, *self._ln(norm), dtype=self.dtype)
             return wp.to(self.device), Wm.f32(g, self.device), Wm.f32(c, self.device)
         return self._memo(("qkv_ln", prefix), f)
 
     def geglu_ln(self, name, norm):
         def f():
             w, b = Wm.pack_geglu(self.sd[f"{name}.weight"].float(), self.sd[f"{name}.bias"].float())
-            wp, g, c = Wm.fold_layernorm(w, b, *self._ln(norm))
+            wp, g, c = Wm.fold_layernorm(w, b, *self._ln(norm), dtype=self.dtype)
             return wp.to(self.device), Wm.f32(g, self.device), Wm.f32(c, self.device)
         return self._memo(("gg_ln", name), f)
 
@@ -210,22 +211,22 @@ class WeightStore:
             w = self.sd[f"{name}.weight"].float()
             w = w.reshape(w.shape[0], -1)
             b = self.sd[f"{name}.bias"].float() if f"{name}.bias" in self.sd else torch.zeros(w.shape[0])
-            return Wm.pack_rowgemm(w, b).to(self.device)
+            return Wm.pack_rowgemm(w, b, dtype=self.dtype).to(self.device)
         return self._memo(("rg_m", name), f)
 
     def rg_qkv_ln(self, prefix, norm):
         def f():
             w = Wm.pack_qkv(*(self.sd[f"{prefix}.{q}.weight"].float() for q in ("to_q", "to_k", "to_v")))
-            wp, g, c = Wm.fold_layernorm(w, None, *self._ln(norm))
-            return Wm.pack_rowgemm(wp.float(), c, g).to(self.device)
+            wp, g, c = Wm.fold_layernorm(w, None, *self._ln(norm), dtype=self.dtype)
+            return Wm.pack_rowgemm(wp.float(), c, g, dtype=self.dtype).to(self.device)
         return self._memo(("rg_qkv_ln", prefix), f)
 
     def rg_geglu_ln(self, name, norm):
         def f():
             w, b = self.sd[f"{name}.weight"].float(), self.sd[f"{name}.bias"].float()
             order = Wm.rowgemm_geglu_order(w.shape[0])
-            wp, g, c = Wm.fold_layernorm(w[order], b[order], *self._ln(norm))
-            return Wm.pack_rowgemm(wp.float(), c, g).to(self.device)
+            wp, g, c = Wm.fold_layernorm(w[order], b[order], *self._ln(norm), dtype=self.dtype)
+            return Wm.pack_rowgemm(wp.float(), c, g, dtype=self.dtype).to(self.device)
         return self._memo(("rg_gg_ln", name), f)
 
     def rg_cross_ln(self, prefix, ctx, heads, norm):
@@ -234,9 +235,9 @@ class WeightStore:
                 self.sd[f"{prefix}.to_q.weight"], self.sd[f"{prefix}.to_k.weight"],
                 self.sd[f"{prefix}.to_v.weight"], self.sd[f"{prefix}.to_out.0.weight"], ctx, heads)
             assert npad == 64
-            wp, g, c = Wm.fold_layernorm(wqk, None, *self._ln(norm))
+            wp, g, c = Wm.fold_layernorm(wqk, None, *self._ln(norm), dtype=self.dtype)
             pack = Wm.pack_rowgemm_xattn if wqk.shape[1] == 320 else Wm.pack_rowgemm_xattn_ksplit
-            return pack(wp.float(), c, g, vot, self.sd[f"{prefix}.to_out.0.bias"].float()).to(self.device)
+            return pack(wp.float(), c, g, vot, self.sd[f"{prefix}.to_out.0.bias"].float(), dtype=self.dtype).to(self.device)
         return self._memo(("rg_x_ln", prefix), f)
 
     def cross_ln(self, prefix, ctx, heads, norm):
@@ -244,8 +245,8 @@ class WeightStore:
             wqk, vot, npad = Wm.cross_attention_tables(
                 self.sd[f"{prefix}.to_q.weight"], self.sd[f"{prefix}.to_k.weight"],
                 self.sd[f"{prefix}.to_v.weight"], self.sd[f"{prefix}.to_out.0.weight"], ctx, heads)
-            wp, g, c = Wm.fold_layernorm(wqk, None, *self._ln(norm))
-            return wp.to(self.device), Wm.f32(g, self.device), Wm.f32(c, self.device), Wm.bf16(vot, self.device), npad
+            wp, g, c = Wm.fold_layernorm(wqk, None, *self._ln(norm), dtype=self.dtype)
+            return wp.to(self.device), Wm.f32(g, self.device), Wm.f32(c, self.device), Wm.bf16(vot, self.device, self.dtype), npad
         return self._memo(("x_ln", prefix), f)
 
 
@@ -492,7 +493,7 @@ class Builder:
         cpg = cout // self.groups
         self.drop_gn(out)   # this launch rewrites `out`: a table left by an earlier producer describes other values
         if GN_BYPRODUCT and cout % self.groups == 0 and cpg in (4, 8, 16, 32) and out.HW * cout * 2 >= (8 << 20):
-            slots = O.conv3x3_gn_slots(op)
+            slots = O.conv3x3_gn_slots(op, getattr(self.seq, "f16", False))
             if slots > 0:
                 part = self.raw(x.B * slots * self.groups * 2 * 4)
                 op = O.conv3x3(x.t, w, out.t, gn_part=part, gn_cpg=cpg, gn_slots=slots, **kw)

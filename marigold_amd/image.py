@@ -97,6 +97,9 @@ def export_model_image(pipe, path, *, ensemble_size, height, width, denoising_st
     B, T = int(ensemble_size), int(denoising_steps or pipe.default_denoising_steps)
     if pipe.empty_text_embed is None:
         pipe.encode_empty_text()
+    if getattr(unet, "f16", False) or getattr(vae, "f16", False):
+        raise ValueError("export_model_image: model images carry bf16 operands (the C host loads libmarigold_hip.so); "
+                         "build the pipeline with compute_dtype=torch.bfloat16")
     unet.set_context(pipe.empty_text_embed)
     enc_seq, enc_in, enc_out = vae._program("encode", 1, height, width)
     h, w = enc_out.shape[-2:]

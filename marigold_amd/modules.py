@@ -30,9 +30,15 @@ def _device_index(device):
 
 
 class _EngineModule:
+    # The 16-bit operand type of the engine (fp32 accumulation either way): bf16 = libmarigold_hip.so, the product build;
+    # torch.float16 = libmarigold_hip_f16.so, the same kernels on fp16 operands - the arithmetic of the reference's
+    # `--fp16` / from_pretrained(torch_dtype=torch.float16) (script/depth/run.py:203-211, marigold_depth_pipeline.py:253, 433).
     compute_dtype = torch.bfloat16
 
-    def __init__(self):
+    def __init__(self, compute_dtype=torch.bfloat16):
+        if compute_dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError(f"compute_dtype={compute_dtype}: the engine's operands are torch.bfloat16 or torch.float16")
+        self.compute_dtype = compute_dtype
         self.device = torch.device("cpu")
         self.ws = None
         self.pool = None
@@ -42,11 +48,20 @@ class _EngineModule:
     def dtype(self):
         return self.compute_dtype
 
+    @property
+    def f16(self):
+        return self.compute_dtype == torch.float16
+
+    def _seq(self, name):
+        return O.OpSeq(name, f16=self.f16)
+
     def to(self, device):
         idx = _device_index(device)
-        L.init(idx)
+        L.init(idx)             # dtype-independent ops (ensembling, resampling, colour table) launch from the product library
+        if self.f16:
+            L.init(idx, True)
         self.device = torch.device("cuda", idx)
-        self.ws = E.WeightStore(self.sd, self.device)
+        self.ws = E.WeightStore(self.sd, self.device, self.compute_dtype)
         self.pool = E.Pool(self.device)
         self._programs = {}
         return self
@@ -55,7 +70,7 @@ class _EngineModule:
         """Host-only mode for contract checks (tests): programs are built against CPU buffers and
         can be ``validate()``d, never run."""
         self.device = torch.device("cpu")
-        self.ws = E.WeightStore(self.sd, self.device)
+        self.ws = E.WeightStore(self.sd, self.device, self.compute_dtype)
         self.pool = E.Pool(self.device)
         self._programs = {}
         return self
@@ -97,8 +112,8 @@ class UNet2DConditionModelHIP(_EngineModule):
     ``unet(sample, t, encoder_hidden_states=ctx).sample`` (marigold_depth_pipeline.py:461-463);
     ``denoise_program`` builds the whole T-step loop (:455-468) as one program."""
 
-    def __init__(self, state_dict, config: UNetConfig = UNetConfig()):
-        super().__init__()
+    def __init__(self, state_dict, config: UNetConfig = UNetConfig(), compute_dtype=torch.bfloat16):
+        super().__init__(compute_dtype)
         _check_state_dict(state_dict, unet_param_shapes(config), "UNet")
         self.sd = state_dict
         self.config = config
@@ -130,7 +145,7 @@ class UNet2DConditionModelHIP(_EngineModule):
         if key in self._programs:
             return self._programs[key]
         dev = self.device
-        seq = O.OpSeq(f"denoise[B={B},{h}x{w},T={len(timesteps)}]")
+        seq = self._seq(f"denoise[B={B},{h}x{w},T={len(timesteps)}]")
         bld = E.Builder(seq, self.pool, self.ws, self.config.norm_groups)
         rgb_latent = torch.zeros(1 if rgb_broadcast else B, 4, h, w, device=dev)
         x = torch.zeros(B, self.config.out_channels, h, w, device=dev)
@@ -177,8 +192,8 @@ class AutoencoderKLHIP(_EngineModule):
     (marigold_depth_pipeline.py:491-495); ``decode`` = decoder(post_quant_conv(z / 0.18215)) with
     the pipeline's pointwise tail fused (:510-515, :473-475 / normals :437-440)."""
 
-    def __init__(self, state_dict, config: VAEConfig = VAEConfig()):
-        super().__init__()
+    def __init__(self, state_dict, config: VAEConfig = VAEConfig(), compute_dtype=torch.bfloat16):
+        super().__init__(compute_dtype)
         _check_state_dict(state_dict, vae_param_shapes(config), "VAE")
         self.sd = state_dict
         self.config = config
@@ -188,7 +203,7 @@ class AutoencoderKLHIP(_EngineModule):
         if key in self._programs:
             return self._programs[key]
         dev = self.device
-        seq = O.OpSeq(f"vae.{kind}[B={B},{H}x{W}]")
+        seq = self._seq(f"vae.{kind}[B={B},{H}x{W}]")
         bld = E.Builder(seq, self.pool, self.ws, self.config.norm_groups)
         if kind == "encode":
             n_down = len(self.config.block_out_channels) - 1

@@ -72,9 +72,10 @@ def conv3x3(a0, w, out, *, B, H, W, C0, N, a1=None, C1=0, subpix=False, ss=None,
                    p=[a0, w, out, bias, rowvec, residual, a1, ss, gn_part], l=[wz])
 
 
-def conv3x3_gn_slots(op):
-    """Partial-table slots per image this MG_OP_CONV3X3 fills with its output's GroupNorm statistics (0: its tile does not)."""
-    return int(L.load().mg_conv3x3_gn_slots(ctypes.byref(op)))
+def conv3x3_gn_slots(op, f16=False):
+    """Partial-table slots per image this MG_OP_CONV3X3 fills with its output's GroupNorm statistics (0: its tile does not);
+    ``f16``: asked of the fp16-operand build (its tile choice differs where a kernel is bf16-only)."""
+    return int(L.load(f16).mg_conv3x3_gn_slots(ctypes.byref(op)))
 
 
 def rowgemm(x, wp, out, *, M, K, N, form=L.RG_BF16, ldx=0, ldo=0, ldr=0, residual=None, ln_in=None, ln_out=None, vt=None,
@@ -212,11 +213,11 @@ def copy(src, dst, nbytes):
 
 # --------------------------------------------------------------------------- containers
 
-def launch(op, stream=None):
-    """Launch one op on torch's current stream (or the given raw handle)."""
-    lib = L.load()
+def launch(op, stream=None, lib=None):
+    """Launch one op on torch's current stream (or the given raw handle); ``lib``: the library build (default: bf16 operands)."""
+    lib = lib or L.load()
     L.check(lib.mg_launch(ctypes.byref(op), stream if stream is not None else current_stream_handle()),
-            f"mg_launch({L.OP_NAMES.get(op.kind, op.kind)})")
+            f"mg_launch({L.OP_NAMES.get(op.kind, op.kind)})", lib)
 
 
 class OpSeq:
@@ -224,8 +225,9 @@ class OpSeq:
     a native ``mg_program`` so that a whole UNet forward / denoising loop / VAE pass is ONE
     C call (and optionally one hipGraph launch)."""
 
-    def __init__(self, name=""):
+    def __init__(self, name="", f16=False):
         self.name = name
+        self.f16 = bool(f16)   # the library build this program belongs to: fp16 operands (libmarigold_hip_f16.so) or bf16
         self.ops = []
         self.labels = []
         self.keep = []
@@ -255,57 +257,57 @@ class OpSeq:
 
     def compile(self):
         if self._prog is None:
-            lib = L.load()
+            lib = L.load(self.f16)
             arr = (MgOp * len(self.ops))(*self.ops)
             prog = lib.mg_program_create(arr, len(self.ops))
             if not prog:
-                L.check(1, "mg_program_create")
+                L.check(1, "mg_program_create", lib)
             self._prog = prog
             self._captured = False
         return self._prog
 
     def run(self, stream=None):
-        lib = L.load()
+        lib = L.load(self.f16)
         prog = self.compile()
         L.check(lib.mg_program_run(prog, stream if stream is not None else current_stream_handle()),
-                f"mg_program_run({self.name})")
+                f"mg_program_run({self.name})", lib)
 
     def run_range(self, first, count, stream=None):
         """Replay ops [first, first+count) only (step-wise inspection of a denoising program in the parity tests)."""
-        lib = L.load()
+        lib = L.load(self.f16)
         L.check(lib.mg_program_run_range(self.compile(), int(first), int(count),
                                          stream if stream is not None else current_stream_handle()),
-                f"mg_program_run_range({self.name})")
+                f"mg_program_run_range({self.name})", lib)
 
     def validate(self):
         """Dry-run every op through its launcher's contract checks (works without a GPU)."""
-        lib = L.load()
-        L.check(lib.mg_program_validate(self.compile()), f"mg_program_validate({self.name})")
+        lib = L.load(self.f16)
+        L.check(lib.mg_program_validate(self.compile()), f"mg_program_validate({self.name})", lib)
 
     def run_eager(self, stream=None):
         for op in self.ops:
-            launch(op, stream)
+            launch(op, stream, L.load(self.f16))
 
     def capture(self, stream=None):
         """Capture into a hipGraph (the stream must not be the legacy default stream)."""
-        lib = L.load()
+        lib = L.load(self.f16)
         prog = self.compile()
         L.check(lib.mg_program_capture(prog, stream if stream is not None else current_stream_handle()),
-                f"mg_program_capture({self.name})")
+                f"mg_program_capture({self.name})", lib)
         self._captured = True
 
     def profile(self, stream=None):
         """Per-op milliseconds (HIP events on the launch stream)."""
-        lib = L.load()
+        lib = L.load(self.f16)
         prog = self.compile()
         ms = (ctypes.c_float * len(self.ops))()
         L.check(lib.mg_program_profile(prog, stream if stream is not None else current_stream_handle(), ms),
-                f"mg_program_profile({self.name})")
+                f"mg_program_profile({self.name})", lib)
         return list(ms)
 
     def __del__(self):
         try:
             if self._prog is not None:
-                L.load().mg_program_destroy(self._prog)
+                L.load(self.f16).mg_program_destroy(self._prog)
         except Exception:
             pass

@@ -12,8 +12,17 @@ diffusers state-dict tensors (``arch.py`` key scheme) are re-laid for the HIP ke
 import torch
 
 
-def bf16(t, device):
-    return t.detach().to(device=device, dtype=torch.bfloat16).contiguous()
+def to_op16(t, dtype=torch.bfloat16):
+    """fp32 -> the engine's 16-bit operand type (bf16, or fp16 for the fp16 build - saturating like its kernels' epilogues)."""
+    t = t.detach().float()
+    if dtype == torch.float16:
+        t = t.clamp(-65504.0, 65504.0)
+    return t.to(dtype)
+
+
+def bf16(t, device, dtype=torch.bfloat16):
+    """Kernel-ready 16-bit operands on the device (``dtype``: bf16, the product type, or fp16)."""
+    return to_op16(t, dtype).to(device=device).contiguous()
 
 
 def f32(t, device):
@@ -95,7 +104,7 @@ def cross_attention_tables(wq, wk, wv, wo, ctx, heads):
     return wqk.float(), vot.float(), npad
 
 
-def fold_layernorm(w, bias, gamma, beta):
+def fold_layernorm(w, bias, gamma, beta, dtype=torch.bfloat16):
     """LayerNorm folded into the Linear layer that consumes it (MG_OP_IGEMM ln_in): y = LN(x) W^T + b
     = rstd * (x (W gamma)^T - mean * g) + c  with  g[n] = sum_k (W gamma)[n][k],  c[n] = sum_k beta[k] W[n][k] + b[n].
     ``w`` [N][K] fp32 (rows already in the kernel's order), ``bias`` [N] | None.  Returns (W gamma as bf16, g, c); g sums
@@ -104,7 +113,7 @@ def fold_layernorm(w, bias, gamma, beta):
     rounded to the bf16 row the consumer reads (igemm2_body.h, ln_out), i.e. they are the statistics of x, not of bf16(x) -
     a deviation of <= 2^-9 |x| per element from LayerNorm(bf16(x)), below the bf16 resolution of the output (measured:
     tests/test_gpu_kernels.py::test_igemm_layernorm_fold, heavy-tailed rows included)."""
-    wp = (w.double() * gamma.double()[None, :]).float().to(torch.bfloat16)
+    wp = to_op16((w.double() * gamma.double()[None, :]).float(), dtype)
     g = wp.double().sum(dim=1).float()
     c = w.double() @ beta.double()
     if bias is not None:
@@ -120,7 +129,7 @@ def _rg_chan():
     return (mm & 0x13) | ((mm & 4) << 1) | ((mm & 8) >> 1)
 
 
-def pack_rowgemm(w, cb, lg=None):
+def pack_rowgemm(w, cb, lg=None, dtype=torch.bfloat16):
     """w [N][K] (rows in the order the kernel's channels take: stage j = rows 64 j .. 64 j + 63, tile 0 its first 32) ->
     uint8 [slots][41 * 1024].  A slot of the kernel's LDS ring is 40 fragments of 1 KB + a 1 KB trailer; fragment (tile t, K step
     s), lane l = 32 g + mm, 8 bf16: w[64 j + 32 t + chan(mm)][16 s + 8 g + 0..7] (the MFMA's own K order).
@@ -131,7 +140,7 @@ def pack_rowgemm(w, cb, lg=None):
     n, k = w.shape
     assert n % 64 == 0 and k in (320, 640)
     nst, ks = n // 64, k // 16
-    wb = w.detach().float().cpu().to(torch.bfloat16).contiguous()
+    wb = to_op16(w.cpu(), dtype).contiguous()
     wv = wb.view(nst, 2, 32, ks, 2, 8)[:, :, _rg_chan()]          # [j][t][mm][s][g][i]
     frag = wv.permute(0, 1, 3, 4, 2, 5).contiguous()              # [j][t][s][g][mm][i] = 1 KB per (j, t, s)
     frag = frag.view(torch.uint8).reshape(nst, 2, ks * 1024)
@@ -155,21 +164,21 @@ def rowgemm_geglu_order(n2):
     return torch.cat([32 * j + r, h + 32 * j + r], dim=1).reshape(-1)
 
 
-def pack_rowgemm_xattn(wqk, c, g, vot, bias):
+def pack_rowgemm_xattn(wqk, c, g, vot, bias, dtype=torch.bfloat16):
     """MG_OP_ROWGEMM form RG_XATTN: [scores stage = pack_rowgemm(Wqk with the LayerNorm folded in [64][K], c, g)] followed by the
     second GEMM's weights VO^T [c2][64] as c2/64 sub-stages of 2 tiles x 4 K steps (fragment (jj, t, s), lane 32 g + mm:
     vot[64 jj + 32 t + chan(mm)][16 s + 8 g .. + 8]) and 2 KB of fp32 bias [c2]."""
     c2 = vot.shape[0]
     assert wqk.shape[0] == 64 and vot.shape[1] == 64 and c2 % 64 == 0 and c2 * 4 <= 2048
-    s0 = pack_rowgemm(wqk, c, g).reshape(-1)
-    vb = vot.detach().float().cpu().to(torch.bfloat16).contiguous()
+    s0 = pack_rowgemm(wqk, c, g, dtype=dtype).reshape(-1)
+    vb = to_op16(vot.cpu(), dtype).contiguous()
     fr = vb.view(c2 // 64, 2, 32, 4, 2, 8)[:, :, _rg_chan()].permute(0, 1, 3, 4, 2, 5).contiguous().view(torch.uint8).reshape(-1)
     tr = torch.zeros(512, dtype=torch.float32)
     tr[:c2] = bias.detach().float().cpu()
     return torch.cat([s0, fr, tr.view(torch.uint8)]).contiguous()
 
 
-def pack_rowgemm_xattn_ksplit(wqk, c, g, vot, bias):
+def pack_rowgemm_xattn_ksplit(wqk, c, g, vot, bias, dtype=torch.bfloat16):
     """MG_OP_ROWGEMM form RG_XATTN at K = c2 = 640 / 1280 (csrc/rowgemm.hip::rowgemm_xattn_ksplit_kernel): wave w of a 32-row
     workgroup owns the channels [K/4 w, K/4 (w + 1)) on both sides.  [score fragments [w][tile t][K step s][lane 32 g + mm][8]:
     wqk[32 t + chan(mm)][K/4 w + 16 s + 8 g + i]] [VO^T fragments [w][tile tt][step s'][lane][8]: vot[K/4 w + 32 tt + chan(mm)]
@@ -179,9 +188,9 @@ def pack_rowgemm_xattn_ksplit(wqk, c, g, vot, bias):
     kq = k // 4
     ksq, nt2 = kq // 16, kq // 32
     ch = _rg_chan()
-    wb = wqk.detach().float().cpu().to(torch.bfloat16).contiguous()
+    wb = to_op16(wqk.cpu(), dtype).contiguous()
     f1 = wb.view(2, 32, 4, ksq, 2, 8)[:, ch].permute(2, 0, 3, 4, 1, 5).contiguous().view(torch.uint8).reshape(-1)     # [w][t][s][g][mm][i]
-    vb = vot.detach().float().cpu().to(torch.bfloat16).contiguous()
+    vb = to_op16(vot.cpu(), dtype).contiguous()
     f2 = vb.view(4, nt2, 32, 4, 2, 8)[:, :, ch].permute(0, 1, 3, 4, 2, 5).contiguous().view(torch.uint8).reshape(-1)   # [w][tt][s'][g][mm][i]
     fl = torch.cat([c.detach().float().cpu().reshape(64), g.detach().float().cpu().reshape(64), bias.detach().float().cpu().reshape(k)])
     return torch.cat([f1, f2, fl.contiguous().view(torch.uint8)]).contiguous()

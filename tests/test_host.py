@@ -31,10 +31,63 @@ def test_library_loads_and_exports_header_symbols():
 
 def test_missing_library_fails_loudly(monkeypatch):
     from marigold_amd import _lib
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmarigold_hip.so")
+    monkeypatch.setattr(_lib, "LIB_PATH_F16", "/nonexistent/libmarigold_hip_f16.so")
     with pytest.raises(_lib.MarigoldHipError):
         _lib.load()
+    with pytest.raises(_lib.MarigoldHipError):
+        _lib.load(f16=True)
+
+
+def test_fp16_engine_programs_validate_without_gpu():
+    """compute_dtype=torch.float16: the modules pack fp16 weights, their programs belong to the fp16 library and pass ITS contract
+    checks (tiny UNet + VAE, host buffers); bf16 stays the default; other dtypes are refused."""
+    from marigold_amd import weights as Wm
+    from marigold_amd.arch import TINY_UNET, TINY_VAE, unet_param_shapes, vae_param_shapes
+    from marigold_amd.modules import AutoencoderKLHIP, UNet2DConditionModelHIP
+    from marigold_amd.schedulers import DDIMScheduler
+    usd = {k: torch.zeros(s) for k, s in unet_param_shapes(TINY_UNET).items()}
+    vsd = {k: torch.zeros(s) for k, s in vae_param_shapes(TINY_VAE).items()}
+    unet = UNet2DConditionModelHIP(usd, TINY_UNET, compute_dtype=torch.float16).dry()
+    unet.set_context(torch.zeros(1, 2, TINY_UNET.cross_attention_dim))
+    prog = unet.denoise_program(2, 8, 16, DDIMScheduler(), 2)
+    assert prog.seq.f16 and unet.dtype == torch.float16 and unet.ws.dtype == torch.float16
+    prog.seq.validate()
+    assert any(t.dtype == torch.float16 for v in unet.ws.cache.values() for t in (v if isinstance(v, tuple) else (v,)) if torch.is_tensor(t))
+    assert not any(t.dtype == torch.bfloat16 for v in unet.ws.cache.values() for t in (v if isinstance(v, tuple) else (v,)) if torch.is_tensor(t))
+    vae = AutoencoderKLHIP(vsd, TINY_VAE, compute_dtype=torch.float16).dry()
+    seq, _, _ = vae._program("decode", 2, 8, 16, 1)
+    assert seq.f16
+    seq.validate()
+    assert not UNet2DConditionModelHIP(usd, TINY_UNET).dry().denoise_program.__self__.f16
+    with pytest.raises(ValueError):
+        UNet2DConditionModelHIP(usd, TINY_UNET, compute_dtype=torch.float32)
+    big = torch.tensor([1e6, -1e6, 1.0])
+    assert Wm.to_op16(big, torch.float16).tolist() == [65504.0, -65504.0, 1.0] and Wm.to_op16(big).dtype == torch.bfloat16
+
+
+def test_both_operand_builds_export_the_abi():
+    """libmarigold_hip.so (bf16 operands) and libmarigold_hip_f16.so (fp16: the reference's --fp16 arithmetic) come from the same
+    sources and export every symbol of include/marigold_hip.h; each says which operand type it was built for, and the loader refuses
+    a swapped pair."""
+    from marigold_amd import _lib
+    a, b = _lib.load(), _lib.load(f16=True)
+    assert a is not b and a.mg_operand_bits() == 0 and b.mg_operand_bits() == 1
+    assert a.mg_abi_version() == b.mg_abi_version() == _lib.ABI_VERSION
+    for name in _lib.EXPORTS:
+        assert hasattr(a, name) and hasattr(b, name), name
+    saved = dict(_lib._libs)
+    try:
+        _lib._libs.clear()
+        old = _lib.LIB_PATH, _lib.LIB_PATH_F16
+        _lib.LIB_PATH, _lib.LIB_PATH_F16 = old[1], old[0]
+        with pytest.raises(_lib.MarigoldHipError):
+            _lib.load()
+    finally:
+        _lib.LIB_PATH, _lib.LIB_PATH_F16 = old
+        _lib._libs.clear()
+        _lib._libs.update(saved)
 
 
 @pytest.mark.parametrize("kind,kw,n", [
