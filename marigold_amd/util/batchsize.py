@@ -11,10 +11,11 @@ import torch
 
 # measured-feasible members per batch on MI355X (bf16 engine); activations of the VAE decoder at
 # 768^2 peak at ~1.2 GB per member, far below 288 GB - the cap keeps headroom for res 2048+.
+# (the engine's two operand types - bf16, and fp16 for the --fp16 build - have the same footprint: one row set each, like the
+# reference's per-dtype rows)
 bs_search_table = [
-    {"res": 768, "total_vram": 250, "bs": 64, "dtype": torch.bfloat16},
-    {"res": 1024, "total_vram": 250, "bs": 32, "dtype": torch.bfloat16},
-    {"res": 2048, "total_vram": 250, "bs": 8, "dtype": torch.bfloat16},
+    {"res": res, "total_vram": 250, "bs": bs, "dtype": dt}
+    for dt in (torch.bfloat16, torch.float16) for res, bs in ((768, 64), (1024, 32), (2048, 8))
 ]
 
 
