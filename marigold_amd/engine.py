@@ -469,7 +469,7 @@ class Builder:
         # Round 6, measured layer by layer with the norm fused everywhere / nowhere (profiles/r6_ab_fuse_gn_per_layer.log): the
         # fix-up is VALU beside the MFMAs, the separate pass is HBM traffic - and with two maps in flight (section 6b) an HBM-bound
         # pass runs under the other map's matrix work.  Fused wins on the VAE's 128 / 256-channel levels (tensors of 0.75-1.5 GB:
-        # +0.45 ... +0.97 ms per block unfused); it LOSES where the plain convolution gets a hand-placed four-wave kernel that the
+        # +0.45 ... +0.97 ms per block unfused, and with two lanes the 256-channel level alone +1.4 ms per map); it LOSES where the plain convolution gets a hand-placed four-wave kernel that the
         # fused one does not - the UNet's 320-channel level from five members (-0.1 ... -0.66 ms per block) - and on the VAE's
         # 512-channel 192 x 192 level (two output-channel tiles repeat the fix-up: -0.17 ... -0.24 ms per block).
         if N == 320:
