@@ -470,10 +470,10 @@ class Builder:
         # fix-up is VALU beside the MFMAs, the separate pass is HBM traffic - and with two maps in flight (section 6b) an HBM-bound
         # pass runs under the other map's matrix work.  Fused wins on the VAE's 128 / 256-channel levels (tensors of 0.75-1.5 GB:
         # +0.45 ... +0.97 ms per block unfused, and with two lanes the 256-channel level alone +1.4 ms per map); it LOSES where the plain convolution gets a hand-placed four-wave kernel that the
-        # fused one does not - the UNet's 320-channel level from five members (-0.1 ... -0.66 ms per block) - and on the VAE's
+        # fused one does not - the UNet's 320-channel level from six members (-0.1 ... -0.66 ms per block) - and on the VAE's
         # 512-channel 192 x 192 level (two output-channel tiles repeat the fix-up: -0.17 ... -0.24 ms per block).
         if N == 320:
-            return B * -(-H // 12) * -(-W // 16) < 200
+            return B * -(-H // 12) * -(-W // 16) < 280   # (six members: -1.1 ms with two lanes, -3 ms alone; five: a tie)
         return tiles_n == 1
 
     def conv3x3p(self, srcs, name, cout, *, ss=None, silu=False, rowvec=None, residual=None, out=None, subpix=False):
