@@ -396,7 +396,7 @@ def main():
     # maps in flight: K steps = K maps handed to pipe.map_images, which keeps up to `in_flight` of them on the GPU (each on its own
     # engine replica and HIP stream; every map is the same computation as a lone pipe(img) call, bit for bit)
     # (with several ranks every rank runs the same lanes; the gathers are issued in map order on all of them - pipeline._Turnstile)
-    in_flight = args.in_flight if args.in_flight > 0 else pipe.default_maps_in_flight
+    in_flight = args.in_flight if args.in_flight > 0 else pipe.maps_in_flight_for(args.ensemble)
 
     def run_maps(k):
         last = None

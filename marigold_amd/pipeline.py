@@ -160,7 +160,20 @@ class _MarigoldPipelineBase:
     # optimiser's ~80 evaluations per map): a SECOND, independent map on another HIP stream fills those holes (DESIGN.md section 6b;
     # tools/inflight_bench.py: +9 % maps/s at E = 10, every map bit-identical to the one-at-a-time result).  288 GB of HBM hold the
     # second set of workspaces (23 GB at 768 x 768, E = 10) many times over; the weights are shared.
+    # A GPU that holds five members or fewer (small ensembles, the shards of the member-parallel path) has more and longer holes
+    # per map - its launches are single part-filled rounds - and takes a THIRD lane: same box, interleaved
+    # (profiles/r6_inflight_by_ensemble.log) E = 1 / 2 / 3 / 5: 51.4 / 77.5 / 100.6 / 146.5 ms per map with two lanes,
+    # 45.0 / 70.3 / 95.0 / 143.1 with three (a fourth: 48.4 / 70.7 / 94.2 / 142.4); at E = 10 the third lane buys 0.4 %.
     default_maps_in_flight = 2
+    small_ensemble_maps_in_flight = 3
+    small_ensemble_members = 5
+
+    def maps_in_flight_for(self, ensemble_size: int = 1) -> int:
+        """The lane count ``map_images`` uses when the caller names none: by the members THIS GPU runs per map (the ensemble
+        divided over the ranks of a member-parallel pipeline)."""
+        world = mdist.world_size(self._member_group) if self._sharded() else 1
+        local = -(-max(1, int(ensemble_size)) // max(1, world))
+        return self.small_ensemble_maps_in_flight if local <= self.small_ensemble_members else self.default_maps_in_flight
 
     def replicate(self):
         """Another pipeline over the same device-resident weights: engine replicas (own workspaces, programs, launch-private
@@ -182,14 +195,14 @@ class _MarigoldPipelineBase:
 
     def map_images(self, images, in_flight: Optional[int] = None, generators=None, **call_kwargs):
         """``(pipe(image, **call_kwargs) for image in images)`` with up to ``in_flight`` maps on the GPU at a time (default
-        ``default_maps_in_flight``; 1 = one after the other on the caller's stream).  A generator: outputs come in input order
+        ``maps_in_flight_for(ensemble_size)``; 1 = one after the other on the caller's stream).  A generator: outputs come in input order
         as they complete, and ``images`` (any iterable) is consumed as lanes become free.  ``generators``: one
         ``torch.Generator`` (or None) per image - with several maps in flight a single shared generator would be consumed in
         completion order, so ``generator=`` is refused; every map is then bit-identical to what ``pipe(image, generator=g)``
         returns on its own.  Member-parallel pipelines (several ranks): every rank must call this with the same images and
         ``in_flight``; the lanes then issue their gathers strictly in map order, one at a time (``_Turnstile``), so the collective
         sequence is the same on every rank whichever lane finishes first."""
-        n = self.default_maps_in_flight if in_flight is None else int(in_flight)
+        n = self.maps_in_flight_for(call_kwargs.get("ensemble_size", 1)) if in_flight is None else int(in_flight)
         if n < 1:
             raise ValueError(f"in_flight must be >= 1 (got {in_flight})")
         if generators is not None and hasattr(images, "__len__") and hasattr(generators, "__len__") and len(images) != len(generators):

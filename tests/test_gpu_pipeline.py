@@ -524,10 +524,12 @@ def _mp_worker(rank, world, port, q, hw=(64, 128)):
     g = torch.Generator(device="cuda:0").manual_seed(5)
     out = pipe(img, denoising_steps=2, ensemble_size=3, processing_res=0, color_map=None, show_progress_bar=False,
                generator=g)
-    # maps in flight with several ranks: two lanes per rank, the gathers issued in map order on both ranks (pipeline._Turnstile)
+    # maps in flight with several ranks: the lane count a shard of two members takes by default (three), the gathers issued in map
+    # order on both ranks (pipeline._Turnstile)
+    assert pipe.maps_in_flight_for(3) == 3 and pipe.maps_in_flight_for(20) == 2
     imgs = [syn.synthetic_image(hw[0], hw[1], seed=k) for k in range(5)]
     gens = [torch.Generator(device="cuda:0").manual_seed(50 + k) for k in range(5)]
-    many = [o.depth_np for o in pipe.map_images(imgs, in_flight=2, generators=gens, denoising_steps=2, ensemble_size=3,
+    many = [o.depth_np for o in pipe.map_images(imgs, in_flight=None, generators=gens, denoising_steps=2, ensemble_size=3,
                                                 processing_res=0, color_map=None, show_progress_bar=False)]
     if rank == 0:
         q.put((out.depth_np, many))
