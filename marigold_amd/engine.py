@@ -55,6 +55,10 @@ XATTN_KSPLIT = _tune("MARIGOLD_XATTN_KSPLIT", True)     # deep-level collapsed c
 ROWGEMM_WIDE = _tune("MARIGOLD_ROWGEMM_WIDE", True)     # ... and its K = 640 form for the 640-channel level's QKV / GEGLU
 XATTN_IN_GEGLU = _tune("MARIGOLD_XATTN_IN_GEGLU", True)   # the collapsed cross-attention as the prologue of the row-resident GEGLU launch
 ROWGEMM_MIN_M = _tune("MARIGOLD_ROWGEMM_MIN_M", 9216)   # below: the tile GEMM (one 96 x 96 member is 72 128-row workgroups)
+# Measurement probe (never the product path): every launch of these op kinds is issued TWICE (idempotent kinds only: GroupNorm
+# 2,3,4,9 / flash attention 6,11 write outputs they do not read) - the map's extra time is what that class costs with the
+# other lanes running beside it, i.e. the most a faster kernel of that class could return (tools: scripts/gpu_ab_env.sh)
+TWICE_KINDS = tuple(int(k) for k in _tune("MARIGOLD_TWICE_KINDS", "").split(",") if k)
 
 
 class Act:
@@ -304,6 +308,9 @@ class Builder:
             # must not share the library's
             op.p[14] = self.zeros_persistent("splitk_ws", O.SPLITK_WS_BYTES).data_ptr()
         self.seq.add(tuning.apply(op), label)   # (MG_OP_IGEMM: the measured tile / split-K choice where the table has one)
+        if op.kind in TWICE_KINDS:
+            assert op.kind in (L.OP_GN_STATS, L.OP_GN_FINALIZE, L.OP_GN_APPLY, L.OP_GN_SLAB, L.OP_FLASH_ATTN64, L.OP_FLASH_ATTN512)
+            self.seq.add(op, label + ".again")
 
     # ---- primitive layers ----------------------------------------------------------------
     @staticmethod

@@ -67,6 +67,9 @@ def case(name, M, N, K, variant, taps=1, res=True, ln_out=False, HW=None, B=1, s
 
 
 if __name__ == "__main__":
+    case("gemm 4096^3 256x256", 4096, 4096, 4096, 72, res=False)
+    case("lvl1 conv 1280->640 3x3", 23040, 640, 11520, 73, taps=9, HW=48, B=10, res=False)
+    case("lvl2 conv 1280->1280 3x3 256x256", 5760, 1280, 11520, 72, taps=9, HW=24, B=10, res=False)
     case("lvl1 to_out (+res, +row stats)", 23040, 640, 640, 73, ln_out=True)
     case("lvl1 proj_out (+res)", 23040, 640, 640, 73)
     case("lvl0 ff.out (+res)", 92160, 320, 1280, 73)
