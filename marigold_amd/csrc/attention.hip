@@ -117,6 +117,7 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       a.ws_bytes = (long long)op->i[8] * 1024;
       a.split = op->i[9];
       a.n_full = a.n_rem = a.n_rem_wg = 0;
+      a.m16 = 0;
       MG_REQUIRE(!a.ws || ((uintptr_t)a.ws % 16 == 0 && a.ws_bytes > 0), "flash_attn64: workspace must be 16-byte aligned, its size (KB) in i[8]");
       a.nqb = (a.Ntok + FA_QB - 1) / FA_QB;
       MG_REQUIRE(g_zero_page || g_dry_run, "flash_attn64: mg_init() not called");
@@ -129,7 +130,7 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
       MG_REQUIRE((a.ldo % 8 == 0) && ((uintptr_t)a.O % 16 == 0) && (a.sO % 8 == 0), "flash_attn64: O needs 16-byte rows (ldo %% 8 == 0, aligned base / batch stride)");
       const int var = op->i[6];
       const bool vt_perm = op->i[7] != 0;   // V^T keys permuted inside every group of 16: [0-3, 8-11, 4-7, 12-15]
-      MG_REQUIRE(var == 0 || vt_perm == (var == 19 || var == 20 || var == 25 || var == 26), "flash_attn64: variant %d and the V^T key order (i[7] = %d) do not match", var, op->i[7]);
+      MG_REQUIRE(var == 0 || vt_perm == (var == 19 || var == 20 || var == 25 || var == 26 || var == 27), "flash_attn64: variant %d and the V^T key order (i[7] = %d) do not match", var, op->i[7]);
       MG_REQUIRE(!vt_perm || a.Ntok % 16 == 0, "flash_attn64: the permuted V^T layout needs Ntok %% 16 == 0");
       const long long g4 = (long long)((a.Ntok + 127) / 128) * a.heads * a.B;
       const long long g8 = (long long)((a.Ntok + 255) / 256) * a.heads * a.B;
@@ -138,8 +139,10 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
         case 20: MG_LAUNCH((flash_attn64_v25_kernel<8, true>), dim3((unsigned)g8), dim3(512), 0, s, a); break;
         case 21: MG_LAUNCH((flash_attn64_v25_kernel<4, false>), dim3((unsigned)g4), dim3(256), 0, s, a); break;  // natural V^T
         case 25: MG_LAUNCH((flash_attn64_v25_kernel<4, true, 2>), dim3((unsigned)g4), dim3(256), 0, s, a); break;   // plain v_add_f32 row sums
-        case 26:   // the hand-placed one-wave-per-SIMD stream (flash4w.hip)
-          MG_REQUIRE(mg_flash4w_ok(a, vt_perm), "flash_attn64 variant 26: Ntok %d must be a multiple of 256 (even number of key tiles), V^T permuted", a.Ntok);
+        case 26:   // the hand-placed stream (flash4w.hip) on 32x32x16 MFMAs
+        case 27:   // ... on 16x16x32 MFMAs
+          MG_REQUIRE(mg_flash4w_ok(a, vt_perm), "flash_attn64 variant %d: Ntok %d must be a multiple of 256 (even number of key tiles), V^T permuted", var, a.Ntok);
+          a.m16 = var == 27;
           return mg_launch_flash4w(a, s);
         case 0: {
           // round 3 (profiles/r3_flash_variants*.log, TFLOP/s at E = 10): generation 2.5 on 4-wave workgroups (three per CU)
@@ -149,6 +152,8 @@ int mg_launch_attention(const mg_op* op, hipStream_t s) {
           // round 4: the hand-placed one-wave-per-SIMD stream (flash4w.hip) where its shape constraints hold (the 96 x 96 and
           // 48 x 48 levels: 9 216 / 2 304 tokens): 1 160-1 260 vs 907-928 TFLOP/s at 9 216 tokens (profiles/r4_flash4w.log).
           static const int f4w = mg_tuning_int("MARIGOLD_FLASH4W", 1);
+          static const int f4w_m16 = mg_tuning_int("MARIGOLD_FLASH4W_M16", -1);   // -1: by shape (mg_launch_flash4w)
+          a.m16 = f4w_m16;
           if (f4w && vt_perm && mg_flash4w_ok(a, true)) return mg_launch_flash4w(a, s);
           if (vt_perm) MG_LAUNCH((flash_attn64_v25_kernel<4, true, 2>), dim3((unsigned)g4), dim3(256), 0, s, a);
           else MG_LAUNCH((flash_attn64_v25_kernel<4, false>), dim3((unsigned)g4), dim3(256), 0, s, a);

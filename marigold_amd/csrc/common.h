@@ -26,9 +26,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // mnemonics for the hand-placed instruction streams (csrc/gen_*.py emit them as adjacent string literals)
 #if MG_OPERAND_F16_BUILD
 #define MG_MFMA32_ASM "v_mfma_f32_32x32x16_f16"
+#define MG_MFMA16_ASM "v_mfma_f32_16x16x32_f16"
 #define MG_CVT_PK_ASM "v_cvt_pk_f16_f32"
 #else
 #define MG_MFMA32_ASM "v_mfma_f32_32x32x16_bf16"
+#define MG_MFMA16_ASM "v_mfma_f32_16x16x32_bf16"
 #define MG_CVT_PK_ASM "v_cvt_pk_bf16_f32"
 #endif
 constexpr float MG_OP16_MAX = MG_F16 ? 65504.0f : 3.3895314e38f;   // largest finite operand value

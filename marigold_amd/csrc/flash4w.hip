@@ -19,6 +19,13 @@
 //     are only ever touched by MFMAs.  Exact as long as no later score tops its reference by more than ~2^100; the row sums
 //     tell (>= 2^100 or not finite) and such a workgroup redoes its queries with the running-maximum loop of flash_attn64_v25
 //     (flash25_body.h; FaArgs::redo_thr lets the tests force that path).
+// Round 6 - the same loop on v_mfma_f32_16x16x32 (template M16, variant 27; stream FA4W16_ASM, layout notes in gen_fa4w.py): the chip
+// is power-limited under this kernel (1.6 GHz), and a 16x16x32 MFMA draws less than a 32x32x16 one for the same product
+// (profiles/r6_mfma_shape.log).  Four 16-query blocks per wave, the K fragment rows read in the order that makes a lane's eight
+// packed probabilities the B operand of its P V MFMA against the permuted V^T, the V^T rows in the order that lets eight
+// v_permlane16_swap per 32 x 32 block rebuild the 32x32x16 accumulator layout for the unchanged finalize, and the ROW SUMS ON THE
+// MATRIX PIPE (P against ones: the stream is issue-bound, and an MFMA costs the wave ~8 issue cycles whatever its size).  Chosen
+// by mg_launch_flash4w where two workgroups per CU run for several rounds at 9 216 tokens: 851 vs 911 us at E = 10.
 // Ring slot t of the four 16 KB slots holds what iteration t reads: K rows 64 t + 32 ... 64 t + 95 and V^T tile t; the K rows
 // of the prologue (the first 32 keys of the sequence: the reference; the first 32 keys of the segment: the stream's first
 // scores) go to two 4 KB regions of their own.  Needs Ntok % 256 == 0, at least four key tiles and V^T in the accumulator's
@@ -55,6 +62,10 @@ constexpr int F4_CTR_BYTES = 4096;                             // tickets (zero 
 __device__ __forceinline__ void f4_mfma(f32x16& acc, const bf16x8& a, const bf16x8& b) {
   asm volatile(MG_MFMA32_ASM " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+__device__ __forceinline__ void f4_mfma16(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile(MG_MFMA16_ASM " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ void f4_dma(unsigned voff, i32x4 srd, unsigned soff, unsigned m0v) {
   asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(srd), "s"(soff), "s"(m0v) : "memory");
 }
@@ -73,6 +84,7 @@ __device__ __host__ __forceinline__ unsigned f4_bound(unsigned r, unsigned nwg, 
 
 // One segment: key tiles [t0, t1) of the 256 queries of block `blk`.  `part` < 0: the whole block (normalise and store);
 // else: piece `part` of `npieces` of split block `rem` (partial result + ticket, the last piece finishes).
+template <bool M16>
 __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const int blk, const int t0, const int t1, const int part,
                                            const int npieces, const int rem) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -118,88 +130,206 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
   }
   // (the queries after the LDS-DMA pieces: their latency runs beside the DMA's; the counted waits below and in the stream only
   // ever see fewer loads in flight than they allow)
-  bf16x8 qf[2][4];
-  {
-    const float c = a.scale_log2;
+  const float qscale = a.scale_log2;
+  auto load_q = [&](int q_row, int d0) {   // eight pre-scaled d values of a query row
+    const uint4 u = *(const uint4*)(Qb + (long long)q_row * a.ldq + d0);
+    uint4 w;
+    w.x = cvt_pk_bf16_f32(bflo(u.x) * qscale, bfhi(u.x) * qscale); w.y = cvt_pk_bf16_f32(bflo(u.y) * qscale, bfhi(u.y) * qscale);
+    w.z = cvt_pk_bf16_f32(bflo(u.z) * qscale, bfhi(u.z) * qscale); w.w = cvt_pk_bf16_f32(bflo(u.w) * qscale, bfhi(u.w) * qscale);
+    return __builtin_bit_cast(bf16x8, w);
+  };
+  // 32x32x16: lane = (query l31 of a 32-query block, d group half: 8 of a k-step's 16); 16x16x32: lane = (query l15 of a 16-query
+  // block, d group kq = lane >> 4: 8 of a k-step's 32)
+  const int l15 = lane & 15, kq = lane >> 4;
+  bf16x8 qf[2][4], qg[4][2];
+  if constexpr (!M16) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int q_row = qb * 256 + wave * 64 + q * 32 + l31;
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const uint4 u = *(const uint4*)(Qb + (long long)q_row * a.ldq + ks * 16 + half * 8);
-        uint4 w;
-        w.x = cvt_pk_bf16_f32(bflo(u.x) * c, bfhi(u.x) * c); w.y = cvt_pk_bf16_f32(bflo(u.y) * c, bfhi(u.y) * c);
-        w.z = cvt_pk_bf16_f32(bflo(u.z) * c, bfhi(u.z) * c); w.w = cvt_pk_bf16_f32(bflo(u.w) * c, bfhi(u.w) * c);
-        qf[q][ks] = __builtin_bit_cast(bf16x8, w);
-      }
-    }
+      for (int ks = 0; ks < 4; ++ks) qf[q][ks] = load_q(qb * 256 + wave * 64 + q * 32 + l31, ks * 16 + half * 8);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) qg[q][ds] = load_q(qb * 256 + wave * 64 + q * 16 + l15, ds * 32 + kq * 8);
   }
   if (dbgw && lane == 0) dbgw[3] = __builtin_amdgcn_s_memrealtime();
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (dbgw && lane == 0) dbgw[4] = __builtin_amdgcn_s_memrealtime();
-  // S^T = K Q^T (lane = query, registers = keys): the reference = the row maximum over the sequence's first 32 keys
-  const int sw = (l31 >> 1) & 7;
-  unsigned ad[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) ad[ks] = (unsigned)(l31 * 128 + (((2 * ks + half) ^ sw) << 4));
-  f32x16 s[2], negm[2];
-  auto first_scores = [&](int region) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[q][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 kf = __builtin_bit_cast(bf16x8, *(const uint4*)(smem + region + ad[ks]));
-      f4_mfma(s[0], kf, qf[0][ks]);
-      f4_mfma(s[1], kf, qf[1][ks]);
-    }
-    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-  };
-  first_scores(F4_PRE);
-  float ref[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    float mx = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[q][r], s[q][r + 1]));
-    float x0, x1;
-    half_swap(mx, mx, x0, x1);
-    ref[q] = fmaxf(x0, x1) + F4_REF_BIAS;
-  }
-  if (t0 != 0) first_scores(F4_PRE + 4096);   // (wave-uniform)
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { negm[q][r] = -ref[q]; s[q][r] -= ref[q]; }
   f32x16 o[2][2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[q][d][r] = 0.f;
-  float l00 = 0.f, l01 = 0.f, l10 = 0.f, l11 = 0.f;
-  unsigned sok = f4_sgpr(k0 + 3u * kst + (kst >> 1)), sov = f4_sgpr(v0 + 3u * 128u), mb = f4_sgpr(mw + 3 * F4_SLOT),
-           cnt = f4_sgpr((unsigned)(t1 - t0 - 3));
-  uint4 kf0, kf1, kf2, kf3, vf0, vf1, vf2, vf3;
+  float ll[2];
   unsigned long long tm0 = 0, rm0 = 0;
-  if (a.dbg) { tm0 = __builtin_amdgcn_s_memtime(); rm0 = __builtin_amdgcn_s_memrealtime(); }
-  asm volatile(FA4W_ASM
-               : "+{v[128:143]}"(s[0]), "+{v[144:159]}"(s[1]),
-                 [o00] "+v"(o[0][0]), [o01] "+v"(o[0][1]), [o10] "+v"(o[1][0]), [o11] "+v"(o[1][1]),
-                 [l00] "+v"(l00), [l01] "+v"(l01), [l10] "+v"(l10), [l11] "+v"(l11),
-                 [ad0] "+v"(ad[0]), [ad1] "+v"(ad[1]), [ad2] "+v"(ad[2]), [ad3] "+v"(ad[3]),
-                 [kf0] "=&v"(kf0), [kf1] "=&v"(kf1), [kf2] "=&v"(kf2), [kf3] "=&v"(kf3),
-                 [vf0] "=&v"(vf0), [vf1] "=&v"(vf1), [vf2] "=&v"(vf2), [vf3] "=&v"(vf3),
-                 [sok] "+s"(sok), [sov] "+s"(sov), [mb] "+s"(mb), [cnt] "+s"(cnt)
-               : [q00] "v"(qf[0][0]), [q01] "v"(qf[0][1]), [q02] "v"(qf[0][2]), [q03] "v"(qf[0][3]),
-                 [q10] "v"(qf[1][0]), [q11] "v"(qf[1][1]), [q12] "v"(qf[1][2]), [q13] "v"(qf[1][3]),
-                 [ng0] "v"(negm[0]), [ng1] "v"(negm[1]),
-                 [vk0] "v"(vk[0]), [vk1] "v"(vk[1]), [vv0] "v"(vv[0]), [vv1] "v"(vv[1]),
-                 [srk] "s"(srk), [srv] "s"(srv), [kst] "s"(kst)
-               : "memory", "scc", F4_CLOBBER_Y);
+  if constexpr (!M16) {
+    // S^T = K Q^T (lane = query, registers = keys): the reference = the row maximum over the sequence's first 32 keys
+    const int sw = (l31 >> 1) & 7;
+    unsigned ad[4];
+  #pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ad[ks] = (unsigned)(l31 * 128 + (((2 * ks + half) ^ sw) << 4));
+    f32x16 s[2], negm[2];
+    auto first_scores = [&](int region) {
+  #pragma unroll
+      for (int q = 0; q < 2; ++q)
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) s[q][r] = 0.f;
+  #pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = __builtin_bit_cast(bf16x8, *(const uint4*)(smem + region + ad[ks]));
+        f4_mfma(s[0], kf, qf[0][ks]);
+        f4_mfma(s[1], kf, qf[1][ks]);
+      }
+      asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    };
+    first_scores(F4_PRE);
+    float ref[2];
+  #pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float mx = -1e30f;
+  #pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[q][r], s[q][r + 1]));
+      float x0, x1;
+      half_swap(mx, mx, x0, x1);
+      ref[q] = fmaxf(x0, x1) + F4_REF_BIAS;
+    }
+    if (t0 != 0) first_scores(F4_PRE + 4096);   // (wave-uniform)
+  #pragma unroll
+    for (int q = 0; q < 2; ++q)
+  #pragma unroll
+      for (int r = 0; r < 16; ++r) { negm[q][r] = -ref[q]; s[q][r] -= ref[q]; }
+  #pragma unroll
+    for (int q = 0; q < 2; ++q)
+  #pragma unroll
+      for (int d = 0; d < 2; ++d)
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) o[q][d][r] = 0.f;
+    float l00 = 0.f, l01 = 0.f, l10 = 0.f, l11 = 0.f;
+    unsigned sok = f4_sgpr(k0 + 3u * kst + (kst >> 1)), sov = f4_sgpr(v0 + 3u * 128u), mb = f4_sgpr(mw + 3 * F4_SLOT),
+             cnt = f4_sgpr((unsigned)(t1 - t0 - 3));
+    uint4 kf0, kf1, kf2, kf3, vf0, vf1, vf2, vf3;
+    if (a.dbg) { tm0 = __builtin_amdgcn_s_memtime(); rm0 = __builtin_amdgcn_s_memrealtime(); }
+    asm volatile(FA4W_ASM
+                 : "+{v[128:143]}"(s[0]), "+{v[144:159]}"(s[1]),
+                   [o00] "+v"(o[0][0]), [o01] "+v"(o[0][1]), [o10] "+v"(o[1][0]), [o11] "+v"(o[1][1]),
+                   [l00] "+v"(l00), [l01] "+v"(l01), [l10] "+v"(l10), [l11] "+v"(l11),
+                   [ad0] "+v"(ad[0]), [ad1] "+v"(ad[1]), [ad2] "+v"(ad[2]), [ad3] "+v"(ad[3]),
+                   [kf0] "=&v"(kf0), [kf1] "=&v"(kf1), [kf2] "=&v"(kf2), [kf3] "=&v"(kf3),
+                   [vf0] "=&v"(vf0), [vf1] "=&v"(vf1), [vf2] "=&v"(vf2), [vf3] "=&v"(vf3),
+                   [sok] "+s"(sok), [sov] "+s"(sov), [mb] "+s"(mb), [cnt] "+s"(cnt)
+                 : [q00] "v"(qf[0][0]), [q01] "v"(qf[0][1]), [q02] "v"(qf[0][2]), [q03] "v"(qf[0][3]),
+                   [q10] "v"(qf[1][0]), [q11] "v"(qf[1][1]), [q12] "v"(qf[1][2]), [q13] "v"(qf[1][3]),
+                   [ng0] "v"(negm[0]), [ng1] "v"(negm[1]),
+                   [vk0] "v"(vk[0]), [vk1] "v"(vk[1]), [vv0] "v"(vv[0]), [vv1] "v"(vv[1]),
+                   [srk] "s"(srk), [srv] "s"(srv), [kst] "s"(kst)
+                 : "memory", "scc", F4_CLOBBER_Y);
+    ll[0] = l00 + l01;   // the lane's share of its queries' row sums (the other half-wave holds the rest)
+    ll[1] = l10 + l11;
+  } else {
+    // ---- the 16x16x32 form (gen_fa4w.py, FA4W16_ASM) ----
+    // K fragment (key block kb, d-step ds): lane (l15, kq) reads d chunk 4 ds + kq of key ROW krow(kb) of the 32-key half - the
+    // key whose probability the lane then holds as element 4 kb + r (r = MFMA row & 3) of its eight: position 8 kq + 4 kb + r of
+    // the half in the V^T order ([0-3, 8-11, 4-7, 12-15] inside every 16): rows 0-3, 4-7, 16-19, 20-23 (kb 0), + 8 (kb 1).
+    // V^T fragment (d block, half hh): lane reads key chunk 4 hh + kq of d ROW pw (bits 2 <-> 3 of l15 swapped), so that eight
+    // v_permlane16_swap per 32 x 32 block rebuild the 32x32x16 accumulator layout for the unchanged finalize (igemm2_body.h).
+    unsigned adk[4], adv[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        const int kr = (l15 & 7) + 2 * (l15 & 8) + 8 * kb;
+        adk[2 * kb + ds] = (unsigned)(kr * 128 + (((4 * ds + kq) ^ ((kr >> 1) & 7)) << 4));
+      }
+    const int pw = (l15 & 3) | ((l15 & 4) << 1) | ((l15 & 8) >> 1);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) adv[hh] = (unsigned)(pw * 128 + (((4 * hh + kq) ^ ((pw >> 1) & 7)) << 4));
+    f32x4 sc[4][2], ng[4];
+    auto first_scores = [&](int region) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) sc[q][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+          const bf16x8 kf = __builtin_bit_cast(bf16x8, *(const uint4*)(smem + region + adk[2 * kb + ds]));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) f4_mfma16(sc[q][kb], kf, qg[q][ds]);
+        }
+      asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    };
+    first_scores(F4_PRE);
+    float ref[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) mx = fmaxf(mx, fmaxf(sc[q][kb][r], sc[q][kb][r + 1]));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      ref[q] = mx + F4_REF_BIAS;
+    }
+    if (t0 != 0) first_scores(F4_PRE + 4096);   // (wave-uniform)
+    f32x8 sx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ng[q] = f32x4{-ref[q], -ref[q], -ref[q], -ref[q]};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sx[q][r] = sc[q][0][r] - ref[q]; sx[q][4 + r] = sc[q][1][r] - ref[q]; }
+    }
+    f32x4 og[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) og[q][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ls[4];   // row sums on the matrix pipe: P against ones - every register of a lane = the sum over the keys so far of its query
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ls[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, MG_F16 ? make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u)
+                                                          : make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+    unsigned sok = f4_sgpr(k0 + 3u * kst + (kst >> 1)), sov = f4_sgpr(v0 + 3u * 128u), mb = f4_sgpr(mw + 3 * F4_SLOT),
+             cnt = f4_sgpr((unsigned)(t1 - t0 - 3));
+    uint4 kf0, kf1, kf2, kf3, vf0, vf1, vf2, vf3;
+    if (a.dbg) { tm0 = __builtin_amdgcn_s_memtime(); rm0 = __builtin_amdgcn_s_memrealtime(); }
+    asm volatile(FA4W16_ASM
+                 : "+{v[128:135]}"(sx[0]), "+{v[136:143]}"(sx[1]), "+{v[144:151]}"(sx[2]), "+{v[152:159]}"(sx[3]),
+                   [o00] "+v"(og[0][0]), [o01] "+v"(og[0][1]), [o02] "+v"(og[0][2]), [o03] "+v"(og[0][3]),
+                   [o10] "+v"(og[1][0]), [o11] "+v"(og[1][1]), [o12] "+v"(og[1][2]), [o13] "+v"(og[1][3]),
+                   [o20] "+v"(og[2][0]), [o21] "+v"(og[2][1]), [o22] "+v"(og[2][2]), [o23] "+v"(og[2][3]),
+                   [o30] "+v"(og[3][0]), [o31] "+v"(og[3][1]), [o32] "+v"(og[3][2]), [o33] "+v"(og[3][3]),
+                   [ls0] "+v"(ls[0]), [ls1] "+v"(ls[1]), [ls2] "+v"(ls[2]), [ls3] "+v"(ls[3]),
+                   [adk0] "+v"(adk[0]), [adk1] "+v"(adk[1]), [adk2] "+v"(adk[2]), [adk3] "+v"(adk[3]),
+                   [adv0] "+v"(adv[0]), [adv1] "+v"(adv[1]),
+                   [kf0] "=&v"(kf0), [kf1] "=&v"(kf1), [kf2] "=&v"(kf2), [kf3] "=&v"(kf3),
+                   [vf0] "=&v"(vf0), [vf1] "=&v"(vf1), [vf2] "=&v"(vf2), [vf3] "=&v"(vf3),
+                   [sok] "+s"(sok), [sov] "+s"(sov), [mb] "+s"(mb), [cnt] "+s"(cnt)
+                 : [q00] "v"(qg[0][0]), [q01] "v"(qg[0][1]), [q10] "v"(qg[1][0]), [q11] "v"(qg[1][1]),
+                   [q20] "v"(qg[2][0]), [q21] "v"(qg[2][1]), [q30] "v"(qg[3][0]), [q31] "v"(qg[3][1]),
+                   [ng0] "v"(ng[0]), [ng1] "v"(ng[1]), [ng2] "v"(ng[2]), [ng3] "v"(ng[3]), [ones] "v"(ones),
+                   [vk0] "v"(vk[0]), [vk1] "v"(vk[1]), [vv0] "v"(vv[0]), [vv1] "v"(vv[1]),
+                   [srk] "s"(srk), [srv] "s"(srv), [kst] "s"(kst)
+                 : "memory", "scc", F4_CLOBBER_Y);
+    // -> the 32x32x16 layout of the finalize: o[Q][dt][4 g + j] = O^T[d = 32 dt + 8 g + 4 half + j][query 32 Q + l31]
+#pragma unroll
+    for (int Q = 0; Q < 2; ++Q)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const auto sw2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(og[2 * Q][2 * dt + cb][r]),
+                                                              __float_as_uint(og[2 * Q + 1][2 * dt + cb][r]), false, false);
+            o[Q][dt][8 * cb + r] = __uint_as_float(sw2[0]);
+            o[Q][dt][8 * cb + 4 + r] = __uint_as_float(sw2[1]);
+          }
+    // row sums: every lane of column l15 holds the whole sum of its four queries; the finalize wants, per lane (query l31, half), a
+    // share whose two halves add up to the query's sum
+    const bool up = (lane >> 4) & 1;
+    ll[0] = half == 0 ? (up ? ls[1][0] : ls[0][0]) : 0.f;
+    ll[1] = half == 0 ? (up ? ls[3][0] : ls[2][0]) : 0.f;
+  }
   if (a.dbg) {   // tuning only: shader cycles / 100 MHz ticks (+ tiles << 40) of the key loop, per wave of the workgroup's last segment
     const unsigned long long tm1 = __builtin_amdgcn_s_memtime(), rm1 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
@@ -209,7 +339,6 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
       dbgw[6] = rm1;
     }
   }
-  float ll[2] = {l00 + l01, l10 + l11};   // the lane's share of its queries' row sums (the other half-wave holds the rest)
   bool finish = true;
   if (part >= 0) {
     // ---- a piece: leave the partial result, draw a ticket; the block's last piece adds the others to its registers ----
@@ -329,6 +458,7 @@ __device__ __forceinline__ void f4_segment(const FaArgs& a, char* smem, const in
   if (dbgw && lane == 0) dbgw[7] = __builtin_amdgcn_s_memrealtime();
 }
 
+template <bool M16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn64_4w_kernel(const FaArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // the ring: LDS address 0 (the stream wraps addresses at 64 KB)
   const int nkt = a.Ntok >> 6;
@@ -351,7 +481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       part = (int)(r - rf);
       npieces = (int)(rl - rf + 1);
     }
-    f4_segment(a, smem, whole ? xcd_remap(bid, a.n_full) : a.n_full + (int)rem, (int)t0, (int)t1, part, npieces, (int)rem);
+    f4_segment<M16>(a, smem, whole ? xcd_remap(bid, a.n_full) : a.n_full + (int)rem, (int)t0, (int)t1, part, npieces, (int)rem);
     s0 += t1 - t0;
   }
 }
@@ -416,10 +546,12 @@ int mg_launch_flash4w(const FaArgs& a_in, hipStream_t s) {
   static bool attr_set = false;
   static int n_cu = 256;
   if (!attr_set && !g_dry_run) {
-    hipFuncAttributes fa;
-    MG_CHECK_HIP(hipFuncGetAttributes(&fa, (const void*)flash_attn64_4w_kernel));
-    MG_REQUIRE(fa.sharedSizeBytes == 0, "flash_attn64 (hand-placed form): the ring must start at LDS address 0 (static LDS %d bytes)", (int)fa.sharedSizeBytes);
-    MG_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn64_4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    for (const void* fn : {(const void*)flash_attn64_4w_kernel<false>, (const void*)flash_attn64_4w_kernel<true>}) {
+      hipFuncAttributes fa;
+      MG_CHECK_HIP(hipFuncGetAttributes(&fa, fn));
+      MG_REQUIRE(fa.sharedSizeBytes == 0, "flash_attn64 (hand-placed form): the ring must start at LDS address 0 (static LDS %d bytes)", (int)fa.sharedSizeBytes);
+      MG_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    }
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
@@ -428,6 +560,11 @@ int mg_launch_flash4w(const FaArgs& a_in, hipStream_t s) {
   MG_REQUIRE((long long)(a.Ntok / 256) * a.heads * a.B < (1ll << 30), "flash_attn64: too many query blocks");
   mg_flash4w_plan(&a, n_cu);
   const long long grid = (long long)a.n_full + a.n_rem_wg;
-  MG_LAUNCH(flash_attn64_4w_kernel, dim3((unsigned)grid), dim3(256), LDS, s, a);
+  // The 16x16x32 stream (variant 27) where the launch keeps two workgroups on every CU for several rounds at 9 216 tokens - the
+  // power-limited regime it was built for: E = 10: 851 vs 911 us; a tie at 2 304 tokens and for two members, 2 % slower for one
+  // (profiles/r6_flash_mfma16.log).  m16 < 0: this rule; MARIGOLD_FLASH4W_M16 = 0 / 1 (tuning gate) forces a form.
+  if (a.m16 < 0) a.m16 = (a.Ntok >= 4096 && (long long)(a.Ntok / 256) * a.heads * a.B >= 2ll * n_cu) ? 1 : 0;
+  if (a.m16) MG_LAUNCH(flash_attn64_4w_kernel<true>, dim3((unsigned)grid), dim3(256), LDS, s, a);   // the stream on 16x16x32 MFMAs (variant 27)
+  else MG_LAUNCH(flash_attn64_4w_kernel<false>, dim3((unsigned)grid), dim3(256), LDS, s, a);
   return 0;
 }

@@ -16,6 +16,7 @@ struct FaArgs {
   void* ws;                  // flash4w.hip: workspace of the key-split blocks (tickets + partial results), or null: no split
   long long ws_bytes;
   int split;                 // 0: split the left-over blocks when it pays, 1: always (tests), 2: never
+  int m16;                   // flash4w.hip: the key loop on 16x16x32 MFMAs (variant 27) instead of 32x32x16 (26); < 0: by shape
   int n_full, n_rem, n_rem_wg;   // (set by mg_launch_flash4w) whole blocks, split blocks, workgroups over the split blocks
 };
 

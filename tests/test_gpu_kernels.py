@@ -1428,8 +1428,9 @@ def test_flash_attn64_running_max_paths(dev, case):
 @pytest.mark.parametrize("B,heads,T", [(1, 1, 256), (2, 2, 512), (1, 5, 1024), (1, 2, 2304), (2, 1, 768), (13, 5, 1024), (3, 23, 1280)])
 @pytest.mark.parametrize("redo_thr", [0.0, 1e-30])
 @pytest.mark.parametrize("split", [False, True])
-def test_flash_attn64_hand_placed(dev, B, heads, T, redo_thr, split):
-    """Variant 26 (flash4w.hip: 64 queries per wave, the key loop as one hand-placed instruction stream, softmax against the
+@pytest.mark.parametrize("variant", [26, 27], ids=["mfma32x32x16", "mfma16x16x32"])
+def test_flash_attn64_hand_placed(dev, B, heads, T, redo_thr, split, variant):
+    """Variants 26 / 27 (the key loop on 32x32x16 / on 16x16x32 MFMAs; flash4w.hip: 64 queries per wave, the key loop as one hand-placed instruction stream, softmax against the
     row maximum over the first 32 keys) against fp32 SDPA on the host; ``redo_thr`` = 1e-30 sends every workgroup through its
     running-maximum fallback as well; ``split``: with the workspace, i.e. the blocks of queries beyond a multiple of the CU
     count split along the keys (13 x 5 x 4 = 260 and 3 x 23 x 5 = 345 blocks: whole ones AND pieces in one launch; the small
@@ -1448,9 +1449,9 @@ def test_flash_attn64_hand_placed(dev, B, heads, T, redo_thr, split):
     for rnd in range(3 if split else 1):
         out = torch.full((B, T, C), float("nan"), device=dev, dtype=OP16)
         _run(ops.flash_attn64(qkd, qkd[:, :, C:], vtp, out, B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=T, sq=T * 3 * C,
-                              sk=T * 3 * C, svt=C * T, so=T * C, scale=0.125, variant=26, vt_perm=True, redo_thr=redo_thr,
+                              sk=T * 3 * C, svt=C * T, so=T * C, scale=0.125, variant=variant, vt_perm=True, redo_thr=redo_thr,
                               ws=ws, ws_bytes=ops.FLASH_WS_BYTES if split else 0, split=1 if split else 2))
-        _close(f"flash_attn64/hand-placed/B{B}h{heads}T{T}/thr{redo_thr}/split{int(split)}/{rnd}", out, ref)
+        _close(f"flash_attn64/hand-placed/v{variant}/B{B}h{heads}T{T}/thr{redo_thr}/split{int(split)}/{rnd}", out, ref)
         if split:
             assert int(ws[:4096].view(torch.int32).abs().sum()) == 0, "tickets not back at zero"
             if first is None:
@@ -1497,8 +1498,9 @@ def test_flash_split_handoff_stress(dev):
 
 
 @pytest.mark.parametrize("case", ["all_negative", "late_spike_2^40", "growing_2^90", "spike_past_2^100", "first_tile_spike"])
-def test_flash_attn64_hand_placed_reference_paths(dev, case):
-    """Variant 26 keeps ONE reference per query (the first key tile's row maximum):
+@pytest.mark.parametrize("variant", [26, 27], ids=["mfma32x32x16", "mfma16x16x32"])
+def test_flash_attn64_hand_placed_reference_paths(dev, case, variant):
+    """Variants 26 / 27 keep ONE reference per query (the first key tile's row maximum):
       all_negative     - logits around -60: the reference is the first tile's maximum whatever its sign;
       late_spike_2^40  - some rows' largest logit sits in the last tile, 2^40 above the first tile's: probabilities up to 2^40
                          in the bf16 P operand and the fp32 sums, no fallback;
@@ -1538,8 +1540,8 @@ def test_flash_attn64_hand_placed_reference_paths(dev, case):
         ws = torch.zeros(ops.FLASH_WS_BYTES, dtype=torch.uint8, device=dev) if split else None
         out = torch.full((1, T, C), float("nan"), device=dev, dtype=OP16)
         _run(ops.flash_attn64(qkv, qkv[:, :, C:], vtp, out, B=1, heads=1, Ntok=T, ldq=2 * C, ldo=C, ldvt=T, sq=0, sk=0, svt=0, so=0,
-                              scale=0.125, variant=26, vt_perm=True, ws=ws, ws_bytes=ops.FLASH_WS_BYTES if split else 0, split=1 if split else 2))
-        _close(f"flash_attn64/hand-placed/{case}/split{int(split)}", out, ref)
+                              scale=0.125, variant=variant, vt_perm=True, ws=ws, ws_bytes=ops.FLASH_WS_BYTES if split else 0, split=1 if split else 2))
+        _close(f"flash_attn64/hand-placed/v{variant}/{case}/split{int(split)}", out, ref)
 
 
 def _flash512_run(dev, q, k, v, B, T):

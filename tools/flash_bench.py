@@ -11,11 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from marigold_amd import _lib as L, ops as O  # noqa: E402
 
-VARIANTS = tuple(int(v) for v in os.environ.get("FLASH_VARIANTS", "25,26,27").split(","))
+VARIANTS = tuple(int(v) for v in os.environ.get("FLASH_VARIANTS", "25,26,27,126,127").split(","))
 ROUNDS = int(os.environ.get("FLASH_ROUNDS", "5"))
 dev = torch.device("cuda:0")
 L.init(0)
 WS = torch.zeros(O.FLASH_WS_BYTES, dtype=torch.uint8, device=dev)
+HP = (26, 27, 126, 127)   # the hand-placed stream on 32x32x16 / 16x16x32 MFMAs; + 100: with the key-split workspace
 
 
 def timeit(fn, warm=1, iters=4):
@@ -34,7 +35,7 @@ def timeit(fn, warm=1, iters=4):
 def case(B, heads, T, qscale=1.0):
     global VARIANTS
     all_variants = VARIANTS
-    VARIANTS = tuple(v for v in VARIANTS if v not in (26, 27) or (T % 256 == 0 and T >= 256))   # the hand-placed form's shapes
+    VARIANTS = tuple(v for v in VARIANTS if v not in HP or (T % 256 == 0 and T >= 256))   # the hand-placed form's shapes
     try:
         _case(B, heads, T, qscale)
     finally:
@@ -59,22 +60,22 @@ def _case(B, heads, T, qscale=1.0):
     outs, ops, times = {}, {}, {v: [] for v in VARIANTS}
     for v in VARIANTS:
         outs[v] = torch.full((B, T, C), float("nan"), device=dev, dtype=torch.bfloat16)
-        vv = 26 if v == 27 else v     # 27 = variant 26 with the key-split workspace
-        ops[v] = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25, 26, 27)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
-                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=vv, vt_perm=(v in (19, 20, 25, 26, 27)),
-                                ws=WS if v == 27 else None, ws_bytes=O.FLASH_WS_BYTES if v == 27 else 0)
+        vv = v - 100 if v > 100 else v
+        ops[v] = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25) or v in HP) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
+                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=vv, vt_perm=(v in (19, 20, 25) or v in HP),
+                                ws=WS if v > 100 else None, ws_bytes=O.FLASH_WS_BYTES if v > 100 else 0)
     for rnd in range(ROUNDS):
         for v in VARIANTS:
             times[v].append(timeit(lambda: O.launch(ops[v])))
     line = f"flash B={B} heads={heads} T={T} qscale={qscale}:"
     if os.environ.get("FLASH_DBG"):   # generation 3 only: shader cycles / wall ticks per workgroup
         for v in VARIANTS:
-            if v in (26, 27):   # the hand-placed form: cycles of the key loop per wave (27: with the key-split workspace)
+            if v in HP:   # the hand-placed form: cycles of the key loop per wave
                 nwg = (T // 256) * heads * B + 1024
                 dbg = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device=dev)
                 op = O.flash_attn64(qkd, qkd[:, :, C:], vtp, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt, sq=T * 3 * C,
-                                    sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=26, vt_perm=True, dbg=dbg,
-                                    ws=WS if v == 27 else None, ws_bytes=O.FLASH_WS_BYTES if v == 27 else 0)
+                                    sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v - 100 if v > 100 else v, vt_perm=True, dbg=dbg,
+                                    ws=WS if v > 100 else None, ws_bytes=O.FLASH_WS_BYTES if v > 100 else 0)
                 O.launch(op)
                 O.launch(op)
                 torch.cuda.synchronize()
@@ -101,7 +102,7 @@ def _case(B, heads, T, qscale=1.0):
             nwg = -(-T // (nw * 32)) * heads * B
             dbg = torch.zeros(nwg * nw * 8, dtype=torch.int64, device=dev)
             op = O.flash_attn64(qkd, qkd[:, :, C:], vtp if (13 <= v <= 20 or v in (22, 23, 25, 26)) else vt, outs[v], B=B, heads=heads, Ntok=T, ldq=3 * C, ldo=C, ldvt=ldvt,
-                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(v in (19, 20, 25, 26, 27)), dbg=dbg)
+                                sq=T * 3 * C, sk=T * 3 * C, svt=C * ldvt, so=T * C, scale=0.125, variant=v, vt_perm=(v in (19, 20, 25, 26)), dbg=dbg)
             O.launch(op)
             O.launch(op)
             torch.cuda.synchronize()
