@@ -160,13 +160,14 @@ class _MarigoldPipelineBase:
     # optimiser's ~80 evaluations per map): a SECOND, independent map on another HIP stream fills those holes (DESIGN.md section 6b;
     # tools/inflight_bench.py: +9 % maps/s at E = 10, every map bit-identical to the one-at-a-time result).  288 GB of HBM hold the
     # second set of workspaces (23 GB at 768 x 768, E = 10) many times over; the weights are shared.
-    # A GPU that holds five members or fewer (small ensembles, the shards of the member-parallel path) has more and longer holes
+    # A GPU that holds eight members or fewer (small ensembles, the shards of the member-parallel path) has more and longer holes
     # per map - its launches are single part-filled rounds - and takes a THIRD lane: same box, interleaved
-    # (profiles/r6_inflight_by_ensemble.log) E = 1 / 2 / 3 / 5: 51.4 / 77.5 / 100.6 / 146.5 ms per map with two lanes,
-    # 45.0 / 70.3 / 95.0 / 143.1 with three (a fourth: 48.4 / 70.7 / 94.2 / 142.4); at E = 10 the third lane buys 0.4 %.
+    # (profiles/r6_inflight_by_ensemble.log) E = 1 / 2 / 3 / 5 / 6 / 8: 51.4 / 77.5 / 100.6 / 146.5 / 172.6 / 211.8 ms per map with two
+    # lanes, 45.0 / 70.3 / 95.0 / 143.1 / 165.7 / 208.2 with three (a fourth: 48.4 / 70.7 / 94.2 / 142.4); at E = 10 the third lane
+    # buys 0.4-0.5 %.
     default_maps_in_flight = 2
     small_ensemble_maps_in_flight = 3
-    small_ensemble_members = 5
+    small_ensemble_members = 8
 
     def maps_in_flight_for(self, ensemble_size: int = 1) -> int:
         """The lane count ``map_images`` uses when the caller names none: by the members THIS GPU runs per map (the ensemble

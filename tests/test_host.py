@@ -600,8 +600,8 @@ def test_map_images_host_logic():
     assert list(it) == [2, 4, 6]
     assert p.seen == [(0, "a", 5), (1, "b", 5), (2, "c", 5), (3, "d", 5)]
     assert list(p.map_images([1, 2], in_flight=1, generator="g")) == [2, 4]     # a shared generator is fine one map at a time
-    # default lane count: by the members this GPU runs per map (three lanes up to five members, two beyond)
-    assert [p.maps_in_flight_for(e) for e in (1, 5, 6, 10)] == [3, 3, 2, 2]
+    # default lane count: by the members this GPU runs per map (three lanes up to eight members, two beyond)
+    assert [p.maps_in_flight_for(e) for e in (1, 5, 8, 9, 10)] == [3, 3, 3, 2, 2]
     with pytest.raises(ValueError):
         p.map_images([1, 2, 3], generators=["a"])
     with pytest.raises(ValueError):
