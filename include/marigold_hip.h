@@ -127,7 +127,8 @@ enum mg_op_kind {
    *  l[0] q batch stride l[1] k batch stride l[2] vt batch stride l[3] o batch stride;
    *  f[0] softmax scale.
    *  With i[7] = 1 and Ntok % 256 == 0 (>= 256) the current kernel is the hand-placed one (flash4w.hip; variant 26 forces
-   *  it): softmax against a fixed per-query reference, exact, with an in-kernel running-maximum fallback for rows whose sums
+   *  its 32x32x16-MFMA stream, 27 the 16x16x32 one with the row sums on the matrix pipe - chosen by itself at >= 4 096 tokens
+   *  from two blocks of 256 queries per CU): softmax against a fixed per-query reference, exact, with an in-kernel running-maximum fallback for rows whose sums
    *  reach f[1] (0 = 2^100; tests force the fallback with a tiny value).  Optional p[5]: workspace (16-byte aligned, i[8] KB,
    *  ZEROED once by the caller, then owned by this op's launches on ONE stream - tickets return to zero): the blocks of 256
    *  queries left over beyond a multiple of the CU count are then split along the keys over the chip (bit-reproducible);
